@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pair-interactions/s of the direct O(N^2) leapfrog step on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one LeapFrogSimulator.step() (kick-drift, one all-pairs force evaluation, kick) on a
+seeded Plummer sphere already resident in HBM. Workload: 65 536 particles PER GPU, i.e.
+BASELINE.json configs[1] at N=1 (65 536 bodies, one MI355X) and configs[4] at N=8 (524 288 bodies
+range-sharded over 8 GPUs with one RCCL all-gather of positions per step). pairs/step = n_total^2
+(the reference evaluates every (i,j) incl. i=j, simulation.py:80-88), one force evaluation per step.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "nbody-deep-sim_amd"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+FLOP_PER_PAIR = 20.0            # customary all-pairs count
+PEAK_FP32_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 vector peak (= fp32 MFMA peak)
+PARTICLES_PER_GPU = 65536
+
+
+def cpu_baseline(n, seed, budget_s, threads):
+    """The reference's torch-CPU algorithm (row-blocked port, oracle/galaxify_oracle.py) timed on
+    this host on a bounded sample: the force on the first R target rows against all n sources."""
+    import torch
+    from nbd.plummer import generate_plummer
+    from oracle import galaxify_oracle as go
+    torch.set_num_threads(threads)
+    p, v, m = generate_plummer(n, seed=seed)
+    pos = torch.tensor(p, dtype=torch.float32)
+    mass = torch.tensor(m, dtype=torch.float32)
+    go.accelerations(pos, mass, 1.0, 0.1, block=256, tgt_slice=slice(0, 256))       # warm-up
+    t0 = time.perf_counter()
+    go.accelerations(pos, mass, 1.0, 0.1, block=512, tgt_slice=slice(0, 1024))
+    t_probe = time.perf_counter() - t0
+    rows = int(min(n, max(1024, 1024 * (budget_s / max(t_probe, 1e-6)))))
+    rows = max(512, (rows // 512) * 512)
+    t0 = time.perf_counter()
+    go.accelerations(pos, mass, 1.0, 0.1, block=512, tgt_slice=slice(0, rows))
+    dt = time.perf_counter() - t0
+    return {"value": rows * n / dt, "unit": "pair-interactions/s", "cores": threads, "kind": "port",
+            "sample": f"force on the first {rows} of {n} targets x all {n} sources (Plummer, fp32), "
+                      f"row-blocked torch-CPU port of simulation.py:80-88, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--particles-per-gpu", type=int, default=PARTICLES_PER_GPU)
+    ap.add_argument("--n-total", type=int, default=0, help="fix the TOTAL particle count (strong scaling)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables")
+    ap.add_argument("--seed", type=int, default=1234)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from galaxify import simulation
+    from nbd import direct
+    from nbd.plummer import generate_plummer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with `python -m torch.distributed.run "
+                     "--nproc-per-node N ...` (one process per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL
+        group = dist.group.WORLD
+
+    n_total = args.n_total or args.particles_per_gpu * world
+    strong = bool(args.n_total)
+    p, v, m = generate_plummer(n_total, seed=args.seed)
+    sim = simulation.LeapFrogSimulator(positions=p, velocities=v, masses=m, g_const=1.0, softening=0.1,
+                                       dt=0.01, calc_energy=False, device="cuda", process_group=group)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sim.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # roofline leg (every rank runs it to stay in lock-step; rank 0 reports): HIP events on the
+    # launch stream around the force kernel of K further steps
+    evs = []
+    for _ in range(args.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); e1.record()                       # creates the hipEvent_t handles
+        if world == 1:
+            new_acc = torch.empty_like(sim.accelerations)
+            direct.leapfrog_step(sim.positions, sim.velocities, sim.accelerations, new_acc, sim.masses,
+                                 direct.f32(0.5 * sim.dt), direct.f32(sim.dt), sim._eps2, sim._g,
+                                 sim._posm, sim._ws, ev_begin=e0, ev_end=e1)
+            sim.accelerations = new_acc
+        else:                                          # sharded step: events around force(+finish)
+            half, dt = direct.f32(0.5 * sim.dt), direct.f32(sim.dt)
+            direct.kick_drift(sim.positions, sim.velocities, sim.accelerations, sim._mass_local, half, dt,
+                              posm=sim._posm_local)
+            sim._exchange()
+            e0.record()
+            sim.accelerations = sim._force()
+            e1.record()
+            direct.kick(sim.velocities, sim.accelerations, half)
+        evs.append((e0, e1))
+    barrier()
+    k_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+    assert torch.isfinite(sim.positions).all()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    pairs_per_step = float(n_total) * float(n_total)
+    value = pairs_per_step * args.steps / elapsed
+    n_loc = sim.part.n_local
+    pairs_per_launch = float(n_loc) * float(n_total)
+    achieved = pairs_per_launch * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and world == 1 and not strong:
+        traffic = json.load(open(tpath)).get("accel_kernel_hbm_bytes_per_launch")
+    plan = direct.accel_plan(n_total, n_loc)
+    out = {
+        "metric": "pair-interactions/sec, direct O(N^2) leapfrog N-body, fp32",
+        "value": value, "unit": "pair-interactions/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"Plummer sphere, {n_total} particles, direct all-pairs leapfrog step "
+                        f"(BASELINE configs[{1 if world == 1 else 4}] shape: {args.particles_per_gpu} bodies per GPU)"
+                        if not strong else f"Plummer sphere, {n_total} particles total (strong scaling)",
+            "n_particles": n_total, "particles_per_gpu": n_loc, "g_const": 1.0, "softening": 0.1, "dt": 0.01,
+            "seed": args.seed, "pairs_per_step": pairs_per_step,
+            "parallelism": "single GPU" if world == 1 else
+                           f"range partition x{world}, one RCCL all-gather of float4[{n_loc}] per rank per step",
+            "launch_plan": plan,
+        },
+        "roofline": {
+            "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+            "kernel": "accel_kernel<false>", "kernel_ms": k_ms, "flop_per_pair": FLOP_PER_PAIR,
+            "pairs_per_launch": pairs_per_launch,
+            "note": "fp32 VALU-issue bound (no dense contraction: MFMA not applicable); peak = fp32 vector "
+                    "peak = fp32 MFMA peak. Issue ceiling is 2 pairs/clk/SIMD = 62% of this peak at 2.4 GHz",
+        },
+    }
+    if args.cpu_seconds > 0 and world == 1:
+        threads = min(len(os.sched_getaffinity(0)), 16)
+        out["cpu_baseline"] = cpu_baseline(min(n_total, 65536), args.seed, args.cpu_seconds, threads)
+    elif world > 1:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,229 @@
+"""MI355X drop-in for the reference integrator module (src/galaxify/simulation.py).
+
+Same public surface -- SimulationState, BaseSimulator, LeapFrogSimulator, EulerSimulator with
+the kw-only constructor, attributes (positions, velocities, accelerations, masses, n, dt,
+g_const, softening, calc_energy, device) and methods step()/run()/compute_accelerations()/
+compute_energies() -- but every O(N^2)/O(N) update runs in hand-written HIP kernels
+(csrc/direct_force.hip) through the C-ABI of include/nbd.h. There is no CPU path: device="cpu"
+or a missing libnbd_hip.so raises.
+
+Addition over the reference (which has no distributed code): `process_group=` range-partitions
+the bodies over the ranks of a torch.distributed group (one process per GPU, RCCL over xGMI);
+positions/velocities/accelerations then hold the local shard [lo, hi) and `gather()` assembles
+the global arrays. See nbd/dist.py and DESIGN.md.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from nbd import _lib, direct
+from nbd import dist as nbd_dist
+
+
+@dataclass
+class SimulationState:
+    """Snapshot of one step; field names and order as simulation.py:8-18."""
+
+    step: int
+    step_time: float
+    positions: torch.Tensor
+    velocities: torch.Tensor
+    accelerations: torch.Tensor
+    u_energy: float = None
+    k_energy: float = None
+
+
+def _to_f32(x, device) -> torch.Tensor:
+    # simulation.py:58-65 makes fp32 device copies with torch.tensor(...)
+    if isinstance(x, torch.Tensor):
+        return x.detach().to(device=device, dtype=torch.float32, copy=True).contiguous()
+    return torch.tensor(np.asarray(x), dtype=torch.float32, device=device).contiguous()
+
+
+class BaseSimulator:
+    def __init__(self, *, positions, velocities, masses, g_const: float = 1.0, softening: float = 0.1,
+                 dt: float = 0.01, calc_energy: bool = True, device: str = None, process_group=None):
+        # device rule of simulation.py:46-51 ("cuda" is PyTorch-ROCm's name for the MI355X)
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("galaxify (MI355X build): no GPU visible and there is no CPU path")
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        elif device == "cuda":
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        elif device == "cpu":
+            raise RuntimeError("galaxify (MI355X build): device='cpu' is not provided by this build; "
+                               "the HIP kernels are the only compute path (use the reference for CPU)")
+        else:
+            raise ValueError("device debe ser 'cuda', 'cpu' o None")
+        _lib.lib()  # fail now, loudly, if the extension is not built
+
+        self.dt = dt
+        self.g_const = g_const
+        self.softening = softening
+        self.calc_energy = calc_energy
+        # fp32 scalars exactly as torch forms them from the Python doubles (simulation.py:82,88,164)
+        self._eps2 = direct.f32(softening ** 2)
+        self._g = direct.f32(g_const)
+
+        full_pos = _to_f32(positions, self.device)
+        full_vel = _to_f32(velocities, self.device)
+        self.masses = _to_f32(masses, self.device)
+        self.n = full_pos.shape[0]
+        if full_pos.shape != (self.n, 3) or full_vel.shape != (self.n, 3) or self.masses.shape != (self.n,):
+            raise ValueError("positions/velocities must be (n,3) and masses (n,)")
+
+        world, rank = nbd_dist.group_info(process_group) if process_group is not None else (1, 0)
+        self.process_group = process_group
+        self.part = nbd_dist.RangePartition(self.n, world, rank)
+        lo, hi = self.part.lo, self.part.hi
+        self.positions = full_pos[lo:hi].clone() if world > 1 else full_pos
+        self.velocities = full_vel[lo:hi].clone() if world > 1 else full_vel
+        self.accelerations = None
+
+        # scratch owned by the simulator: packed sources (all ranks' bodies), slabs, energy partials
+        self._posm = direct.alloc_posm(self.n, self.device)
+        self._posm.zero_()
+        self._ws = direct.step_workspace(max(self.n, 1), self.device) if world == 1 else \
+            direct.accel_workspace(self.n, self.part.n_local, self.device)
+        self._gather_scratch = None
+        self._posm_local = direct.alloc_posm(self.part.n_local, self.device) if world > 1 else None
+        self._mass_local = self.masses[lo:hi].contiguous() if world > 1 else self.masses
+
+        self.accelerations = self.compute_accelerations()
+
+    # ------------------------------------------------------------------ force
+    def _refresh_sources(self):
+        """posm[:n] = {x,y,z,m} of ALL bodies in global order (one all-gather when sharded)."""
+        if self.part.world_size == 1:
+            direct.pack_posm(self.positions, self.masses, out=self._posm)
+        else:
+            direct.pack_posm(self.positions, self._mass_local, out=self._posm_local)
+            self._exchange()
+
+    def _exchange(self):
+        nbd_dist.allgather_rows(self._posm_local[:self.part.n_local], self.part, self._posm,
+                                group=self.process_group, scratch=self._gather_scratch)
+
+    def _force(self) -> torch.Tensor:
+        p = self.part
+        return direct.accel(self._posm, self.n, self._posm[p.lo:], p.n_local, p.lo, self._eps2, self._g,
+                            workspace=self._ws)
+
+    def compute_accelerations(self) -> torch.Tensor:
+        """a_i = G sum_{j!=i} m_j (r_j - r_i)/(|r_j - r_i|^2 + eps^2)^(3/2) -> new (n_local,3) tensor
+        (simulation.py:71-89)."""
+        if self.n == 0:
+            return torch.zeros((0, 3), dtype=torch.float32, device=self.device)
+        self._refresh_sources()
+        return self._force()
+
+    def compute_energies(self):
+        """(U, K) as Python floats (simulation.py:91-115). Sharded: every rank evaluates the
+        global sums from the gathered state (velocities are gathered for this call)."""
+        if self.n == 0:
+            return 0.0, 0.0
+        self._refresh_sources()
+        vel = self.gather("velocities") if self.part.world_size > 1 else self.velocities
+        uk = direct.energy(self._posm, vel, self.n, direct.f32(self.softening), self._g)
+        u, k = uk.cpu().tolist()
+        return u, k
+
+    def gather(self, name: str) -> torch.Tensor:
+        """Global (n,3) copy of a sharded state array on every rank ('positions', ...)."""
+        local = getattr(self, name)
+        if self.part.world_size == 1:
+            return local
+        out = torch.empty((self.n, 3), dtype=torch.float32, device=self.device)
+        return nbd_dist.allgather_rows(local, self.part, out, group=self.process_group)
+
+    # ------------------------------------------------------------------ run loop
+    def run(self, steps: int) -> list[SimulationState]:
+        """Run `steps` steps and return one SimulationState per step (simulation.py:117-146):
+        CPU clones of the state after the step, the step's time and (if calc_energy) U and K.
+        step_time is the GPU time of step() from HIP events (the reference's un-synchronised
+        time.time() bracket would only time the launches)."""
+        states = []
+        if steps <= 0:
+            return states
+        n_loc = self.part.n_local
+        per_step = 3 * n_loc * 3 * 4
+        chunk = max(1, min(steps, (256 << 20) // max(per_step, 1)))
+        stage = torch.empty((chunk, 3, n_loc, 3), dtype=torch.float32).pin_memory()
+        uk_dev = torch.zeros((chunk, 2), dtype=torch.float64, device=self.device)
+        uk_host = torch.empty((chunk, 2), dtype=torch.float64).pin_memory()
+        done = 0
+        while done < steps:
+            m = min(chunk, steps - done)
+            events = []
+            for s in range(m):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.step()
+                e1.record()
+                events.append((e0, e1))
+                if self.calc_energy:
+                    if self.part.world_size == 1:  # posm already holds the post-drift positions
+                        direct.energy(self._posm, self.velocities, self.n, direct.f32(self.softening),
+                                      self._g, out_uk=uk_dev[s])
+                    else:
+                        u, k = self.compute_energies()
+                        uk_dev[s, 0], uk_dev[s, 1] = u, k
+                stage[s, 0].copy_(self.positions, non_blocking=True)
+                stage[s, 1].copy_(self.velocities, non_blocking=True)
+                stage[s, 2].copy_(self.accelerations, non_blocking=True)
+            uk_host[:m].copy_(uk_dev[:m], non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+            for s in range(m):
+                u, k = (uk_host[s, 0].item(), uk_host[s, 1].item()) if self.calc_energy else (None, None)
+                states.append(SimulationState(
+                    positions=stage[s, 0].clone(), velocities=stage[s, 1].clone(),
+                    accelerations=stage[s, 2].clone(), step=done + s,
+                    step_time=events[s][0].elapsed_time(events[s][1]) * 1e-3, u_energy=u, k_energy=k))
+            done += m
+        return states
+
+    def step(self):
+        raise NotImplementedError("El método step debe ser implementado en la subclase")
+
+
+class LeapFrogSimulator(BaseSimulator):
+    def step(self):
+        """Kick-drift-kick (simulation.py:153-170); one force evaluation per step; positions and
+        velocities are updated in place, `accelerations` is rebound to a new tensor (:168)."""
+        if self.n == 0:
+            return
+        half = direct.f32(0.5 * self.dt)
+        dt = direct.f32(self.dt)
+        if self.part.world_size == 1:
+            new_acc = torch.empty_like(self.accelerations)
+            direct.leapfrog_step(self.positions, self.velocities, self.accelerations, new_acc, self.masses,
+                                 half, dt, self._eps2, self._g, self._posm, self._ws)
+            self.accelerations = new_acc
+            return
+        # sharded: local kick+drift+pack -> one all-gather -> local targets x all sources -> kick
+        direct.kick_drift(self.positions, self.velocities, self.accelerations, self._mass_local, half, dt,
+                          posm=self._posm_local)
+        self._exchange()
+        self.accelerations = self._force()
+        direct.kick(self.velocities, self.accelerations, half)
+
+
+class EulerSimulator(BaseSimulator):
+    def step(self):
+        """a(t) -> v += dt a -> x += dt v (simulation.py:173-187)."""
+        if self.n == 0:
+            return
+        dt = direct.f32(self.dt)
+        if self.part.world_size == 1:
+            new_acc = torch.empty_like(self.accelerations)
+            direct.euler_step(self.positions, self.velocities, new_acc, self.masses, dt, self._eps2,
+                              self._g, self._posm, self._ws)
+            self.accelerations = new_acc
+            return
+        self.accelerations = self.compute_accelerations()
+        direct.kick(self.velocities, self.accelerations, dt)
+        direct.drift(self.positions, self.velocities, dt)

@@ -1,0 +1,99 @@
+"""ctypes loader for libnbd_hip.so (C-ABI: include/nbd.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, the product path
+raises. `build()` compiles it in-tree with hipcc (gfx950); the built .so travels with the
+repo snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+LIB_PATH = os.path.join(CSRC_DIR, "libnbd_hip.so")
+
+
+class NbdError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every .hip under csrc/ into libnbd_hip.so (make is incremental)."""
+    res = subprocess.run(["make", "-C", CSRC_DIR, "-j4"], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise NbdError("building libnbd_hip.so failed (hipcc/make); see output above")
+    return LIB_PATH
+
+
+# name -> (restype, argtypes); mirrors include/nbd.h one to one (tests check the two agree)
+_F = POINTER(c_float)
+SIGNATURES = {
+    "nbd_abi_version": (c_int, []),
+    "nbd_strerror": (c_char_p, [c_int]),
+    "nbd_posm_padded_len": (c_int, [c_int]),
+    "nbd_pack_posm_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "nbd_accel_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "nbd_accel_plan": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "nbd_accel_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_float, c_void_p,
+                              c_void_p, c_size_t, c_void_p]),
+    "nbd_kick_drift_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
+                                   c_void_p, c_void_p]),
+    "nbd_kick_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "nbd_drift_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "nbd_step_workspace_bytes": (c_size_t, [c_int]),
+    "nbd_leapfrog_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_float, c_float, c_float, c_float, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]),
+    "nbd_leapfrog_step_ev_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                         c_float, c_float, c_float, c_float, c_void_p, c_void_p,
+                                         c_size_t, c_void_p, c_void_p, c_void_p]),
+    "nbd_euler_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
+                                   c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nbd_energy_workspace_bytes": (c_size_t, [c_int]),
+    "nbd_energy_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p,
+                               c_size_t, c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library; raises NbdError (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NbdError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                "There is no CPU fallback for this path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if handle.nbd_abi_version() != 1:
+            raise NbdError("libnbd_hip.so ABI version mismatch; rebuild")
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().nbd_strerror(code)
+        raise NbdError(f"{what} failed with code {code}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> int | None:
+    """Device pointer of a torch tensor (None passes NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device=None) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,233 @@
+"""Parity of the HIP direct-force path (through the C-ABI) against (i) the golden vectors the
+real reference produced and (ii) the pinned CPU oracle on seeded inputs; plus size-independent
+properties at BASELINE.json's full size. Tolerance (BASELINE.json north_star): positions and
+velocities within 1e-5 relative after one step, measured per particle on vector norms
+(SURVEY 8c); accelerations are held to the same bound and to 1e-6 globally."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import global_rel, golden_cases, load_golden, row_rel
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5          # per-particle relative (north_star)
+TOL_ACC_GLOBAL = 1e-6
+
+
+def _mk(cls, g, **over):
+    from galaxify import simulation
+    kw = dict(positions=g["pos"], velocities=g["vel"], masses=g["mass"], g_const=float(g["g_const"]),
+              softening=float(g["softening"]), dt=float(g["dt"]), calc_energy=True, device="cuda")
+    kw.update(over)
+    return getattr(simulation, cls)(**kw)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_initial_acceleration(name, gpu_device):
+    g = load_golden(name)
+    sim = _mk("LeapFrogSimulator", g)
+    acc = _np(sim.accelerations)
+    assert np.isfinite(acc).all()
+    assert row_rel(acc, g["acc0"]) < TOL
+    assert global_rel(acc, g["acc0"]) < TOL_ACC_GLOBAL
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_leapfrog_one_step(name, gpu_device):
+    g = load_golden(name)
+    sim = _mk("LeapFrogSimulator", g)
+    old_acc = sim.accelerations
+    pos_ptr = sim.positions.data_ptr()
+    sim.step()
+    assert sim.positions.data_ptr() == pos_ptr            # in place (simulation.py:166)
+    assert sim.accelerations is not old_acc               # rebound (simulation.py:168)
+    for key, t in (("pos", sim.positions), ("vel", sim.velocities), ("acc", sim.accelerations)):
+        assert row_rel(_np(t), g[f"lf1_{key}"]) < TOL, key
+
+
+@pytest.mark.parametrize("name", [n for n in golden_cases() if "4096" not in n])
+def test_golden_leapfrog_ten_steps(name, gpu_device):
+    g = load_golden(name)
+    sim = _mk("LeapFrogSimulator", g)
+    for _ in range(10):
+        sim.step()
+    for key, t in (("pos", sim.positions), ("vel", sim.velocities), ("acc", sim.accelerations)):
+        assert row_rel(_np(t), g[f"lf10_{key}"]) < 10 * TOL, key
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_euler_one_step(name, gpu_device):
+    g = load_golden(name)
+    sim = _mk("EulerSimulator", g)
+    sim.step()
+    for key, t in (("pos", sim.positions), ("vel", sim.velocities), ("acc", sim.accelerations)):
+        assert row_rel(_np(t), g[f"eu1_{key}"]) < TOL, key
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_energies(name, gpu_device):
+    g = load_golden(name)
+    u, k = _mk("LeapFrogSimulator", g).compute_energies()
+    u0, k0 = g["energy0"]
+    assert abs(u - u0) <= 2e-5 * abs(u0) + 1e-30
+    assert abs(k - k0) <= 2e-6 * abs(k0) + 1e-30
+
+
+def test_kick_drift_bit_exact_given_same_acceleration(gpu_device):
+    """The O(N) updates are two-rounding mul+add like torch eager: given identical a(t), the
+    drifted positions and half-kicked velocities match the reference BIT FOR BIT."""
+    from nbd import direct
+    g = load_golden("direct_plummer_n1000")
+    dt = float(g["dt"])
+    pos, vel, acc = (torch.tensor(g[k]) for k in ("pos", "vel", "acc0"))
+    v_ref = vel + 0.5 * dt * acc          # torch CPU eager = the reference's arithmetic
+    x_ref = pos + dt * v_ref
+    p, v, a = pos.cuda(), vel.cuda(), acc.cuda()
+    m = torch.tensor(g["mass"]).cuda()
+    posm = direct.alloc_posm(1000, gpu_device)
+    direct.kick_drift(p, v, a, m, direct.f32(0.5 * dt), direct.f32(dt), posm=posm)
+    assert torch.equal(v.cpu(), v_ref) and torch.equal(p.cpu(), x_ref)
+    assert torch.equal(posm[:1000, :3].cpu(), x_ref) and torch.equal(posm[:1000, 3].cpu(), m.cpu())
+    assert (posm[1000:] == 0).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 129, 500, 2048, 5000])
+def test_ragged_sizes_against_oracle(n, gpu_device):
+    from nbd.plummer import generate_plummer
+    from oracle import galaxify_oracle as go
+    p, v, m = generate_plummer(n, seed=100 + n)
+    rng = np.random.default_rng(n)
+    m = m * rng.uniform(0.5, 2.0, n)
+    g = dict(pos=p, vel=v, mass=m, g_const=1.0, softening=0.1, dt=0.01)
+    sim = _mk("LeapFrogSimulator", g)
+    ora = go.OracleSimulator(positions=p, velocities=v, masses=m)
+    sim.step(); ora.leapfrog_step()
+    for a, b in ((sim.positions, ora.positions), (sim.velocities, ora.velocities),
+                 (sim.accelerations, ora.accelerations)):
+        assert row_rel(_np(a), b.numpy()) < TOL
+
+
+def test_empty_system(gpu_device):
+    z = np.zeros((0, 3))
+    sim = _mk("LeapFrogSimulator", dict(pos=z, vel=z, mass=np.zeros(0), g_const=1.0, softening=0.1, dt=0.01))
+    sim.step()
+    assert sim.accelerations.shape == (0, 3) and sim.run(2)[1].positions.shape == (0, 3)
+
+
+def test_eps0_coincident_bodies_give_nan_like_reference(gpu_device):
+    """softening = 0: only the diagonal is masked (fill_diagonal_, simulation.py:85); two distinct
+    bodies at the same point give 0*inf = NaN in the reference, and here."""
+    pos = np.array([[0., 0, 0], [1, 0, 0], [1, 0, 0], [0, 2, 0]])
+    sim = _mk("LeapFrogSimulator", dict(pos=pos, vel=np.zeros((4, 3)), mass=np.ones(4), g_const=1.0,
+                                        softening=0.0, dt=0.01))
+    acc = _np(sim.accelerations)
+    assert np.isnan(acc[1]).any() and np.isnan(acc[2]).any()
+    assert np.isfinite(acc[0]).all() and np.isfinite(acc[3]).all()
+
+
+def test_tiny_softening_uses_index_mask(gpu_device):
+    """softening**2 underflows/overflows rsq^3 on the diagonal: must still match the oracle."""
+    from nbd.plummer import generate_plummer
+    from oracle import galaxify_oracle as go
+    p, v, m = generate_plummer(200, seed=3)
+    for eps in (1e-14, 1e-30):
+        sim = _mk("LeapFrogSimulator", dict(pos=p, vel=v, mass=m, g_const=1.0, softening=eps, dt=0.01))
+        ref = go.accelerations(torch.tensor(p, dtype=torch.float32), torch.tensor(m, dtype=torch.float32), 1.0, eps)
+        assert row_rel(_np(sim.accelerations), ref.numpy()) < TOL
+
+
+def test_deterministic_and_partition_invariant(gpu_device):
+    """Same inputs -> bit-identical output; a target sub-range with tgt_global_offset equals the
+    same rows of the full evaluation bit for bit when the slab plan is the same, and to rounding
+    otherwise (this is the multi-GPU range partition on one device)."""
+    from nbd import direct
+    from nbd.plummer import generate_plummer
+    n = 4096
+    p, v, m = generate_plummer(n, seed=11)
+    pos = torch.tensor(p, dtype=torch.float32).cuda(); mass = torch.tensor(m, dtype=torch.float32).cuda()
+    posm = direct.pack_posm(pos, mass)
+    a1 = direct.accel(posm, n, posm, n, 0, 0.01, 1.0)
+    a2 = direct.accel(posm, n, posm, n, 0, 0.01, 1.0)
+    assert torch.equal(a1, a2)
+    parts = []
+    for r in range(4):
+        lo = r * 1024
+        parts.append(direct.accel(posm, n, posm[lo:], 1024, lo, 0.01, 1.0))
+    assert row_rel(_np(torch.cat(parts)), _np(a1)) < 2e-6
+    # masked kernel: the offset decides which pair is the diagonal
+    a0 = direct.accel(posm, n, posm, n, 0, 0.0, 1.0)
+    b = torch.cat([direct.accel(posm, n, posm[r * 1024:], 1024, r * 1024, 0.0, 1.0) for r in range(4)])
+    assert torch.isfinite(a0).all() and row_rel(_np(b), _np(a0)) < 2e-6
+
+
+def test_linearity_in_mass_and_g(gpu_device):
+    """a is linear in the source masses and in G: size-independent property, no oracle needed."""
+    from nbd import direct
+    from nbd.plummer import generate_plummer
+    n = 65536
+    p, v, m = generate_plummer(n, seed=1234)
+    pos = torch.tensor(p, dtype=torch.float32).cuda(); m1 = torch.tensor(m, dtype=torch.float32).cuda()
+    a = direct.accel(direct.pack_posm(pos, m1), n, direct.pack_posm(pos, m1), n, 0, 0.01, 1.0)
+    b = direct.accel(direct.pack_posm(pos, 2 * m1), n, direct.pack_posm(pos, m1), n, 0, 0.01, 0.5)
+    assert torch.equal(a, b)       # scaling by powers of two is exact in fp32
+
+
+def test_full_size_momentum_and_rows_against_f64(gpu_device):
+    """BASELINE config 2 (N = 65 536 Plummer): total momentum change sum_i m_i a_i vanishes
+    (Newton's third law) to fp32 summation noise, and 64 sampled rows match an fp64 evaluation."""
+    from nbd.plummer import generate_plummer
+    n = 65536
+    p, v, m = generate_plummer(n, seed=1234)
+    sim = _mk("LeapFrogSimulator", dict(pos=p, vel=v, mass=m, g_const=1.0, softening=0.1, dt=0.01))
+    acc = _np(sim.accelerations).astype(np.float64)
+    pf, mf = p.astype(np.float32).astype(np.float64), m.astype(np.float32).astype(np.float64)
+    net = (mf[:, None] * acc).sum(0)
+    assert np.abs(net).max() < 1e-6 * (mf[:, None] * np.abs(acc)).sum(0).max()
+    rows = np.random.default_rng(0).choice(n, 64, replace=False)
+    d = pf[None, :, :] - pf[rows, None, :]
+    q = (d * d).sum(2) + float(np.float32(0.1 ** 2))
+    inv = q ** -1.5
+    inv[np.arange(64), rows] = 0.0
+    ref = (d * (inv * mf[None, :])[:, :, None]).sum(1)
+    assert row_rel(acc[rows], ref) < 2e-6
+    # one full step stays finite and moves positions by O(dt*v)
+    x0 = _np(sim.positions).copy()
+    sim.step()
+    dx = np.linalg.norm(_np(sim.positions) - x0, axis=1)
+    assert np.isfinite(dx).all() and 1e-4 < np.median(dx) < 1e-2
+
+
+def test_run_returns_reference_shaped_states(gpu_device):
+    g = load_golden("direct_plummer_n64")
+    sim = _mk("LeapFrogSimulator", g)
+    states = sim.run(10)
+    assert len(states) == 10 and [s.step for s in states] == list(range(10))
+    s = states[-1]
+    assert s.positions.device.type == "cpu" and s.positions.dtype == torch.float32
+    assert isinstance(s.u_energy, float) and isinstance(s.k_energy, float) and s.step_time > 0
+    assert row_rel(s.positions.numpy(), g["lf10_pos"]) < 10 * TOL
+    assert row_rel(states[0].positions.numpy(), g["lf1_pos"]) < TOL
+    # energy is that of the state after the step; drift of total energy over 10 steps is small
+    e = [st.u_energy + st.k_energy for st in states]
+    assert abs(e[-1] - e[0]) < 1e-3 * abs(e[0])
+    sim2 = _mk("LeapFrogSimulator", g, calc_energy=False)
+    assert sim2.run(2)[0].u_energy is None
+
+
+def test_base_step_not_implemented(gpu_device):
+    g = load_golden("direct_spiral_n3")
+    with pytest.raises(NotImplementedError):
+        _mk("BaseSimulator", g).step()
+
+
+def test_tensor_inputs_are_copied(gpu_device):
+    g = load_golden("direct_spiral_n25")
+    pos = torch.tensor(g["pos"], device="cuda")
+    sim = _mk("LeapFrogSimulator", g, positions=pos)
+    sim.step()
+    assert torch.equal(pos.cpu(), torch.tensor(g["pos"]))       # caller's tensor untouched
