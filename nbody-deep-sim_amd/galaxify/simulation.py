@@ -44,21 +44,25 @@ def _to_f32(x, device) -> torch.Tensor:
     return torch.tensor(np.asarray(x), dtype=torch.float32, device=device).contiguous()
 
 
+def _resolve_device(device) -> torch.device:
+    """Device rule of simulation.py:46-51 ("cuda" is PyTorch-ROCm's name for the MI355X), minus
+    the CPU branch: this build has no CPU compute path."""
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("galaxify (MI355X build): no GPU visible and there is no CPU path")
+        return torch.device("cuda", torch.cuda.current_device())
+    if device == "cuda":
+        return torch.device("cuda", torch.cuda.current_device())
+    if device == "cpu":
+        raise RuntimeError("galaxify (MI355X build): device='cpu' is not provided by this build; "
+                           "the HIP kernels are the only compute path (use the reference for CPU)")
+    raise ValueError("device debe ser 'cuda', 'cpu' o None")
+
+
 class BaseSimulator:
     def __init__(self, *, positions, velocities, masses, g_const: float = 1.0, softening: float = 0.1,
                  dt: float = 0.01, calc_energy: bool = True, device: str = None, process_group=None):
-        # device rule of simulation.py:46-51 ("cuda" is PyTorch-ROCm's name for the MI355X)
-        if device is None:
-            if not torch.cuda.is_available():
-                raise RuntimeError("galaxify (MI355X build): no GPU visible and there is no CPU path")
-            self.device = torch.device("cuda", torch.cuda.current_device())
-        elif device == "cuda":
-            self.device = torch.device("cuda", torch.cuda.current_device())
-        elif device == "cpu":
-            raise RuntimeError("galaxify (MI355X build): device='cpu' is not provided by this build; "
-                               "the HIP kernels are the only compute path (use the reference for CPU)")
-        else:
-            raise ValueError("device debe ser 'cuda', 'cpu' o None")
+        self.device = _resolve_device(device)
         _lib.lib()  # fail now, loudly, if the extension is not built
 
         self.dt = dt

@@ -11,6 +11,12 @@ import os
 import subprocess
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER
 
+# torch must be imported BEFORE libnbd_hip.so is dlopen'ed: torch ships its own libamdhip64 /
+# libhsa-runtime64 under torch/lib with the same sonames as /opt/rocm/lib. Whichever is loaded
+# first satisfies both; if ours pulled in /opt/rocm's copy first, torch would bring up a second
+# HSA runtime in the process and every HIP call from here fails with hipErrorNoDevice (100).
+import torch  # noqa: F401  (load order matters, see above)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 LIB_PATH = os.path.join(CSRC_DIR, "libnbd_hip.so")
