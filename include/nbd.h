@@ -116,6 +116,78 @@ size_t nbd_energy_workspace_bytes(int n);
 int nbd_energy_f32(const float* posm, const float* vel, int n, float softening, float g_const,
                    double* out_uk, void* workspace, size_t workspace_bytes, nbd_stream_t stream);
 
+/* ------------------------------------------------------------ surrogate models: graph build
+ * Replace the torch_cluster kernels the reference reaches through PyG. Index-exact rule (the
+ * reference delegates ties/truncation to torch_cluster; fixed here, see oracle/surrogate_oracle.py):
+ * d2 = (dx*dx + dy*dy) + dz*dz in fp32; edges grouped by centre, ascending centre index;
+ * edge_index[0] = neighbour j, edge_index[1] = centre i, both int64, row stride = num_edges.
+ * seg_lo/seg_hi (both NULL or both given, int32 per node): candidate range = the node's batch
+ * segment, replacing PyG's `batch` vector. */
+
+/* knn_graph(pos, k, batch, loop) -- gnn.py:13, datautils.py:36. Per centre the k smallest (d2, j),
+ * ties -> lower j, ascending. out_off[i] = first edge slot of centre i (NULL: i * min(k, n - !loop)).
+ * k <= 256. */
+int nbd_knn_graph_f32(const float* pos, int n, int k, int loop, const int* seg_lo, const int* seg_hi,
+                      const int64_t* out_off, int64_t num_edges, int64_t* edge_index, nbd_stream_t stream);
+
+/* radius_graph(pos, r, batch, loop, max_num_neighbors) -- contconv.py:225 -- in padded (ELL) form:
+ * nbr[i][0..deg[i]) = the first max_num_neighbors indices j (ascending) with d2 < radius_sq
+ * (strict), j == i iff loop; last[i] = the largest listed j (-1 if none). No host sync needed. */
+int nbd_radius_search_f32(const float* pos, int n, float radius_sq, int loop, int max_num_neighbors,
+                          const int* seg_lo, const int* seg_hi, int* nbr, int* deg, int* last,
+                          nbd_stream_t stream);
+
+/* Transposed adjacency of those capped lists: indeg[j] = number of centres c whose list holds j;
+ * after an exclusive scan, centres[rowptr[j] ..] = those c, ascending. This is the grouping
+ * ContinuousConv aggregates over (scatter by edge_index[0], contconv.py:82,95-97). */
+int nbd_radius_transpose_count_f32(const float* pos, int n, float radius_sq, int loop, const int* seg_lo,
+                                   const int* seg_hi, const int* last, int* indeg, nbd_stream_t stream);
+int nbd_radius_transpose_fill_f32(const float* pos, int n, float radius_sq, int loop, const int* seg_lo,
+                                  const int* seg_hi, const int* last, const int* rowptr, int* centres,
+                                  nbd_stream_t stream);
+
+/* ptr[0] = 0, ptr[i+1] = ptr[i] + counts[i]  (int32, n counts -> n+1 entries). */
+int nbd_exclusive_scan_i32(const int* counts, int n, int* ptr, nbd_stream_t stream);
+
+/* ELL lists -> compact int64 edge_index[2][num_edges] (what radius_graph returns). */
+int nbd_ell_to_edge_index(const int* nbr, const int* deg, const int* ptr, int n, int cap, int64_t num_edges,
+                          int64_t* edge_index, nbd_stream_t stream);
+
+/* ------------------------------------------------------------ surrogate models: dense blocks */
+
+/* y[r][c] = act( rowscale[r] * sum_k x[r][k] w[c][k]  +  bias_rowscale[r] * bias[c] ),
+ * act 0 = identity, 1 = tanh; bias, rowscale, bias_rowscale may be NULL (= 0, 1, 1).
+ * torch.nn.Linear layout (w is out x in); ld* are row strides in floats, so inputs/outputs may be
+ * column slices of wider buffers (replaces torch.cat). fp32-input MFMA, exact fp32 arithmetic.
+ * Used for gnn.py:57-63,75-93,105-114 and contconv.py:92,136-141,206-216. */
+int nbd_linear_f32(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* rowscale,
+                   const float* bias_rowscale, int act, float* y, int ldy, int n_rows, int n_cols, int k,
+                   nbd_stream_t stream);
+
+/* EdgeConv aggregation (gnn.py:75-93) after the per-node factoring of its first Linear:
+ * pq[i] = [P_i (h) | Q_i (h)], s[i] = aggr_j tanh(P_i + Q_j) over the edges of target i, i.e.
+ * src[rowptr[i] .. rowptr[i+1]) (rowptr NULL: exactly fixed_k edges per node, i*fixed_k ..).
+ * aggr 0 = sum, 1 = mean (sum / max(count,1)), 2 = max (no edges -> 0). */
+int nbd_edgeconv_aggregate_f32(const float* pq, int ldpq, int h, const int* rowptr, const int64_t* src,
+                               int fixed_k, int n, int aggr, float* s, int lds, nbd_stream_t stream);
+
+/* torch.nn.LayerNorm over the last dim (gnn.py:146, contconv.py:233); gamma/beta may be NULL. */
+int nbd_layernorm_f32(const float* x, int ldx, int c, const float* gamma, const float* beta, float eps, float* y,
+                      int ldy, int n, nbd_stream_t stream);
+
+/* ContinuousConv.forward (contconv.py:80-98) feature-side binning:
+ * a_out[n][cell][i] = sum over edges e with edge_index[0][e] == n of
+ *      window_e * trilinear_weight_e(cell) * feat[centre_e][i],   cell = (z*D + y)*D + x,
+ * window/ball_to_cube/grid_sample(align_corners=True) exactly as contconv.py:30-33,53-78,85-90, so
+ * that ContinuousConv = scatter_mean(...) = rowscale * (a_out . filters.reshape(D^3*I, O)).
+ * rowptr/centres: CSR by aggregation target (nbd_radius_transpose_*). D <= 8. */
+int nbd_contconv_bin_f32(const float* pos, const float* feat, int ldf, int in_channels, const int* rowptr,
+                         const int* centres, int n, int filter_resolution, float radius_sq, float* a_out,
+                         nbd_stream_t stream);
+
+/* scale[i] from the CSR degree d_i: mode 0 = 1/max(d,1), 1 = d, 2 = (d > 0). */
+int nbd_degree_scale_f32(const int* rowptr, int n, int mode, float* scale, nbd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

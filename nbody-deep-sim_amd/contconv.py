@@ -1,0 +1,171 @@
+"""MI355X drop-in for the reference's contconv.py: `ContinuousConv` and `ContinuousConvModel` with
+the same constructor arguments, attributes (`neighbors` = 0, `radius`, ...), parameter names
+(`contconv.{l}.filters`, `node_encoder.lins/norms.*`, `layer_norm.*`, `output.*`) and inference
+methods `forward(data)`, `predict(pos, feat)`, `eval_graph_batch(data)`.
+
+HIP pipeline per forward (csrc/graph.hip, csrc/nn.hip):
+  radius_graph(loop=self_loops, max_num_neighbors=32) -> nbd_radius_search_f32 + transpose (CSR by
+      edge_index[0], the index the reference aggregates over, contconv.py:82,95)
+  node encoder (PyG MLP, BatchNorm folded for eval)   -> nbd_linear_f32 (+tanh)
+  ContinuousConv layer  -> nbd_contconv_bin_f32: A[n][cell][i] = sum_e window_e t_cell(e) feat[c_e][i]
+                           nbd_linear_f32: tanh( (1/deg_n) * A . filters.reshape(D^3 I, O) )   [fp32 MFMA]
+  LayerNorm + decoder   -> nbd_layernorm_f32 + nbd_linear_f32
+The trilinear blend of contconv.py:53-78 is linear in the filter, so it is applied to the features
+(8 weighted copies per edge) instead of to the (I x O) filters; the contraction with the filters then
+becomes one dense GEMM and the (E, I, O) tensor (34 GB at N = 16 384) is never formed.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from gnn import MLP, _WeightCache, head_chain, run_chain, transform_to_graph  # noqa: F401  (same import as contconv.py:6)
+from nbd import graphops, nnops
+from nbd._lib import NbdError
+
+
+class ContinuousConv(nn.Module):
+    def __init__(self, in_channels, out_channels, filter_resolution=4, radius=0.5, agg="mean"):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.radius, self.agg = radius, agg
+        self.filter_resolution = filter_resolution
+        if agg not in ("mean", "sum", "add"):
+            raise NotImplementedError(f"agg={agg!r}: the feature-side binning needs a linear aggregation")
+        self.filters = nn.Parameter(torch.randn(filter_resolution, filter_resolution, filter_resolution,
+                                                in_channels, out_channels))            # contconv.py:20-28
+
+    def weight_t(self):
+        """filters (D,D,D,I,O) -> (O, D^3*I): the `w` operand of nbd_linear_f32, k = ((z*D+y)*D+x)*I + i."""
+        d, i, o = self.filter_resolution, self.in_channels, self.out_channels
+        return self.filters.detach().reshape(d * d * d * i, o).t().contiguous()
+
+    def forward(self, positions, features, edge_index=None, lists=None, act=None, out=None, wt=None):
+        """contconv.py:80-98. Give either the sync-free `lists` (graphops.radius_lists) or a PyG-style
+        edge_index [2,E] (row 0 = aggregation target, row 1 = feature source)."""
+        n = positions.shape[0]
+        if lists is not None:
+            rowptr, centres = lists.rowptr, lists.centres
+        else:
+            row, col = edge_index[0], edge_index[1]
+            order = torch.sort(row, stable=True).indices
+            centres = col[order].to(torch.int32).contiguous()
+            rowptr = torch.zeros(n + 1, dtype=torch.int32, device=positions.device)
+            rowptr[1:] = torch.cumsum(torch.bincount(row, minlength=n), 0).to(torch.int32)
+            if centres.numel() == 0:
+                centres = torch.zeros(1, dtype=torch.int32, device=positions.device)
+        r2 = float(np.float32(self.radius ** 2))                       # contconv.py:86: python double -> fp32
+        a = nnops.contconv_bin(positions.contiguous(), features, rowptr, centres, self.filter_resolution, r2)
+        scale = nnops.degree_scale(rowptr, n, 0, positions.device) if self.agg == "mean" else None
+        return nnops.linear(a, self.weight_t() if wt is None else wt, None, act=act, out=out, rowscale=scale)
+
+
+class ContinuousConvModel(nn.Module):
+    def __init__(self, in_channels=4, out_channels=3, filter_resolution=[4], radius=0.5, agg="mean",
+                 self_loops=True, continuous_conv_layers=1, continuous_conv_dim=64, continuous_conv_dropout=0.0,
+                 encoder_hiddens=None, encoder_dropout=0.0, decoder_hiddens=None, decoder_dropout=0.0,
+                 device="cuda", scale_factor=1):
+        super().__init__()
+        self.device, self.scale_factor = device, scale_factor
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.encoder_hiddens = encoder_hiddens
+        self.encoder_dropout = encoder_dropout
+        self.decoder_hiddens = decoder_hiddens
+        self.decoder_dropout = decoder_dropout
+        self.continuous_conv_layers = continuous_conv_layers
+        self.continuous_conv_dim = continuous_conv_dim
+        self.continuous_conv_dropout = continuous_conv_dropout
+        self.neighbors = 0                                                           # contconv.py:131
+        self.radius = radius
+        self.self_loops = self_loops
+        self.max_num_neighbors = 32            # PyG radius_graph default; the reference does not override it
+        if not isinstance(filter_resolution, (list, tuple)):
+            # upstream's scalar branch appends to an undefined self.gnns (contconv.py:177,187)
+            raise AttributeError("'ContinuousConvModel' object has no attribute 'gnns' (scalar filter_resolution "
+                                 "is broken in the reference; pass a list)")
+        if encoder_hiddens:                                                          # contconv.py:135-143
+            self.node_encoder = MLP([in_channels] + list(encoder_hiddens) + [continuous_conv_dim],
+                                    dropout=encoder_dropout)                         # PyG default: batch_norm
+        else:
+            self.node_encoder = torch.nn.Identity()
+        self.contconv = nn.ModuleList()                                              # contconv.py:150-173
+        for i in range(continuous_conv_layers):
+            cin = in_channels if (i == 0 and encoder_hiddens is None) else continuous_conv_dim
+            self.contconv.append(ContinuousConv(cin, continuous_conv_dim, filter_resolution[i], self.radius, agg))
+        out_dim = continuous_conv_dim + in_channels if encoder_hiddens is None else continuous_conv_dim * 2
+        self.layer_norm = nn.LayerNorm(out_dim)
+        if decoder_hiddens:                                                          # contconv.py:206-216
+            layers, dims = [], [out_dim] + list(decoder_hiddens) + [out_channels]
+            for i in range(len(dims) - 1):
+                layers.append(nn.Linear(dims[i], dims[i + 1]))
+                if i < len(dims) - 2:
+                    layers.append(nn.Tanh())
+            self.output = nn.Sequential(*layers)
+        else:
+            self.output = nn.Linear(out_dim, out_channels)
+        self._cache = _WeightCache(self)
+        self.to(device)
+
+    def _build_weights(self):
+        enc = self.node_encoder.folded() if isinstance(self.node_encoder, MLP) else None
+        return {"enc": enc, "wt": [layer.weight_t() for layer in self.contconv], "head": head_chain(self.output)}
+
+    def forward(self, data):                                                         # contconv.py:218-234
+        if self.training and (isinstance(self.node_encoder, MLP) and self.node_encoder.has_norm
+                              or self.continuous_conv_dropout > 0 or self.encoder_dropout > 0):
+            raise NotImplementedError("training-mode BatchNorm/dropout is outside this build: call eval() "
+                                      "(predict/eval_graph_batch do)")
+        x7 = data.x
+        if not x7.is_cuda:
+            raise NbdError("ContinuousConvModel.forward: data must live on the GPU (no CPU path)")
+        w = self._cache.get(self._build_weights)
+        n = x7.shape[0]
+        x = torch.cat((x7[:, :3], x7[:, 6:]), dim=-1) if self.in_channels == 4 else x7
+        x = x.to(torch.float32).contiguous()
+        pos = x[:, :3].contiguous()
+        lists = graphops.radius_lists(pos, self.radius, getattr(data, "batch", None), loop=self.self_loops,
+                                      max_num_neighbors=self.max_num_neighbors)
+        c = self.continuous_conv_dim
+        enc_dim = self.in_channels if w["enc"] is None else c
+        cat_buf = torch.empty((n, enc_dim + c), dtype=torch.float32, device=x7.device)
+        enc_view, conv_view = cat_buf[:, :enc_dim], cat_buf[:, enc_dim:]
+        if w["enc"] is None:
+            enc_view.copy_(x)
+        else:
+            run_chain(x, w["enc"], out_last=enc_view)
+        h = enc_view
+        for li, layer in enumerate(self.contconv):
+            last = li == len(self.contconv) - 1
+            h = layer(pos, h, lists=lists, act="tanh", out=conv_view if last else None, wt=w["wt"][li])
+        ln = nnops.layernorm(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
+                             self.layer_norm.eps)
+        return run_chain(ln, w["head"])
+
+    def predict(self, pos, feat):
+        """contconv.py:261-271. (The reference also builds a k=50 kNN graph here that forward() then
+        ignores; that dead work is not reproduced.)"""
+        from nbd.data import Data
+        self.eval()
+        with torch.no_grad():
+            return self.forward(Data(x=torch.cat((pos, feat), dim=-1), batch=None))
+
+    def eval_graph_batch(self, data):
+        self.eval()
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            start = time.time()
+            acc_pred = self.forward(data)
+            torch.cuda.synchronize()
+            end = time.time()
+            mse_loss = torch.nn.functional.mse_loss(acc_pred, data.y, reduction="mean")
+            loss = torch.sqrt(mse_loss)
+        return loss.item(), mse_loss.item(), end - start
+
+    def compute_loss(self, data):
+        raise NotImplementedError("training (contconv.py:236-247) is outside this build: forward-only HIP kernels")
+
+    train_graph_batch = compute_loss

@@ -1,0 +1,268 @@
+// graph.hip -- neighbour search for the surrogate models, gfx950 (MI355X).
+//
+// Replaces the third-party kernels the reference reaches through PyG: torch_cluster.knn behind
+// knn_graph (gnn.py:13, datautils.py:36) and torch_cluster.radius behind radius_graph
+// (contconv.py:225). Index-exact specification (restated in oracle/surrogate_oracle.py):
+//   d2 = (dx*dx + dy*dy) + dz*dz in fp32 (no FMA);
+//   kNN:    k smallest (d2, j) per centre, ties -> lower j, listed ascending; self excluded unless loop
+//   radius: the first `cap` indices j (ascending) with d2 < r2 strictly; self included iff loop
+//   both restricted to the centre's batch segment [seg_lo, seg_hi).
+// Structure: ONE WAVE PER CENTRE. The 64 lanes test 64 candidates per step (coalesced reads of the
+// L2-resident position array); decisions are made with wave-wide ballots, so there is no divergence
+// and no atomics, and results are bit-reproducible.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nbd.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+
+__device__ __forceinline__ float dist2(const float* __restrict__ pos, int j, float xi, float yi, float zi) {
+  const float dx = pos[3 * j] - xi, dy = pos[3 * j + 1] - yi, dz = pos[3 * j + 2] - zi;
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+// ---- kNN: the wave keeps the current best 64*R (d2, j) pairs sorted across lanes (rank = r*64+lane).
+template <int R>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void knn_kernel(
+    const float* __restrict__ pos, int n, int k, int loop, const int* __restrict__ seg_lo,
+    const int* __restrict__ seg_hi, const int64_t* __restrict__ out_off, int64_t e_total,
+    int64_t* __restrict__ edge_index) {
+  const int i = blockIdx.x * kWavesPerBlock + wave_id();
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int lo = seg_lo ? seg_lo[i] : 0, hi = seg_hi ? seg_hi[i] : n;
+  const int avail = (hi - lo) - (loop ? 0 : 1);
+  const int kk = min(k, avail);
+  if (kk <= 0) return;
+  const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+  float bd[R];
+  int bj[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { bd[r] = __builtin_inff(); bj[r] = -1; }
+  float thr = __builtin_inff();                // d2 of the current kk-th best
+  const int thr_r = (kk - 1) >> 6, thr_lane = (kk - 1) & 63;
+
+  for (int c0 = lo; c0 < hi; c0 += 64) {
+    const int j = c0 + lane;
+    float d = __builtin_inff();
+    if (j < hi && (loop || j != i)) d = dist2(pos, j, xi, yi, zi);
+    unsigned long long m = __ballot(d < thr);
+    while (m) {
+      const int b = __builtin_ctzll(m);        // lowest candidate index first
+      m &= m - 1;
+      const float dn = __shfl(d, b);
+      if (!(dn < thr)) continue;               // thr may have dropped inside this chunk
+      const int jn = c0 + b;
+      int p = 0;                               // insertion rank: after every entry with d2 <= dn
+#pragma unroll
+      for (int r = 0; r < R; ++r) p += __builtin_popcountll(__ballot(bd[r] <= dn));
+#pragma unroll
+      for (int r = R - 1; r >= 0; --r) {
+        float ud = __shfl_up(bd[r], 1);
+        int uj = __shfl_up(bj[r], 1);
+        if (r > 0) {
+          const float cd = __shfl(bd[r - 1], 63);
+          const int cj = __shfl(bj[r - 1], 63);
+          if (lane == 0) { ud = cd; uj = cj; }
+        }
+        const int rank = r * 64 + lane;
+        if (rank > p) { bd[r] = ud; bj[r] = uj; }
+        else if (rank == p) { bd[r] = dn; bj[r] = jn; }
+      }
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) if (r == thr_r) t = __shfl(bd[r], thr_lane);
+      thr = t;
+    }
+  }
+  const int64_t base = out_off ? out_off[i] : (int64_t)i * kk;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int rank = r * 64 + lane;
+    if (rank < kk) {
+      edge_index[base + rank] = bj[r];             // row 0: neighbour j (source)
+      edge_index[e_total + base + rank] = i;       // row 1: centre i (target)
+    }
+  }
+}
+
+// ---- radius: first `cap` hits in index order -> ELL lists nbr[n][cap], deg[n], last[n]
+__global__ __launch_bounds__(64 * kWavesPerBlock) void radius_kernel(
+    const float* __restrict__ pos, int n, float r2, int loop, int cap, const int* __restrict__ seg_lo,
+    const int* __restrict__ seg_hi, int* __restrict__ nbr, int* __restrict__ deg, int* __restrict__ last) {
+  const int i = blockIdx.x * kWavesPerBlock + wave_id();
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int lo = seg_lo ? seg_lo[i] : 0, hi = seg_hi ? seg_hi[i] : n;
+  const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+  int count = 0, last_j = -1;
+  for (int c0 = lo; c0 < hi && count < cap; c0 += 64) {
+    const int j = c0 + lane;
+    bool hit = false;
+    if (j < hi && (loop || j != i)) hit = dist2(pos, j, xi, yi, zi) < r2;
+    const unsigned long long m = __ballot(hit);
+    const int slot = count + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (hit && slot < cap) nbr[(size_t)i * cap + slot] = j;
+    const int taken = min(__builtin_popcountll(m), cap - count);
+    if (taken > 0) {                                // index of the taken-th set bit = last listed j
+      unsigned long long mm = m;
+      for (int t = 1; t < taken; ++t) mm &= mm - 1;
+      last_j = c0 + __builtin_ctzll(mm);
+    }
+    count += taken;
+  }
+  if (lane == 0) { deg[i] = count; last[i] = last_j; }
+}
+
+// ---- transpose of the capped lists: for node j, the centres c (ascending) whose list contains j.
+// "c lists j"  <=>  d2(c,j) < r2, (loop or c != j), same segment, and j <= last[c]  (lists are the
+// first `cap` hits in ascending index, so membership is a comparison, not a search).
+template <bool FILL>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void radius_transpose_kernel(
+    const float* __restrict__ pos, int n, float r2, int loop, const int* __restrict__ seg_lo,
+    const int* __restrict__ seg_hi, const int* __restrict__ last, const int* __restrict__ rowptr,
+    int* __restrict__ indeg, int* __restrict__ centres) {
+  const int j = blockIdx.x * kWavesPerBlock + wave_id();
+  if (j >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int lo = seg_lo ? seg_lo[j] : 0, hi = seg_hi ? seg_hi[j] : n;
+  const float xj = pos[3 * j], yj = pos[3 * j + 1], zj = pos[3 * j + 2];
+  int count = 0;
+  const int base = FILL ? rowptr[j] : 0;
+  for (int c0 = lo; c0 < hi; c0 += 64) {
+    const int c = c0 + lane;
+    bool hit = false;
+    // same operand order as the forward search: d = pos[j] - pos[c] component-wise
+    if (c < hi && (loop || c != j)) {
+      const float dx = xj - pos[3 * c], dy = yj - pos[3 * c + 1], dz = zj - pos[3 * c + 2];
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      hit = d < r2 && j <= last[c];
+    }
+    const unsigned long long m = __ballot(hit);
+    if (FILL && hit) centres[base + count + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = c;
+    count += __builtin_popcountll(m);
+  }
+  if (!FILL && lane == 0) indeg[j] = count;
+}
+
+// exclusive scan of int32 counts into ptr[0..n] (single workgroup; n up to a few million)
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int* __restrict__ cnt, int n,
+                                                              int* __restrict__ ptr) {
+  __shared__ int wave_sum[16];
+  __shared__ int carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < n ? cnt[i] : 0;
+    int s = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(s, off);
+      if (lane >= off) s += t;
+    }
+    if (lane == 63) wave_sum[wave] = s;
+    __syncthreads();
+    int wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += wave_sum[w];
+    const int carry = carry_s;
+    if (i < n) ptr[i] = carry + wave_off + s - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + wave_off + s;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ptr[n] = carry_s;
+}
+
+// ELL (nbr/deg) -> compact edge_index[2][E] grouped by centre (radius_graph's return value)
+__global__ __launch_bounds__(256) void ell_to_edges_kernel(const int* __restrict__ nbr, const int* __restrict__ deg,
+                                                          const int* __restrict__ ptr, int n, int cap,
+                                                          int64_t e_total, int64_t* __restrict__ edge_index) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int i = t / cap, s = t - i * cap;
+  if (i >= n || s >= deg[i]) return;
+  const int64_t e = ptr[i] + s;
+  edge_index[e] = nbr[(size_t)i * cap + s];
+  edge_index[e_total + e] = i;
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int status() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : (int)e; }
+
+}  // namespace
+
+extern "C" {
+
+int nbd_knn_graph_f32(const float* pos, int n, int k, int loop, const int* seg_lo, const int* seg_hi,
+                      const int64_t* out_off, int64_t num_edges, int64_t* edge_index, nbd_stream_t stream) {
+  if (n < 0 || k < 0 || num_edges < 0 || (seg_lo == nullptr) != (seg_hi == nullptr)) return NBD_E_BADARG;
+  if (n == 0 || k == 0 || num_edges == 0) return 0;
+  if (!pos || !edge_index) return NBD_E_BADARG;
+  if (k > 256) return NBD_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ceil_div(n, kWavesPerBlock)), block(64 * kWavesPerBlock);
+  if (k <= 64)
+    knn_kernel<1><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
+  else if (k <= 128)
+    knn_kernel<2><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
+  else
+    knn_kernel<4><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
+  return status();
+}
+
+int nbd_radius_search_f32(const float* pos, int n, float radius_sq, int loop, int max_num_neighbors,
+                          const int* seg_lo, const int* seg_hi, int* nbr, int* deg, int* last,
+                          nbd_stream_t stream) {
+  if (n < 0 || max_num_neighbors < 0 || (seg_lo == nullptr) != (seg_hi == nullptr)) return NBD_E_BADARG;
+  if (n == 0) return 0;
+  if (!pos || !deg || !last || (max_num_neighbors > 0 && !nbr)) return NBD_E_BADARG;
+  radius_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, (hipStream_t)stream>>>(
+      pos, n, radius_sq, loop, max_num_neighbors, seg_lo, seg_hi, nbr, deg, last);
+  return status();
+}
+
+int nbd_radius_transpose_count_f32(const float* pos, int n, float radius_sq, int loop, const int* seg_lo,
+                                   const int* seg_hi, const int* last, int* indeg, nbd_stream_t stream) {
+  if (n < 0 || (seg_lo == nullptr) != (seg_hi == nullptr)) return NBD_E_BADARG;
+  if (n == 0) return 0;
+  if (!pos || !last || !indeg) return NBD_E_BADARG;
+  radius_transpose_kernel<false><<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, (hipStream_t)stream>>>(
+      pos, n, radius_sq, loop, seg_lo, seg_hi, last, nullptr, indeg, nullptr);
+  return status();
+}
+
+int nbd_radius_transpose_fill_f32(const float* pos, int n, float radius_sq, int loop, const int* seg_lo,
+                                  const int* seg_hi, const int* last, const int* rowptr, int* centres,
+                                  nbd_stream_t stream) {
+  if (n < 0 || (seg_lo == nullptr) != (seg_hi == nullptr)) return NBD_E_BADARG;
+  if (n == 0) return 0;
+  if (!pos || !last || !rowptr || !centres) return NBD_E_BADARG;
+  radius_transpose_kernel<true><<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, (hipStream_t)stream>>>(
+      pos, n, radius_sq, loop, seg_lo, seg_hi, last, rowptr, nullptr, centres);
+  return status();
+}
+
+int nbd_exclusive_scan_i32(const int* counts, int n, int* ptr, nbd_stream_t stream) {
+  if (n < 0 || !ptr || (n > 0 && !counts)) return NBD_E_BADARG;
+  exclusive_scan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(counts, n, ptr);
+  return status();
+}
+
+int nbd_ell_to_edge_index(const int* nbr, const int* deg, const int* ptr, int n, int cap, int64_t num_edges,
+                          int64_t* edge_index, nbd_stream_t stream) {
+  if (n < 0 || cap < 0 || num_edges < 0) return NBD_E_BADARG;
+  if (n == 0 || cap == 0 || num_edges == 0) return 0;
+  if (!nbr || !deg || !ptr || !edge_index) return NBD_E_BADARG;
+  const long long total = (long long)n * cap;
+  if (total > 0x7fffffffLL) return NBD_E_UNSUPPORTED;
+  ell_to_edges_kernel<<<ceil_div((int)total, 256), 256, 0, (hipStream_t)stream>>>(nbr, deg, ptr, n, cap, num_edges,
+                                                                                 edge_index);
+  return status();
+}
+
+}  // extern "C"

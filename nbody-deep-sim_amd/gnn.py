@@ -1,0 +1,251 @@
+"""MI355X drop-in for the reference's gnn.py: `transform_to_graph` and `GraphModel` with the same
+constructor arguments, attributes (`neighbors`, ...), parameter names (`gnns.{l}.nn.{0,2}.*`,
+`node_encoder.lins.*`, `layer_norm.*`, `output.*` -- reference state_dicts load unchanged) and the
+inference methods `forward(data)`, `predict(pos, feat)`, `predict_graph`, `eval_graph_batch`.
+
+The forward pass runs in hand-written HIP kernels (csrc/graph.hip, csrc/nn.hip):
+  knn_graph            -> nbd_knn_graph_f32                         (gnn.py:13)
+  EdgeConv layer l     -> nbd_linear_f32 [x -> P|Q]  +  nbd_edgeconv_aggregate_f32  +  nbd_linear_f32 [W2]
+  LayerNorm + head     -> nbd_layernorm_f32 + nbd_linear_f32        (gnn.py:146-148)
+EdgeConv is evaluated in an algebraically factored form (exact in real arithmetic, differs from the
+per-edge order by fp32 rounding only):
+  nn([x_i || x_j - x_i]) = W2 tanh((W1a - W1b) x_i + b1 + W1b x_j) + b2 = W2 tanh(P_i + Q_j) + b2
+  sum/mean over j commute with the affine W2, so W2 is applied once per node, not once per edge.
+Training methods are not part of this build (forward-only kernels): they raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import time
+
+import torch
+from torch.nn import LayerNorm, Linear, ModuleList, Sequential, Tanh
+
+from nbd import graphops, nnops
+from nbd._lib import NbdError
+from nbd.data import Data
+
+
+def transform_to_graph(positions, features, y, batch=None, neighbors=50, device="cuda"):
+    """gnn.py:11-22: kNN graph (loop=False) + Data(x=[positions|features], edge_index, y, batch)."""
+    graph = graphops.knn_graph(positions, k=neighbors, batch=batch, loop=False)
+    return Data(x=torch.cat((positions, features), dim=-1), edge_index=graph, edge_attr=None, y=y, batch=batch)
+
+
+class MLP(torch.nn.Module):
+    """Parameter container with torch_geometric.nn.MLP's layout (lins.{i}, norms.{i}.module) for the
+    way the reference builds it: act='tanh', plain last layer, BatchNorm unless norm=None."""
+
+    def __init__(self, channels, norm="batch_norm", dropout=0.0):
+        super().__init__()
+        self.channels = list(channels)
+        self.lins = ModuleList(Linear(a, b) for a, b in zip(channels[:-1], channels[1:]))
+        self.norms = ModuleList()
+        for c in channels[1:-1]:
+            if norm is None:
+                self.norms.append(torch.nn.Identity())
+            else:
+                holder = torch.nn.Module()
+                holder.module = torch.nn.BatchNorm1d(c)
+                self.norms.append(holder)
+        self.has_norm = norm is not None
+        self.dropout = dropout
+
+    def folded(self):
+        """[(W, b, act)] with the eval-mode BatchNorm folded into the preceding Linear."""
+        out = []
+        last = len(self.lins) - 1
+        for i, lin in enumerate(self.lins):
+            w, b = lin.weight.detach(), lin.bias.detach()
+            if i < last and self.has_norm:
+                bn = self.norms[i].module
+                s = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+                w = w * s.unsqueeze(1)
+                b = (b - bn.running_mean) * s + bn.bias.detach()
+            out.append((w.contiguous(), b.contiguous(), "tanh" if i < last else None))
+        return out
+
+
+class EdgeConv(torch.nn.Module):
+    """Parameter holder named like torch_geometric.nn.EdgeConv (`nn`, `aggr`)."""
+
+    def __init__(self, nn, aggr):
+        super().__init__()
+        self.nn, self.aggr = nn, aggr
+
+
+def run_chain(x, chain, out_last=None):
+    """Apply [(W, b, act)] with nbd_linear_f32; the last layer may write into `out_last` (a slice)."""
+    for li, (w, b, act) in enumerate(chain):
+        x = nnops.linear(x, w, b, act=act, out=out_last if li == len(chain) - 1 else None)
+    return x
+
+
+def head_chain(output):
+    """torch Sequential(Linear, Tanh, Linear, ...) or a single Linear -> [(W, b, act)]."""
+    if isinstance(output, Linear):
+        return [(output.weight.detach().contiguous(), output.bias.detach().contiguous(), None)]
+    lins = [m for m in output if isinstance(m, Linear)]
+    return [(l.weight.detach().contiguous(), l.bias.detach().contiguous(), "tanh" if i < len(lins) - 1 else None)
+            for i, l in enumerate(lins)]
+
+
+class _WeightCache:
+    """Derived (folded / re-laid-out) weights, rebuilt when any parameter or buffer changes."""
+
+    def __init__(self, module):
+        self.module, self.key, self.value = module, None, None
+
+    def get(self, builder):
+        tensors = list(self.module.parameters()) + list(self.module.buffers())
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors)
+        if key != self.key:
+            with torch.no_grad():
+                self.value = builder()
+            self.key = key
+        return self.value
+
+
+class GraphModel(torch.nn.Module):
+    def __init__(self, input_dim=1, output_hiddens=None, output_dim=3, node_encoder_dims=None, gnn_dim=128,
+                 encoder_dropout=0.0, message_passing_steps=4, aggr="sum", device="cpu", neighbors=50,
+                 scale_factor=1):
+        super().__init__()
+        self.device = device
+        self.neighbors = neighbors
+        self.node_encoder_dims = node_encoder_dims
+        self.message_passing_steps = message_passing_steps
+        self.aggr = aggr
+        self.output_hiddens = output_hiddens
+        self.output_dim = output_dim
+        self.input_dim = input_dim
+        self.gnn_dim = gnn_dim
+        self.encoder_dropout = encoder_dropout
+        self.scale_factor = scale_factor
+        if aggr not in ("sum", "add", "mean"):
+            raise NotImplementedError(f"aggr={aggr!r}: this build factors EdgeConv's second Linear through the "
+                                      "aggregation, which needs a linear aggregation (sum/add/mean)")
+        if node_encoder_dims:                                                     # gnn.py:56-65
+            self.node_encoder = MLP([input_dim] + list(node_encoder_dims) + [gnn_dim], norm=None,
+                                    dropout=encoder_dropout)
+        else:
+            self.node_encoder = torch.nn.Identity()
+        self.gnns = ModuleList()                                                  # gnn.py:71-95
+        for i in range(message_passing_steps):
+            fin = input_dim if (i == 0 and node_encoder_dims is None) else gnn_dim
+            self.gnns.append(EdgeConv(nn=Sequential(Linear(fin * 2, gnn_dim), Tanh(), Linear(gnn_dim, gnn_dim)),
+                                      aggr=aggr))
+        out_dim = gnn_dim + input_dim if node_encoder_dims is None else gnn_dim * 2   # gnn.py:97-100
+        self.layer_norm = LayerNorm(out_dim)
+        if output_hiddens:                                                        # gnn.py:105-114
+            layers, dims = [], [out_dim] + list(output_hiddens) + [output_dim]
+            for i in range(len(dims) - 1):
+                layers.append(Linear(dims[i], dims[i + 1]))
+                if i < len(dims) - 2:
+                    layers.append(Tanh())
+            self.output = Sequential(*layers)
+        else:
+            self.output = Linear(out_dim, output_dim)
+        self._cache = _WeightCache(self)
+        self.to(device)
+
+    def get_config(self):
+        return {"input_dim": self.input_dim, "output_hiddens": self.output_hiddens, "output_dim": self.output_dim,
+                "node_encoder_dims": self.node_encoder_dims, "gnn_dim": self.gnn_dim,
+                "encoder_dropout": self.encoder_dropout, "message_passing_steps": self.message_passing_steps,
+                "aggr": self.aggr, "device": self.device, "neighbors": self.neighbors}
+
+    # ------------------------------------------------------------------ derived weights
+    def _build_weights(self):
+        layers = []
+        for g in self.gnns:
+            w1, b1 = g.nn[0].weight.detach(), g.nn[0].bias.detach()
+            f = w1.shape[1] // 2
+            w1a, w1b = w1[:, :f], w1[:, f:]
+            wpq = torch.cat([w1a - w1b, w1b], dim=0).contiguous()                 # (2H, F): rows P then Q
+            bpq = torch.cat([b1, torch.zeros_like(b1)]).contiguous()
+            layers.append((wpq, bpq, g.nn[2].weight.detach().contiguous(), g.nn[2].bias.detach().contiguous()))
+        enc = self.node_encoder.folded() if isinstance(self.node_encoder, MLP) else None
+        return {"enc": enc, "layers": layers, "head": head_chain(self.output)}
+
+    # ------------------------------------------------------------------ forward (gnn.py:130-148)
+    def forward(self, data):
+        if self.training and self.encoder_dropout > 0:
+            raise NotImplementedError("training-mode dropout is outside this build (inference kernels only)")
+        w = self._cache.get(self._build_weights)
+        x7 = data.x
+        if not x7.is_cuda:
+            raise NbdError("GraphModel.forward: data must live on the GPU (no CPU path)")
+        n = x7.shape[0]
+        x_in = torch.cat((x7[:, :3], x7[:, 6:]), dim=-1) if self.input_dim == 4 else x7
+        x_in = x_in.to(torch.float32)
+        h = self.gnn_dim
+        enc_dim = self.input_dim if w["enc"] is None else h
+        cat_buf = torch.empty((n, enc_dim + h), dtype=torch.float32, device=x7.device)
+        enc_view, gnn_view = cat_buf[:, :enc_dim], cat_buf[:, enc_dim:]
+        if w["enc"] is None:
+            enc_view.copy_(x_in)
+        else:
+            run_chain(x_in.contiguous(), w["enc"], out_last=enc_view)
+        # edges grouped by target (edge_index[1]); regular kNN output needs no CSR
+        ei = data.edge_index
+        e = ei.shape[1]
+        fixed_k, rowptr, src = -1, None, ei[0].contiguous()
+        reg = getattr(data, "_regular_k", None)
+        if reg is not None and n * reg == e:
+            fixed_k = reg
+        else:
+            rowptr, src = graphops.csr_by_target(ei, n)
+        if self.aggr == "mean":
+            brs_mode = 2
+        else:
+            brs_mode = 1
+        if rowptr is None:
+            val = float(fixed_k) if brs_mode == 1 else (1.0 if fixed_k > 0 else 0.0)
+            brs = torch.full((n,), val, dtype=torch.float32, device=x7.device)
+        else:
+            brs = nnops.degree_scale(rowptr, n, brs_mode, x7.device)
+        x = enc_view
+        aggr = "mean" if self.aggr == "mean" else "sum"
+        for li, (wpq, bpq, w2, b2) in enumerate(w["layers"]):
+            pq = nnops.linear(x, wpq, bpq)                                        # (n, 2H) = [P | Q]
+            s = nnops.edgeconv_aggregate(pq, h, rowptr, src, fixed_k, aggr)
+            last = li == len(w["layers"]) - 1
+            x = nnops.linear(s, w2, b2, bias_rowscale=brs, out=gnn_view if last else None)
+        ln = nnops.layernorm(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
+                             self.layer_norm.eps)
+        return run_chain(ln, w["head"])
+
+    # ------------------------------------------------------------------ inference API
+    def predict(self, pos, feat, neighbors=None):
+        """gnn.py:205-215. The reference never forwards `self.neighbors` here, so the graph uses
+        transform_to_graph's default k = 50; `neighbors=` is this build's optional override."""
+        self.eval()
+        with torch.no_grad():
+            k = 50 if neighbors is None else neighbors
+            data = transform_to_graph(pos, feat, None, neighbors=k, device=self.device)
+            data._regular_k = max(min(k, pos.shape[0] - 1), 0)
+            pred = self.forward(data)
+        return pred
+
+    def predict_graph(self, data):
+        self.eval()
+        with torch.no_grad():
+            return self.forward(data)
+
+    def eval_graph_batch(self, data):
+        """(rmse, mse, seconds) as gnn.py:193-203; the time brackets forward() with a device sync."""
+        self.eval()
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            start = time.time()
+            acc_pred = self.forward(data)
+            torch.cuda.synchronize()
+            end = time.time()
+            mse_loss = torch.nn.functional.mse_loss(acc_pred, data.y, reduction="mean")
+            loss = torch.sqrt(mse_loss)
+        return loss.item(), mse_loss.item(), end - start
+
+    def compute_loss(self, data):
+        raise NotImplementedError("training (gnn.py:150-191) is outside this build: forward-only HIP kernels")
+
+    train_batch = train_graph_batch = compute_loss

@@ -64,6 +64,27 @@ SIGNATURES = {
     "nbd_energy_workspace_bytes": (c_size_t, [c_int]),
     "nbd_energy_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p,
                                c_size_t, c_void_p]),
+    # --- surrogate models: graph build (csrc/graph.hip)
+    "nbd_knn_graph_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
+                                  c_void_p, c_void_p]),
+    "nbd_radius_search_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p]),
+    "nbd_radius_transpose_count_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p]),
+    "nbd_radius_transpose_fill_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p]),
+    "nbd_exclusive_scan_i32": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "nbd_ell_to_edge_index": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
+    # --- surrogate models: dense blocks (csrc/nn.hip)
+    "nbd_linear_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                               c_int, c_int, c_int, c_int, c_void_p]),
+    "nbd_edgeconv_aggregate_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                           c_void_p, c_int, c_void_p]),
+    "nbd_layernorm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
+                                  c_void_p]),
+    "nbd_contconv_bin_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float,
+                                     c_void_p, c_void_p]),
+    "nbd_degree_scale_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,134 @@
+"""Neighbour-graph construction on the GPU (csrc/graph.hip) behind PyG-shaped functions.
+
+knn_graph / radius_graph keep the signatures the reference imports from torch_geometric
+(gnn.py:5, contconv.py:5) for the arguments it uses; `radius_lists` is the sync-free padded form
+the ContinuousConv pipeline consumes."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from .direct import _chk
+
+
+def _stream(dev):
+    return _lib.current_stream(dev)
+
+
+def _segments(batch: torch.Tensor | None, n: int, device):
+    """Per-node [lo, hi) of its batch segment (batch must be sorted, as PyG requires)."""
+    if batch is None:
+        return None, None
+    if batch.numel() != n:
+        raise _lib.NbdError(f"batch has {batch.numel()} entries for {n} nodes")
+    b = batch.to(device=device, dtype=torch.int64).contiguous()
+    if n > 1 and bool((b[1:] < b[:-1]).any()):
+        raise _lib.NbdError("batch vector must be sorted (PyG convention)")
+    uniq, counts = torch.unique_consecutive(b, return_counts=True)
+    ends = torch.cumsum(counts, 0)
+    starts = ends - counts
+    lo = torch.repeat_interleave(starts, counts).to(torch.int32).contiguous()
+    hi = torch.repeat_interleave(ends, counts).to(torch.int32).contiguous()
+    return lo, hi
+
+
+def knn_graph(x: torch.Tensor, k: int, batch: torch.Tensor | None = None, loop: bool = False) -> torch.Tensor:
+    """int64 edge_index [2, E]: per centre i its k nearest j (ascending (d2, j)); row 0 = j, row 1 = i."""
+    n = x.shape[0]
+    pos = x[:, :3].contiguous() if x.shape[1] != 3 else x
+    _chk(pos, (n, 3), "x")
+    dev = pos.device
+    lo, hi = _segments(batch, n, dev)
+    if lo is None:
+        kk = max(min(k, n - (0 if loop else 1)), 0)
+        e, off = n * kk, None
+    else:
+        per = torch.clamp((hi - lo).to(torch.int64) - (0 if loop else 1), min=0, max=k)
+        off = (torch.cumsum(per, 0) - per).contiguous()
+        e = int(per.sum().item())
+    ei = torch.empty((2, e), dtype=torch.int64, device=dev)
+    if e:
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().nbd_knn_graph_f32(pos.data_ptr(), n, k, int(loop), _lib.ptr(lo), _lib.ptr(hi),
+                                                    _lib.ptr(off), e, ei.data_ptr(), _stream(dev)), "nbd_knn_graph_f32")
+    return ei
+
+
+@dataclass
+class RadiusLists:
+    """radius_graph in padded form + its transpose (what ContinuousConv aggregates over)."""
+    n: int
+    cap: int
+    nbr: torch.Tensor       # (n, cap) int32, first deg[i] entries valid: neighbours j of centre i, ascending
+    deg: torch.Tensor       # (n,) int32
+    last: torch.Tensor      # (n,) int32 largest listed j
+    rowptr: torch.Tensor    # (n+1,) int32 CSR by neighbour j (= edge_index[0], the aggregation target)
+    centres: torch.Tensor   # (>= E,) int32 centres c listing j, ascending per row (first rowptr[n] valid)
+
+
+def radius_r2(r: float) -> float:
+    """torch_cluster compares against r*r in fp32."""
+    r32 = np.float32(r)
+    return float(np.float32(r32 * r32))
+
+
+def radius_lists(pos: torch.Tensor, r: float, batch=None, loop: bool = False, max_num_neighbors: int = 32,
+                 transpose: bool = True) -> RadiusLists:
+    n = pos.shape[0]
+    _chk(pos, (n, 3), "pos")
+    dev = pos.device
+    cap = int(max_num_neighbors) if loop else int(max_num_neighbors)
+    lo, hi = _segments(batch, n, dev)
+    nbr = torch.empty((n, max(cap, 1)), dtype=torch.int32, device=dev)
+    deg = torch.empty(n, dtype=torch.int32, device=dev)
+    last = torch.empty(n, dtype=torch.int32, device=dev)
+    r2 = radius_r2(r)
+    L, st = _lib.lib(), _stream(dev)
+    rowptr = centres = None
+    with torch.cuda.device(dev):
+        _lib.check(L.nbd_radius_search_f32(pos.data_ptr(), n, r2, int(loop), cap, _lib.ptr(lo), _lib.ptr(hi),
+                                           nbr.data_ptr(), deg.data_ptr(), last.data_ptr(), st), "nbd_radius_search_f32")
+        if transpose:
+            indeg = torch.empty(n, dtype=torch.int32, device=dev)
+            rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            centres = torch.empty(max(n * cap, 1), dtype=torch.int32, device=dev)   # E <= n*cap: no sync needed
+            _lib.check(L.nbd_radius_transpose_count_f32(pos.data_ptr(), n, r2, int(loop), _lib.ptr(lo), _lib.ptr(hi),
+                                                        last.data_ptr(), indeg.data_ptr(), st), "radius_transpose_count")
+            _lib.check(L.nbd_exclusive_scan_i32(indeg.data_ptr(), n, rowptr.data_ptr(), st), "exclusive_scan")
+            _lib.check(L.nbd_radius_transpose_fill_f32(pos.data_ptr(), n, r2, int(loop), _lib.ptr(lo), _lib.ptr(hi),
+                                                       last.data_ptr(), rowptr.data_ptr(), centres.data_ptr(), st),
+                       "radius_transpose_fill")
+    return RadiusLists(n, cap, nbr, deg, last, rowptr, centres)
+
+
+def radius_graph(x: torch.Tensor, r: float, batch=None, loop: bool = False, max_num_neighbors: int = 32) -> torch.Tensor:
+    """int64 edge_index [2, E] as torch_geometric.nn.radius_graph returns it (one host sync for E)."""
+    lists = radius_lists(x, r, batch, loop, max_num_neighbors, transpose=False)
+    n, dev = lists.n, x.device
+    ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    L, st = _lib.lib(), _stream(dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.nbd_exclusive_scan_i32(lists.deg.data_ptr(), n, ptr.data_ptr(), st), "exclusive_scan")
+        e = int(ptr[n].item()) if n else 0
+        ei = torch.empty((2, e), dtype=torch.int64, device=dev)
+        if e:
+            _lib.check(L.nbd_ell_to_edge_index(lists.nbr.data_ptr(), lists.deg.data_ptr(), ptr.data_ptr(), n, lists.cap,
+                                               e, ei.data_ptr(), st), "nbd_ell_to_edge_index")
+    return ei
+
+
+def csr_by_target(edge_index: torch.Tensor, n: int):
+    """(rowptr int32 [n+1], src int64 [E]) for edges grouped by edge_index[1]; already-grouped input
+    (what knn_graph / PyG produce) is used as is, anything else is stably sorted first."""
+    tgt = edge_index[1]
+    src = edge_index[0]
+    if tgt.numel() > 1 and bool((tgt[1:] < tgt[:-1]).any()):
+        order = torch.sort(tgt, stable=True).indices
+        tgt, src = tgt[order], src[order]
+    counts = torch.bincount(tgt, minlength=n)
+    rowptr = torch.zeros(n + 1, dtype=torch.int32, device=edge_index.device)
+    rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return rowptr, src.contiguous()

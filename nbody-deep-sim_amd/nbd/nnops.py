@@ -1,0 +1,108 @@
+"""Typed wrappers for the dense surrogate kernels (csrc/nn.hip). All tensors fp32, CUDA/HIP, 2-D,
+unit inner stride; row strides are passed through so column slices of wider buffers work."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+ACT = {None: 0, "none": 0, "tanh": 1}
+AGGR = {"sum": 0, "add": 0, "mean": 1, "max": 2}
+
+
+def _mat(t: torch.Tensor, name: str):
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+        raise _lib.NbdError(f"{name}: need a 2-D fp32 CUDA/HIP tensor with unit inner stride, got "
+                            f"{t.dtype} {tuple(t.shape)} strides {t.stride()} on {t.device}")
+    return t.stride(0)
+
+
+def _vec(t, n, name):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 1 or t.numel() != n or not t.is_contiguous():
+        raise _lib.NbdError(f"{name}: need a contiguous fp32 CUDA vector of {n}")
+    return t.data_ptr()
+
+
+def linear(x, w, bias=None, act=None, out=None, rowscale=None, bias_rowscale=None):
+    """out = act(rowscale * x @ w.T + bias_rowscale * bias); w is (out_features, in_features)."""
+    n, k = x.shape
+    m = w.shape[0]
+    if w.shape[1] != k:
+        raise _lib.NbdError(f"linear: x is {tuple(x.shape)}, w is {tuple(w.shape)}")
+    ldx, ldw = _mat(x, "x"), _mat(w, "w")
+    if out is None:
+        out = torch.empty((n, m), dtype=torch.float32, device=x.device)
+    if tuple(out.shape) != (n, m):
+        raise _lib.NbdError(f"linear: out is {tuple(out.shape)}, expected {(n, m)}")
+    ldy = _mat(out, "out")
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().nbd_linear_f32(x.data_ptr(), ldx, w.data_ptr(), ldw, _vec(bias, m, "bias"),
+                                             _vec(rowscale, n, "rowscale"), _vec(bias_rowscale, n, "bias_rowscale"),
+                                             ACT[act], out.data_ptr(), ldy, n, m, k,
+                                             _lib.current_stream(x.device)), "nbd_linear_f32")
+    return out
+
+
+def edgeconv_aggregate(pq, h, rowptr, src, fixed_k, aggr, out=None):
+    n = pq.shape[0]
+    ld = _mat(pq, "pq")
+    if pq.shape[1] != 2 * h:
+        raise _lib.NbdError(f"pq must be (n, 2h) = (n, {2 * h}), got {tuple(pq.shape)}")
+    if out is None:
+        out = torch.empty((n, h), dtype=torch.float32, device=pq.device)
+    ldo = _mat(out, "out")
+    if src is not None and (src.dtype != torch.int64 or not src.is_contiguous()):
+        raise _lib.NbdError("src must be contiguous int64")
+    if rowptr is not None and (rowptr.dtype != torch.int32 or rowptr.numel() != n + 1):
+        raise _lib.NbdError("rowptr must be int32 [n+1]")
+    n_edges = 0 if src is None else src.numel()
+    if rowptr is None and n * fixed_k != n_edges:
+        raise _lib.NbdError(f"fixed_k={fixed_k} x n={n} != {n_edges} edges")
+    with torch.cuda.device(pq.device):
+        _lib.check(_lib.lib().nbd_edgeconv_aggregate_f32(pq.data_ptr(), ld, h, _lib.ptr(rowptr), _lib.ptr(src),
+                                                         fixed_k, n, AGGR[aggr], out.data_ptr(), ldo,
+                                                         _lib.current_stream(pq.device)), "nbd_edgeconv_aggregate_f32")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, out=None):
+    n, c = x.shape
+    ldx = _mat(x, "x")
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    ldy = _mat(out, "out")
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().nbd_layernorm_f32(x.data_ptr(), ldx, c, _vec(gamma, c, "gamma"), _vec(beta, c, "beta"),
+                                                float(eps), out.data_ptr(), ldy, n,
+                                                _lib.current_stream(x.device)), "nbd_layernorm_f32")
+    return out
+
+
+def contconv_bin(pos, feat, rowptr, centres, d, radius_sq, out=None):
+    """A (n, d^3 * I): feature-side trilinear binning of ContinuousConv (contconv.py:80-93)."""
+    n, i_ch = feat.shape
+    ldf = _mat(feat, "feat")
+    if pos.shape != (n, 3) or pos.dtype != torch.float32 or not pos.is_contiguous():
+        raise _lib.NbdError("pos must be contiguous fp32 (n,3)")
+    if rowptr.dtype != torch.int32 or rowptr.numel() != n + 1 or centres.dtype != torch.int32:
+        raise _lib.NbdError("rowptr int32 [n+1] / centres int32 required")
+    kc = d * d * d * i_ch
+    if out is None:
+        out = torch.empty((n, kc), dtype=torch.float32, device=feat.device)
+    if tuple(out.shape) != (n, kc) or not out.is_contiguous():
+        raise _lib.NbdError(f"A must be contiguous {(n, kc)}")
+    with torch.cuda.device(feat.device):
+        _lib.check(_lib.lib().nbd_contconv_bin_f32(pos.data_ptr(), feat.data_ptr(), ldf, i_ch, rowptr.data_ptr(),
+                                                   centres.data_ptr(), n, d, float(radius_sq), out.data_ptr(),
+                                                   _lib.current_stream(feat.device)), "nbd_contconv_bin_f32")
+    return out
+
+
+def degree_scale(rowptr, n, mode, device):
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().nbd_degree_scale_f32(rowptr.data_ptr(), n, mode, out.data_ptr(),
+                                                   _lib.current_stream(device)), "nbd_degree_scale_f32")
+    return out

@@ -1,0 +1,141 @@
+"""MI355X drop-in for the rollout / evaluation half of the reference's trainer.py: `Trainer` with
+`step`, `evaluate_rollout`, `evaluate_stepwise`, `test_from_dir` (trainer.py:94-344) -- same
+signatures, same DataFrame columns and statistics. `train_from_dir` (the optimiser loop,
+trainer.py:20-92) is outside this build and raises.
+
+Differences that do not change outputs: the leapfrog updates run in the HIP kick/drift kernels;
+the 18 N `.item()` host syncs per rollout step (trainer.py:286-312) are replaced by one bulk
+device->host copy per rollout; step_time is measured with HIP events (the reference's
+un-synchronised time.time() would time kernel launches only).
+"""
+from __future__ import annotations
+
+import os
+from glob import glob
+
+import numpy as np
+import pandas as pd
+import torch
+
+from datautils import get_dataloader
+from nbd import direct
+
+ROLLOUT_COLUMNS = ["filename", "scene", "step", "x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az",
+                   "pred_x", "pred_y", "pred_z", "pred_vx", "pred_vy", "pred_vz", "pred_ax", "pred_ay", "pred_az",
+                   "step_time"]
+
+
+class Trainer:
+    def __init__(self, model, optimizer, scheduler=None, device="cpu", dt=0.01):
+        self.model = model
+        self.optimizer = optimizer
+        self.device = device
+        self.dt = dt
+        self.model = self.model.to(self.device)
+        self.scheduler = scheduler
+
+    def train_from_dir(self, *args, **kwargs):
+        raise NotImplementedError("train_from_dir (trainer.py:20-92) is the training loop; this build provides "
+                                  "the inference / rollout path only")
+
+    # ------------------------------------------------------------------ trainer.py:217-226
+    def step(self, pos, vel, m, acc, dt):
+        """Leapfrog with model-predicted accelerations; functional (returns new tensors)."""
+        half, full = direct.f32(0.5 * dt), direct.f32(dt)
+        pos_, vel_ = pos.contiguous().clone(), vel.contiguous().clone()
+        direct.kick_drift(pos_, vel_, acc.contiguous(), None, half, full)          # vel_ = vel + .5dt acc ; pos_ = pos + dt vel_
+        acc_ = self.model.predict(pos_, torch.cat([vel_, m], dim=-1))
+        direct.kick(vel_, acc_, half)                                              # vel_ += .5dt acc_
+        return pos_, vel_, acc_
+
+    # ------------------------------------------------------------------ trainer.py:228-344
+    def evaluate_rollout(self, filename, data, scene, sim_steps, dt, df):
+        data = data.to(self.device)
+        mask = data.step == 0
+        feats, accs = data.x[mask], data.y[mask]
+        pos, vel, m = feats[:, :3].contiguous(), feats[:, 3:6].contiguous(), feats[:, 6:].contiguous()
+        n = pos.shape[0]
+
+        def timed(fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn()
+            e1.record()
+            return out, (e0, e1)
+
+        pred_accs, ev = timed(lambda: self.model.predict(pos, feats[:, 3:].contiguous()))
+        events = [ev]
+        # per step: [gt_pos gt_vel gt_acc | pred_pos pred_vel pred_acc] (n, 18), kept on the device
+        blocks = [torch.cat([pos, vel, accs, pos, vel, pred_accs], dim=1)]
+        for step in range(1, sim_steps):
+            (pos, vel, pred_accs), ev = timed(lambda: self.step(pos, vel, m, pred_accs, dt))
+            events.append(ev)
+            gt_mask = data.step == step
+            gt_feats, gt_accs = data.x[gt_mask], data.y[gt_mask]
+            blocks.append(torch.cat([gt_feats[:, :3], gt_feats[:, 3:6], gt_accs, pos, vel, pred_accs], dim=1))
+        table = torch.stack(blocks).cpu().numpy().astype(np.float64)               # ONE device->host copy
+        times = np.array([a.elapsed_time(b) * 1e-3 for a, b in events])
+        steps = np.repeat(np.arange(sim_steps), n)
+        df_new = pd.DataFrame(table.reshape(sim_steps * n, 18), columns=ROLLOUT_COLUMNS[3:21])
+        df_new.insert(0, "step", steps)
+        df_new.insert(0, "scene", scene)
+        df_new.insert(0, "filename", filename)
+        df_new["step_time"] = np.repeat(times, n)
+        df_new = df_new[ROLLOUT_COLUMNS]
+        return df_new if df is None or len(df) == 0 else pd.concat([df, df_new], ignore_index=True)
+
+    # ------------------------------------------------------------------ trainer.py:202-215
+    def evaluate_stepwise(self, filename, loader, df):
+        rows = []
+        for data in loader:
+            data = data.to(self.device)
+            loss, mse_loss, step_time = self.model.eval_graph_batch(data)
+            rows.append({"filename": filename, "scene": data.scene[0].item(), "step": data.step[0].item(),
+                         "loss": loss, "mse_loss": mse_loss, "step_time": step_time})
+        if rows:
+            new = pd.DataFrame(rows)
+            df = new if df is None or len(df) == 0 else pd.concat([df, new], ignore_index=True)
+        return df
+
+    # ------------------------------------------------------------------ trainer.py:94-200
+    def test_from_dir(self, data_path, model_path=None, sim_steps=1000, stepwise=True, rollout=True):
+        if model_path:
+            models = sorted(os.listdir(model_path), key=lambda x: int(x.split("_")[1].split(".")[0]))
+            with torch.no_grad():
+                self.model.load_state_dict(torch.load(f"{model_path}/{models[-1]}", map_location=self.device))
+            print(f"Loaded model {models[-1]}")
+        csv_files = [f.replace("\\", "/") for f in glob(data_path + "/*.csv")]
+        df_stepwise = pd.DataFrame(columns=["filename", "scene", "step", "loss", "mse_loss", "step_time"])
+        df_rollout = pd.DataFrame(columns=ROLLOUT_COLUMNS)
+        if stepwise:
+            for f in csv_files:
+                loader = get_dataloader(csv_path=f, batch_size=1, k=self.model.neighbors, shuffle=False,
+                                        device=self.device)
+                df_stepwise = self.evaluate_stepwise(f.split("/")[-1], loader, df_stepwise)
+        if rollout:
+            for f in csv_files:
+                loader = get_dataloader(csv_path=f, batch_size=sim_steps, k=self.model.neighbors, shuffle=False,
+                                        device=self.device)
+                for scene, data in enumerate(loader):
+                    df_rollout = self.evaluate_rollout(f.split("/")[-1], data, scene, sim_steps, self.dt, df_rollout)
+        cols = ["x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az"]
+        for col in cols:                                                           # trainer.py:177-178
+            df_rollout[f"error_{col}"] = df_rollout[col].astype(float) - df_rollout[f"pred_{col}"].astype(float)
+        df_rollout = df_rollout.groupby(["filename", "scene", "step"])[[f"error_{c}" for c in cols]].mean()
+        for name, trio in (("pos", ["x", "y", "z"]), ("vel", ["vx", "vy", "vz"]), ("acc", ["ax", "ay", "az"])):
+            errors = torch.tensor(df_rollout[[f"error_{c}" for c in trio]].values.astype(np.float64))
+            df_rollout[f"{name}_rmse"] = torch.sqrt((errors ** 2).mean(dim=1)).numpy()   # trainer.py:186-195
+        df_stepwise = df_stepwise.astype({"loss": float, "step_time": float}) if len(df_stepwise) else df_stepwise
+        return (df_stepwise.groupby(["filename", "scene"]).mean(numeric_only=True)[["loss", "step_time"]],
+                df_rollout[["pos_rmse", "vel_rmse", "acc_rmse"]])
+
+
+def rollout_mse(df_rollout_rows: pd.DataFrame) -> pd.DataFrame:
+    """True per-step MSE over particles x xyz for pos / vel / acc (BASELINE.json 'rollout MSE'), from
+    the rows evaluate_rollout() returns. The reference's own statistic (mean signed error first,
+    trainer.py:179-195) is what test_from_dir() reports."""
+    out = {}
+    for name, trio in (("pos", ["x", "y", "z"]), ("vel", ["vx", "vy", "vz"]), ("acc", ["ax", "ay", "az"])):
+        err2 = sum((df_rollout_rows[c].astype(float) - df_rollout_rows[f"pred_{c}"].astype(float)) ** 2 for c in trio) / 3.0
+        out[f"{name}_mse"] = err2.groupby([df_rollout_rows["filename"], df_rollout_rows["scene"], df_rollout_rows["step"]]).mean()
+    return pd.DataFrame(out)

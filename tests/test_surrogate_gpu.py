@@ -1,0 +1,268 @@
+"""HIP surrogate path (kNN / radius graph, EdgeConv GNN, ContinuousConv, Trainer.step / rollout)
+against the CPU oracle (oracle/surrogate_oracle.py), through the C-ABI. Neighbour indices must be
+BIT-EXACT; floating-point outputs within 1e-5 relative (north_star's bar), measured on the whole
+tensor and per row (rows with a tiny reference norm are measured against the RMS row norm)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import global_rel, row_rel
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _plummer_pos(n, seed):
+    from nbd.plummer import generate_plummer
+    p, v, m = generate_plummer(n, seed=seed)
+    return (torch.tensor(p, dtype=torch.float32), torch.tensor(v, dtype=torch.float32),
+            torch.tensor(m, dtype=torch.float32))
+
+
+def _batch(n, sizes):
+    b = torch.cat([torch.full((s,), i, dtype=torch.int64) for i, s in enumerate(sizes)])
+    assert b.numel() == n
+    return b
+
+
+# ------------------------------------------------------------------ graph build: index-exact
+@pytest.mark.parametrize("n,k", [(1, 5), (2, 1), (10, 3), (10, 50), (65, 10), (200, 64), (500, 32), (500, 50),
+                                 (300, 100), (400, 200), (4096, 32)])
+def test_knn_graph_bit_exact(n, k, gpu_device):
+    from nbd import graphops
+    from oracle import surrogate_oracle as so
+    pos, _, _ = _plummer_pos(n, 10 + n)
+    ref = so.knn_graph(pos, k)
+    got = graphops.knn_graph(pos.cuda(), k).cpu()
+    assert got.dtype == torch.int64 and got.shape == ref.shape
+    assert torch.equal(got, ref)
+
+
+def test_knn_graph_ties_and_loop(gpu_device):
+    """Lattice points make exact distance ties: the lower index must win, as specified."""
+    from nbd import graphops
+    from oracle import surrogate_oracle as so
+    g = torch.arange(6, dtype=torch.float32)
+    pos = torch.stack(torch.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).contiguous()    # 216 points
+    for k, loop in ((6, False), (7, True), (26, False), (70, False)):
+        assert torch.equal(graphops.knn_graph(pos.cuda(), k, loop=loop).cpu(), so.knn_graph(pos, k, loop=loop))
+
+
+def test_knn_graph_batched(gpu_device):
+    from nbd import graphops
+    from oracle import surrogate_oracle as so
+    pos, _, _ = _plummer_pos(300, 4)
+    b = _batch(300, [100, 3, 1, 130, 66])
+    for k in (2, 10, 70):
+        assert torch.equal(graphops.knn_graph(pos.cuda(), k, batch=b.cuda()).cpu(), so.knn_graph(pos, k, batch=b))
+
+
+@pytest.mark.parametrize("n,r,loop,cap", [(1, 1.0, True, 32), (50, 0.5, False, 32), (500, 1.0, True, 32),
+                                          (500, 1.0, False, 32), (500, 0.3, True, 4), (2000, 1.0, True, 32),
+                                          (300, 100.0, True, 7)])
+def test_radius_graph_bit_exact(n, r, loop, cap, gpu_device):
+    from nbd import graphops
+    from oracle import surrogate_oracle as so
+    pos, _, _ = _plummer_pos(n, 20 + n)
+    ref = so.radius_graph(pos, r, loop=loop, max_num_neighbors=cap)
+    got = graphops.radius_graph(pos.cuda(), r, loop=loop, max_num_neighbors=cap).cpu()
+    assert torch.equal(got, ref)
+    # the transposed lists are the same edges sorted (stably) by edge_index[0]
+    lists = graphops.radius_lists(pos.cuda(), r, loop=loop, max_num_neighbors=cap)
+    order = torch.sort(ref[0], stable=True).indices
+    e = ref.shape[1]
+    assert int(lists.rowptr[-1]) == e
+    assert torch.equal(lists.centres[:e].cpu().to(torch.int64), ref[1][order])
+    assert torch.equal(lists.rowptr.cpu().to(torch.int64)[1:], torch.cumsum(torch.bincount(ref[0], minlength=n), 0))
+
+
+def test_radius_graph_batched(gpu_device):
+    from nbd import graphops
+    from oracle import surrogate_oracle as so
+    pos, _, _ = _plummer_pos(400, 9)
+    b = _batch(400, [150, 1, 249])
+    ref = so.radius_graph(pos, 1.0, batch=b, loop=True, max_num_neighbors=16)
+    assert torch.equal(graphops.radius_graph(pos.cuda(), 1.0, batch=b.cuda(), loop=True, max_num_neighbors=16).cpu(), ref)
+
+
+# ------------------------------------------------------------------ dense blocks
+@pytest.mark.parametrize("n,k,m", [(1, 4, 3), (100, 4, 128), (4096, 8, 64), (333, 7, 5), (1000, 68, 3), (257, 64, 64),
+                                   (700, 128, 128), (129, 1000, 130), (64, 256, 32)])
+def test_linear_matches_torch(n, k, m, gpu_device):
+    from nbd import nnops
+    g = torch.Generator().manual_seed(n * 7 + k)
+    x, w, b = torch.randn(n, k, generator=g), torch.randn(m, k, generator=g) / k ** 0.5, torch.randn(m, generator=g)
+    ref = x.double() @ w.double().t() + b.double()
+    got = nnops.linear(x.cuda(), w.cuda(), b.cuda()).cpu()
+    assert global_rel(got, ref) < 2e-6
+    got_t = nnops.linear(x.cuda(), w.cuda(), b.cuda(), act="tanh").cpu()
+    assert (got_t.double() - torch.tanh(ref)).abs().max() < 5e-6
+    # no bias, row scale, bias row scale, strided output slice
+    rs, brs = torch.rand(n, generator=g) + 0.5, torch.rand(n, generator=g)
+    wide = torch.zeros(n, m + 5).cuda()
+    nnops.linear(x.cuda(), w.cuda(), b.cuda(), out=wide[:, 5:], rowscale=rs.cuda(), bias_rowscale=brs.cuda())
+    ref2 = rs.double()[:, None] * (x.double() @ w.double().t()) + brs.double()[:, None] * b.double()
+    assert global_rel(wide[:, 5:].cpu(), ref2) < 2e-6 and (wide[:, :5] == 0).all()
+
+
+def test_linear_asymmetric_operands(gpu_device):
+    """A = I against an asymmetric W catches a transposed fragment map (MFMA C/D layout)."""
+    from nbd import nnops
+    w = torch.arange(96 * 64, dtype=torch.float32).reshape(96, 64)
+    out = nnops.linear(torch.eye(64).cuda(), w.cuda()).cpu()
+    assert torch.equal(out, w.t())
+
+
+def test_layernorm_matches_torch(gpu_device):
+    from nbd import nnops
+    for n, c in ((5, 68), (1000, 256), (77, 4), (300, 130)):
+        x = torch.randn(n, c) * 3 + 1
+        ln = torch.nn.LayerNorm(c)
+        with torch.no_grad():
+            ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-1, 1)
+            ref = ln(x)
+        got = nnops.layernorm(x.cuda(), ln.weight.detach().cuda(), ln.bias.detach().cuda(), ln.eps).cpu()
+        assert (got - ref).abs().max() < 5e-6
+
+
+def _copy_state(dst, src):
+    missing = dst.load_state_dict(src.state_dict(), strict=True)
+    return missing
+
+
+# ------------------------------------------------------------------ GNN
+@pytest.mark.parametrize("cfg", [
+    dict(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", neighbors=10),            # published (gnn_experiment.py:61-72)
+    dict(input_dim=4, gnn_dim=32, message_passing_steps=3, aggr="sum", neighbors=5, output_hiddens=[16, 8]),
+    dict(input_dim=7, gnn_dim=48, message_passing_steps=1, aggr="mean", neighbors=8, node_encoder_dims=[20, 24]),
+])
+def test_gnn_forward_matches_oracle(cfg, gpu_device):
+    import gnn
+    from nbd.data import Data
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(1)
+    ocfg = {k: v for k, v in cfg.items()}
+    ora = so.GraphModelOracle(**ocfg).eval()
+    model = gnn.GraphModel(device="cuda", **cfg)
+    _copy_state(model, ora)
+    pos, vel, m = _plummer_pos(700, 5)
+    x7 = torch.cat([pos, vel, m[:, None] * 700], 1)
+    ei = so.knn_graph(pos, cfg["neighbors"])
+    with torch.no_grad():
+        ref = ora.forward_graph(x7, ei)
+    got = model.predict_graph(Data(x=x7.cuda(), edge_index=ei.cuda())).cpu()
+    assert global_rel(got, ref) < TOL and row_rel(got, ref) < 10 * TOL
+    # ragged graph (arbitrary edge order, a node without edges): general CSR path
+    keep = torch.rand(ei.shape[1], generator=torch.Generator().manual_seed(3)) < 0.7
+    keep &= ei[1] != 13
+    ei2 = ei[:, keep][:, torch.randperm(int(keep.sum()), generator=torch.Generator().manual_seed(4))]
+    with torch.no_grad():
+        ref2 = ora.forward_graph(x7, ei2)
+    got2 = model.predict_graph(Data(x=x7.cuda(), edge_index=ei2.cuda())).cpu()
+    assert global_rel(got2, ref2) < TOL
+
+
+def test_gnn_predict_uses_k50_like_reference(gpu_device):
+    import gnn
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(2)
+    ora = so.GraphModelOracle(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", neighbors=10).eval()
+    model = gnn.GraphModel(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", neighbors=10, device="cuda")
+    _copy_state(model, ora)
+    pos, vel, m = _plummer_pos(512, 6)
+    feat = torch.cat([vel, m[:, None] * 512], 1)
+    ref = ora.predict(pos, feat, k=50)
+    got = model.predict(pos.cuda(), feat.cuda()).cpu()
+    assert global_rel(got, ref) < TOL
+    assert global_rel(model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu(), ora.predict(pos, feat, k=32)) < TOL
+    data = gnn.transform_to_graph(pos.cuda(), feat.cuda(), torch.zeros(512, 3).cuda())
+    assert data.edge_index.shape == (2, 512 * 50) and data.x.shape == (512, 7)
+    assert model.neighbors == 10 and model.get_config()["gnn_dim"] == 64
+
+
+# ------------------------------------------------------------------ ContinuousConv
+@pytest.mark.parametrize("agg,D,I,O", [("mean", 4, 8, 16), ("sum", 6, 4, 8), ("mean", 3, 70, 40)])
+def test_contconv_layer_matches_oracle(agg, D, I, O, gpu_device):
+    """One ContinuousConv layer vs the oracle, which calls F.grid_sample exactly as contconv.py:73-75."""
+    import contconv
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(D)
+    pos, _, _ = _plummer_pos(400, 8)
+    feat = torch.randn(400, I)
+    ora = so.ContinuousConvOracle(I, O, D, radius=1.0, agg=agg)
+    layer = contconv.ContinuousConv(I, O, D, radius=1.0, agg=agg).cuda()
+    _copy_state(layer, ora)
+    ei = so.radius_graph(pos, 1.0, loop=True, max_num_neighbors=32)
+    with torch.no_grad():
+        ref = ora(pos, feat, ei)
+        got = layer(pos.cuda(), feat.cuda(), edge_index=ei.cuda()).cpu()
+    assert global_rel(got, ref) < TOL and row_rel(got, ref) < 10 * TOL
+
+
+def test_contconv_model_matches_oracle(gpu_device):
+    import contconv
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(3)
+    cfg = dict(in_channels=4, out_channels=3, filter_resolution=[4, 3], radius=1.0, agg="mean", self_loops=True,
+               continuous_conv_layers=2, continuous_conv_dim=16, encoder_hiddens=[8, 12], decoder_hiddens=[10, 6])
+    ora = so.ContinuousConvModelOracle(**cfg)
+    with torch.no_grad():                       # non-trivial BatchNorm running statistics
+        for nrm in ora.node_encoder.norms:
+            nrm.module.running_mean.uniform_(-0.5, 0.5); nrm.module.running_var.uniform_(0.5, 2.0)
+            nrm.module.weight.uniform_(0.5, 1.5); nrm.module.bias.uniform_(-0.3, 0.3)
+    ora.eval()
+    model = contconv.ContinuousConvModel(device="cuda", **cfg)
+    _copy_state(model, ora)
+    pos, vel, m = _plummer_pos(600, 12)
+    feat = torch.cat([vel, m[:, None] * 600], 1)
+    ref = ora.predict(pos, feat)
+    got = model.predict(pos.cuda(), feat.cuda()).cpu()
+    assert global_rel(got, ref) < TOL and row_rel(got, ref) < 10 * TOL
+    assert model.neighbors == 0
+    # no encoder / no self loops / sum aggregation / single Linear head
+    cfg2 = dict(in_channels=4, out_channels=3, filter_resolution=[5], radius=0.7, agg="sum", self_loops=False,
+                continuous_conv_layers=1, continuous_conv_dim=24)
+    ora2 = so.ContinuousConvModelOracle(**cfg2).eval()
+    model2 = contconv.ContinuousConvModel(device="cuda", **cfg2)
+    _copy_state(model2, ora2)
+    assert global_rel(model2.predict(pos.cuda(), feat.cuda()).cpu(), ora2.predict(pos, feat)) < TOL
+    with pytest.raises(AttributeError):
+        contconv.ContinuousConvModel(filter_resolution=4)
+
+
+# ------------------------------------------------------------------ Trainer
+def test_trainer_step_and_rollout(gpu_device):
+    import gnn
+    import trainer
+    from nbd.data import Data
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(4)
+    ora = so.GraphModelOracle(input_dim=4, gnn_dim=32, message_passing_steps=2, aggr="mean", neighbors=10).eval()
+    model = gnn.GraphModel(input_dim=4, gnn_dim=32, message_passing_steps=2, aggr="mean", neighbors=10, device="cuda")
+    _copy_state(model, ora)
+    tr = trainer.Trainer(model, optimizer=None, device="cuda", dt=0.01)
+    n, steps, dt = 128, 4, 0.01
+    pos, vel, m = _plummer_pos(n, 2)
+    m1 = (m * n)[:, None]
+    acc = ora.predict(pos, torch.cat([vel, m1], 1))
+    # one Trainer.step (trainer.py:217-226) vs the oracle restatement
+    p_ref, v_ref, a_ref = so.trainer_step(lambda p, f: ora.predict(p, f), pos, vel, m1, acc, dt)
+    p_got, v_got, a_got = tr.step(pos.cuda(), vel.cuda(), m1.cuda(), acc.cuda(), dt)
+    assert torch.equal(p_got.cpu(), p_ref)                     # kick/drift are bit-exact given the same acc
+    assert global_rel(a_got.cpu(), a_ref) < TOL and global_rel(v_got.cpu(), v_ref) < TOL
+    # evaluate_rollout: ground truth = the oracle rollout itself -> errors ~ fp32 noise, schema as reference
+    xs, ys, st = [], [], []
+    p, v, a = pos, vel, acc
+    for s in range(steps):
+        xs.append(torch.cat([p, v, m1], 1)); ys.append(a); st.append(torch.full((n,), s))
+        p, v, a = so.trainer_step(lambda pp, ff: ora.predict(pp, ff), p, v, m1, a, dt)
+    data = Data(x=torch.cat(xs), y=torch.cat(ys), step=torch.cat(st), scene=torch.zeros(n * steps, dtype=torch.int64))
+    import pandas as pd
+    df = tr.evaluate_rollout("f.csv", data, 0, steps, dt, pd.DataFrame(columns=trainer.ROLLOUT_COLUMNS))
+    assert list(df.columns) == trainer.ROLLOUT_COLUMNS and len(df) == n * steps
+    assert (df["step"].values == np.repeat(np.arange(steps), n)).all() and (df["step_time"] > 0).all()
+    for c in ("x", "vx", "ax"):
+        err = np.abs(df[c].astype(float) - df[f"pred_{c}"].astype(float)).max()
+        assert err < 1e-4 * np.abs(df[c].astype(float)).max()
+    mse = trainer.rollout_mse(df)
+    assert len(mse) == steps and (mse["pos_mse"] < 1e-10).all()
