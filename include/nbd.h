@@ -159,10 +159,13 @@ int nbd_ell_to_edge_index(const int* nbr, const int* deg, const int* ptr, int n,
  * act 0 = identity, 1 = tanh; bias, rowscale, bias_rowscale may be NULL (= 0, 1, 1).
  * torch.nn.Linear layout (w is out x in); ld* are row strides in floats, so inputs/outputs may be
  * column slices of wider buffers (replaces torch.cat). fp32-input MFMA, exact fp32 arithmetic.
- * Used for gnn.py:57-63,75-93,105-114 and contconv.py:92,136-141,206-216. */
+ * Used for gnn.py:57-63,75-93,105-114 and contconv.py:92,136-141,206-216. Deterministic. */
 int nbd_linear_f32(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* rowscale,
                    const float* bias_rowscale, int act, float* y, int ldy, int n_rows, int n_cols, int k,
-                   nbd_stream_t stream);
+                   void* workspace, size_t workspace_bytes, nbd_stream_t stream);
+/* Scratch for the split-K path of large products (0 for small ones). Without it the call still
+ * succeeds through the un-split kernel. */
+size_t nbd_linear_workspace_bytes(int n_rows, int n_cols, int k);
 
 /* EdgeConv aggregation (gnn.py:75-93) after the per-node factoring of its first Linear:
  * pq[i] = [P_i (h) | Q_i (h)], s[i] = aggr_j tanh(P_i + Q_j) over the edges of target i, i.e.
@@ -180,7 +183,7 @@ int nbd_layernorm_f32(const float* x, int ldx, int c, const float* gamma, const 
  *      window_e * trilinear_weight_e(cell) * feat[centre_e][i],   cell = (z*D + y)*D + x,
  * window/ball_to_cube/grid_sample(align_corners=True) exactly as contconv.py:30-33,53-78,85-90, so
  * that ContinuousConv = scatter_mean(...) = rowscale * (a_out . filters.reshape(D^3*I, O)).
- * rowptr/centres: CSR by aggregation target (nbd_radius_transpose_*). D <= 8. */
+ * rowptr/centres: CSR by aggregation target (nbd_radius_transpose_*). D <= 15. */
 int nbd_contconv_bin_f32(const float* pos, const float* feat, int ldf, int in_channels, const int* rowptr,
                          const int* centres, int n, int filter_resolution, float radius_sq, float* a_out,
                          nbd_stream_t stream);

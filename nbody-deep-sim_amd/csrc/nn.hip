@@ -114,6 +114,146 @@ __global__ __launch_bounds__(256) void linear_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------ big linear: 128x128x32 tiles, split-K
+// For the ContinuousConv contraction (rows = nodes, K = D^3*I up to 27 648, 128 output channels).
+// Block 256 threads = 2x2 waves, each wave a 64x64 strip = 2x2 MFMA 32x32 tiles (64 accumulator regs).
+// LDS tiles are [row][k] with a 36-float row stride: 16-B aligned for ds_write_b128 staging and
+// conflict-free for the ds_read_b128 fragment reads (36*i mod 64 hits every 4-bank group once for
+// i = 0..15). A lane's b128 gives 4 k-values for its row; lanes 0-31 take k0..k0+3, lanes 32-63
+// k0+4..k0+7, so MFMA c pairs (k0+c, k0+4+c) -- any pairing is valid as long as A and B agree.
+// Global->register prefetch of tile t+1 is issued before the 64 MFMAs of tile t (one barrier per step).
+// gridDim.z = split-K slices; with more than one slice raw partials go to slabs[z] and
+// linear_finish_kernel applies scale/bias/activation in fixed slice order (deterministic).
+constexpr int G2_BM = 128, G2_BN = 128, G2_LD = 36;
+
+__global__ __launch_bounds__(256) void linear_big_kernel(
+    const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+    const float* __restrict__ rowscale, const float* __restrict__ bias_rowscale, int act, float* __restrict__ Y,
+    int ldy, int n_rows, int n_cols, int K, int k_per_slice, float* __restrict__ slabs) {
+  extern __shared__ float smem[];                 // 2 x (128 + 128) x 36 floats
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int row0 = blockIdx.x * G2_BM, col0 = blockIdx.y * G2_BN;
+  const int k_begin = blockIdx.z * k_per_slice, k_end = min(K, k_begin + k_per_slice);
+  const int q = tid & 7, r0 = tid >> 3;           // 8 lanes x float4 = one 128-B row piece; 32 rows per pass
+
+  f16v acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  f4 pa[4], pb[4];
+  auto load_tile = [&](int k0) {
+    const int k = k0 + 4 * q;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ra = row0 + r0 + 32 * p, rb = col0 + r0 + 32 * p;
+      pa[p] = (ra < n_rows && k < k_end) ? *reinterpret_cast<const f4*>(X + (size_t)ra * ldx + k) : f4{0.f, 0.f, 0.f, 0.f};
+      pb[p] = (rb < n_cols && k < k_end) ? *reinterpret_cast<const f4*>(W + (size_t)rb * ldw + k) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* As = smem + buf * (G2_BM + G2_BN) * G2_LD;
+    float* Bs = As + G2_BM * G2_LD;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<f4*>(As + (r0 + 32 * p) * G2_LD + 4 * q) = pa[p];
+      *reinterpret_cast<f4*>(Bs + (r0 + 32 * p) * G2_LD + 4 * q) = pb[p];
+    }
+  };
+
+  load_tile(k_begin);
+  store_tile(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+    const bool more = k0 + 32 < k_end;
+    if (more) load_tile(k0 + 32);
+    const float* As = smem + buf * (G2_BM + G2_BN) * G2_LD;
+    const float* Bs = As + G2_BM * G2_LD;
+    const float* a_base = As + (wm * 64 + (lane & 31)) * G2_LD + (lane >> 5) * 4;
+    const float* b_base = Bs + (wn * 64 + (lane & 31)) * G2_LD + (lane >> 5) * 4;
+#pragma unroll
+    for (int k8 = 0; k8 < 4; ++k8) {
+      const f4 a0 = *reinterpret_cast<const f4*>(a_base + k8 * 8);
+      const f4 a1 = *reinterpret_cast<const f4*>(a_base + 32 * G2_LD + k8 * 8);
+      const f4 b0 = *reinterpret_cast<const f4*>(b_base + k8 * 8);
+      const f4 b1 = *reinterpret_cast<const f4*>(b_base + 32 * G2_LD + k8 * 8);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b0[c], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b1[c], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b0[c], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b1[c], acc[1][1], 0, 0, 0);
+      }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  const bool direct = gridDim.z == 1;
+  float* dst = direct ? Y : slabs + (size_t)blockIdx.z * n_rows * n_cols;
+  const int ldd = direct ? ldy : n_cols;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = col0 + wn * 64 + b * 32 + (lane & 31);
+      const float bv = (direct && bias && col < n_cols) ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < n_rows && col < n_cols) {
+          float v = acc[a][b][r];
+          if (direct) {
+            if (rowscale) v = __fmul_rn(v, rowscale[row]);
+            const float bb = bias_rowscale ? __fmul_rn(bv, bias_rowscale[row]) : bv;
+            v = act_apply(__fadd_rn(v, bb), act);
+          }
+          dst[(size_t)row * ldd + col] = v;
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void linear_finish_kernel(const float* __restrict__ slabs, int n_slabs,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ rowscale,
+                                                            const float* __restrict__ bias_rowscale, int act,
+                                                            float* __restrict__ Y, int ldy, int n_rows, int n_cols) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)n_rows * n_cols;
+  if (i >= total) return;
+  const int row = (int)(i / n_cols), col = (int)(i - (size_t)row * n_cols);
+  float v = slabs[i];
+  for (int s = 1; s < n_slabs; ++s) v += slabs[(size_t)s * total + i];
+  if (rowscale) v = __fmul_rn(v, rowscale[row]);
+  float b = bias ? bias[col] : 0.f;
+  if (bias_rowscale) b = __fmul_rn(b, bias_rowscale[row]);
+  Y[(size_t)row * ldy + col] = act_apply(__fadd_rn(v, b), act);
+}
+
+struct BigPlan { bool use; int slices, k_per_slice; size_t ws; };
+BigPlan plan_big(int n_rows, int n_cols, int k) {
+  BigPlan p{false, 1, k, 0};
+  if (n_rows < 512 || k < 512 || n_cols < 96) return p;
+  p.use = true;
+  const int blocks = ceil_div(n_rows, G2_BM) * ceil_div(n_cols, G2_BN);
+  int s = ceil_div(512, blocks);
+  const int max_s = k / 256;                        // >= 8 k-steps per slice
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  p.k_per_slice = ceil_div(ceil_div(k, s), 32) * 32;
+  p.slices = ceil_div(k, p.k_per_slice);
+  p.ws = p.slices > 1 ? (size_t)p.slices * n_rows * n_cols * sizeof(float) : 0;
+  return p;
+}
+
 // ------------------------------------------------------------------ EdgeConv aggregation
 // One wave per target node; lanes own channels h, h+64, ... (Q rows are read coalesced).
 // mode: 0 = sum, 1 = mean (sum / max(count,1)), 2 = max (empty -> 0).
@@ -163,52 +303,75 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------ ContinuousConv cell binning
-// grid = (nodes, channel groups of 64); block = one wave, lane = channel. The wave walks the node's
-// incoming edges (CSR by aggregation target = edge_index[0], contconv.py:82,95), evaluates the edge
-// geometry once (wave-uniform) and adds w * feat[c][lane] into the 8 touched cells of an LDS image of
-// this node's A row (cells x 64 channels), then streams the image out and re-zeroes it.
+// grid = (nodes, channel groups of 64); block = one wave, lane = channel. The A row of a node is
+// built one z-slab (D*D cells x 64 channels, <= 16 KiB of LDS) at a time so that many waves fit a
+// CU: for each slab the wave walks the node's incoming edges (CSR by aggregation target =
+// edge_index[0], contconv.py:82,95) in chunks of 64 -- lane e evaluates the geometry of edge e
+// (window, ball_to_cube, trilinear weights) and parks it in LDS -- then every lane (= channel) adds
+// w * feat[c][lane] into the <= 4 touched cells of the slab, and the slab is streamed out (256-B
+// coalesced stores) and re-zeroed.
 // Trilinear weights follow F.grid_sample(align_corners=True) with coordinate component 0 indexing
 // filter axis 2 (x fastest) and component 2 indexing axis 0: cell = (z*D + y)*D + x  (contconv.py:62-75).
+struct EdgeGeo { int c, ix, iy, iz; float tx, ty, tz, window; };
+
 __global__ __launch_bounds__(64) void contconv_bin_kernel(
     const float* __restrict__ pos, const float* __restrict__ feat, int ldf, int I, const int* __restrict__ rowptr,
-    const int* __restrict__ centres, int n, int D, float r2max, float* __restrict__ A, int* __restrict__ indeg_out) {
-  extern __shared__ float img[];            // [cells][64]
+    const int* __restrict__ centres, int n, int D, float r2max, float* __restrict__ A) {
+  extern __shared__ float img[];            // [D*D][64] slab image, then 64 EdgeGeo records
   const int node = blockIdx.x, cg = blockIdx.y, lane = threadIdx.x;
   const int ch = cg * 64 + lane;
-  const int cells = D * D * D;
-  for (int c = 0; c < cells; ++c) img[c * 64 + lane] = 0.f;
+  const int slab_cells = D * D;
+  EdgeGeo* geo = reinterpret_cast<EdgeGeo*>(img + slab_cells * 64);
   const float xn = pos[3 * node], yn = pos[3 * node + 1], zn = pos[3 * node + 2];
   const float half = (float)(D - 1) / 2.0f;
   const int e0 = rowptr[node], e1 = rowptr[node + 1];
-  for (int e = e0; e < e1; ++e) {
-    const int c = centres[e];
-    // r = positions[col] - positions[row] (contconv.py:84): centre minus this node
-    const float rx = pos[3 * c] - xn, ry = pos[3 * c + 1] - yn, rz = pos[3 * c + 2] - zn;
-    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz));
-    if (!(d2 < r2max)) continue;                                   // window = 0 (contconv.py:86-87)
-    const float q = 1.0f - d2 / r2max;
-    const float window = q * q * q;
-    const float nrm = sqrtf(d2);
-    const float sc = tanhf(nrm) / (nrm + 1e-8f);                   // ball_to_cube (contconv.py:30-33)
-    const float gx = (rx * sc + 1.0f) * half, gy = (ry * sc + 1.0f) * half, gz = (rz * sc + 1.0f) * half;
-    const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
-    const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-    const float tx = gx - fx, ty = gy - fy, tz = gz - fz;
-    const float f = (ch < I) ? feat[(size_t)c * ldf + ch] * window : 0.f;
+  for (int c = 0; c < slab_cells; ++c) img[c * 64 + lane] = 0.f;
+  for (int z = 0; z < D; ++z) {
+    for (int eb = e0; eb < e1; eb += 64) {
+      const int cnt = min(64, e1 - eb);
+      if (lane < cnt) {
+        EdgeGeo g;
+        g.c = centres[eb + lane];
+        // r = positions[col] - positions[row] (contconv.py:84): centre minus this node
+        const float rx = pos[3 * g.c] - xn, ry = pos[3 * g.c + 1] - yn, rz = pos[3 * g.c + 2] - zn;
+        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz));
+        const float qq = 1.0f - d2 / r2max;
+        g.window = (d2 < r2max) ? qq * qq * qq : 0.f;                  // contconv.py:85-87
+        const float nrm = sqrtf(d2);
+        const float sc = tanhf(nrm) / (nrm + 1e-8f);                   // ball_to_cube (contconv.py:30-33)
+        const float gx = (rx * sc + 1.0f) * half, gy = (ry * sc + 1.0f) * half, gz = (rz * sc + 1.0f) * half;
+        const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+        g.ix = (int)fx; g.iy = (int)fy; g.iz = (int)fz;
+        g.tx = gx - fx; g.ty = gy - fy; g.tz = gz - fz;
+        geo[lane] = g;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int e = 0; e < cnt; ++e) {
+        const EdgeGeo g = geo[e];                                      // wave-uniform LDS broadcast
+        const int az = z - g.iz;                                       // 0 or 1 if this edge touches slab z
+        if ((az != 0 && az != 1) || g.window == 0.f) continue;
+        const float wz = (az ? g.tz : 1.0f - g.tz) * g.window;
+        const float f = (ch < I) ? feat[(size_t)g.c * ldf + ch] * wz : 0.f;
 #pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-      const int ax = corner & 1, ay = (corner >> 1) & 1, az = corner >> 2;
-      const int cx = ix + ax, cy = iy + ay, cz = iz + az;
-      if (cx < 0 || cx >= D || cy < 0 || cy >= D || cz < 0 || cz >= D) continue;   // zero padding
-      const float w = (ax ? tx : 1.0f - tx) * (ay ? ty : 1.0f - ty) * (az ? tz : 1.0f - tz);
-      img[((cz * D + cy) * D + cx) * 64 + lane] += w * f;
+        for (int corner = 0; corner < 4; ++corner) {
+          const int ax = corner & 1, ay = corner >> 1;
+          const int cx = g.ix + ax, cy = g.iy + ay;
+          if (cx < 0 || cx >= D || cy < 0 || cy >= D) continue;        // zero padding of grid_sample
+          const float w = (ax ? g.tx : 1.0f - g.tx) * (ay ? g.ty : 1.0f - g.ty);
+          img[(cy * D + cx) * 64 + lane] += w * f;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (ch < I) {
+      float* dst = A + ((size_t)node * D * slab_cells + (size_t)z * slab_cells) * I + ch;
+      for (int c = 0; c < slab_cells; ++c) { dst[(size_t)c * I] = img[c * 64 + lane]; img[c * 64 + lane] = 0.f; }
+    } else {
+      for (int c = 0; c < slab_cells; ++c) img[c * 64 + lane] = 0.f;
     }
   }
-  if (ch < I) {
-    float* dst = A + (size_t)node * cells * I + ch;
-    for (int c = 0; c < cells; ++c) dst[(size_t)c * I] = img[c * 64 + lane];
-  }
-  if (indeg_out && cg == 0 && lane == 0) indeg_out[node] = e1 - e0;
 }
 
 // rowscale[n] = 1 / max(indeg, 1) for mean aggregation, 1 for sum (scatter, contconv.py:95-97)
@@ -241,15 +404,37 @@ int launch_linear(const float* X, int ldx, const float* W, int ldw, const float*
 
 extern "C" {
 
+size_t nbd_linear_workspace_bytes(int n_rows, int n_cols, int k) {
+  if (n_rows <= 0 || n_cols <= 0 || k <= 0) return 0;
+  return plan_big(n_rows, n_cols, k).ws;
+}
+
 int nbd_linear_f32(const float* x, int ldx, const float* w, int ldw, const float* bias, const float* rowscale,
                    const float* bias_rowscale, int act, float* y, int ldy, int n_rows, int n_cols, int k,
-                   nbd_stream_t stream) {
+                   void* workspace, size_t workspace_bytes, nbd_stream_t stream) {
   if (n_rows < 0 || n_cols < 0 || k < 0 || act < 0 || act > 1) return NBD_E_BADARG;
   if (n_rows == 0 || n_cols == 0) return 0;
   if (!x || !w || !y || ldx < k || ldw < k || ldy < n_cols) return NBD_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (k % 4 == 0) && (ldx % 4 == 0) && (ldw % 4 == 0) &&
                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0;
+  const BigPlan bp = plan_big(n_rows, n_cols, k);
+  if (vec && bp.use && (bp.slices == 1 || (workspace && workspace_bytes >= bp.ws))) {
+    const size_t shmem = 2 * (G2_BM + G2_BN) * G2_LD * sizeof(float);     // 73 728 B
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_big_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid(ceil_div(n_rows, G2_BM), ceil_div(n_cols, G2_BN), bp.slices);
+    float* slabs = static_cast<float*>(workspace);
+    linear_big_kernel<<<grid, 256, shmem, st>>>(x, ldx, w, ldw, bias, rowscale, bias_rowscale, act, y, ldy, n_rows,
+                                                n_cols, k, bp.k_per_slice, slabs);
+    int rc = status();
+    if (rc || bp.slices == 1) return rc;
+    const size_t total = (size_t)n_rows * n_cols;
+    linear_finish_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(slabs, bp.slices, bias, rowscale, bias_rowscale,
+                                                                          act, y, ldy, n_rows, n_cols);
+    return status();
+  }
   return vec ? launch_linear<true>(x, ldx, w, ldw, bias, rowscale, bias_rowscale, act, y, ldy, n_rows, n_cols, k, st)
              : launch_linear<false>(x, ldx, w, ldw, bias, rowscale, bias_rowscale, act, y, ldy, n_rows, n_cols, k, st);
 }
@@ -280,17 +465,11 @@ int nbd_contconv_bin_f32(const float* pos, const float* feat, int ldf, int in_ch
   if (n < 0 || in_channels <= 0 || filter_resolution < 2) return NBD_E_BADARG;
   if (n == 0) return 0;
   if (!pos || !feat || !rowptr || !centres || !a_out || ldf < in_channels) return NBD_E_BADARG;
-  const int cells = filter_resolution * filter_resolution * filter_resolution;
-  const size_t shmem = (size_t)cells * 64 * sizeof(float);
-  if (shmem > 160 * 1024) return NBD_E_UNSUPPORTED;      // D <= 8
-  if (shmem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(contconv_bin_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return (int)e;
-  }
+  const size_t shmem = (size_t)filter_resolution * filter_resolution * 64 * sizeof(float) + 64 * sizeof(EdgeGeo);
+  if (shmem > 64 * 1024) return NBD_E_UNSUPPORTED;       // D <= 15
   dim3 grid(n, ceil_div(in_channels, 64));
   contconv_bin_kernel<<<grid, 64, shmem, (hipStream_t)stream>>>(pos, feat, ldf, in_channels, rowptr, centres, n,
-                                                                filter_resolution, radius_sq, a_out, nullptr);
+                                                                filter_resolution, radius_sq, a_out);
   return status();
 }
 

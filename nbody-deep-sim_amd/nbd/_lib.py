@@ -77,7 +77,8 @@ SIGNATURES = {
     "nbd_ell_to_edge_index": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
     # --- surrogate models: dense blocks (csrc/nn.hip)
     "nbd_linear_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                               c_int, c_int, c_int, c_int, c_void_p]),
+                               c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "nbd_linear_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "nbd_edgeconv_aggregate_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_void_p, c_int, c_void_p]),
     "nbd_layernorm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,

@@ -37,10 +37,12 @@ def linear(x, w, bias=None, act=None, out=None, rowscale=None, bias_rowscale=Non
     if tuple(out.shape) != (n, m):
         raise _lib.NbdError(f"linear: out is {tuple(out.shape)}, expected {(n, m)}")
     ldy = _mat(out, "out")
+    need = _lib.lib().nbd_linear_workspace_bytes(n, m, k)
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().nbd_linear_f32(x.data_ptr(), ldx, w.data_ptr(), ldw, _vec(bias, m, "bias"),
                                              _vec(rowscale, n, "rowscale"), _vec(bias_rowscale, n, "bias_rowscale"),
-                                             ACT[act], out.data_ptr(), ldy, n, m, k,
+                                             ACT[act], out.data_ptr(), ldy, n, m, k, _lib.ptr(ws), need,
                                              _lib.current_stream(x.device)), "nbd_linear_f32")
     return out
 

@@ -87,7 +87,8 @@ def test_radius_graph_batched(gpu_device):
 
 # ------------------------------------------------------------------ dense blocks
 @pytest.mark.parametrize("n,k,m", [(1, 4, 3), (100, 4, 128), (4096, 8, 64), (333, 7, 5), (1000, 68, 3), (257, 64, 64),
-                                   (700, 128, 128), (129, 1000, 130), (64, 256, 32)])
+                                   (700, 128, 128), (129, 1000, 130), (64, 256, 32),
+                                   (1000, 2048, 128), (700, 1028, 200), (513, 512, 96)])   # last three: split-K 128x128 path
 def test_linear_matches_torch(n, k, m, gpu_device):
     from nbd import nnops
     g = torch.Generator().manual_seed(n * 7 + k)

@@ -1,0 +1,90 @@
+"""Secondary benchmark (BASELINE configs[2] and [3]): ms per surrogate rollout step on one MI355X.
+  config 3: GraphModel (published shape: input 4, gnn_dim 64, 2 EdgeConv layers, mean) on N = 4096,
+            k = 32 (and k = 50, the reference predict() default)
+  config 4: ContinuousConvModel (published shape: dim 128, filter_resolution [6,4], R = 1, mean,
+            self loops, encoder [32,64], decoder [64,32]) on N = 16384, positions scaled so that the
+            mean radius-1 degree is ~32
+Weights: torch.manual_seed(0) default initialisers (no trained weights are published)."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "nbody-deep-sim_amd"), ROOT]
+import numpy as np
+import torch
+import gnn, contconv, trainer
+from nbd import graphops
+from nbd.plummer import generate_plummer
+
+
+def state(n, seed, scale=1.0):
+    p, v, m = generate_plummer(n, seed=seed)
+    pos = torch.tensor(p * scale, dtype=torch.float32, device="cuda")
+    vel = torch.tensor(v, dtype=torch.float32, device="cuda")
+    m1 = torch.tensor(m * n, dtype=torch.float32, device="cuda")[:, None]
+    return pos, vel, m1
+
+
+def timeit(fn, iters, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters, (time.perf_counter() - t0) / iters * 1e3
+
+
+def degree_scale_for(n, target=32.0, seed=1234):
+    """Scale factor on Plummer positions so the mean number of bodies within radius 1 is ~target."""
+    pos, _, _ = state(n, seed)
+    lo, hi = 0.05, 50.0
+    for _ in range(30):
+        mid = (lo * hi) ** 0.5
+        lists = graphops.radius_lists(pos * mid, 1.0, loop=True, max_num_neighbors=1 << 20 if n <= 4096 else 4096,
+                                      transpose=False)
+        deg = lists.deg.float().mean().item()
+        lo, hi = (mid, hi) if deg > target else (lo, mid)
+    return mid, deg
+
+
+out = {}
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+torch.manual_seed(0)
+model = gnn.GraphModel(input_dim=4, node_encoder_dims=None, gnn_dim=64, message_passing_steps=2, aggr="mean",
+                       output_hiddens=None, device="cuda", neighbors=10, scale_factor=1e6)
+tr = trainer.Trainer(model, None, device="cuda", dt=1e-4)
+pos, vel, m1 = state(4096, 1234)
+for k in (32, 50):
+    acc = model.predict(pos, torch.cat([vel, m1], 1), neighbors=k)
+    st = [pos, vel, acc]
+    def step():
+        p_, v_ = st[0].clone(), st[1].clone()
+        from nbd import direct
+        direct.kick_drift(p_, v_, st[2], None, direct.f32(0.5e-4), direct.f32(1e-4))
+        a_ = model.predict(p_, torch.cat([v_, m1], 1), neighbors=k)
+        direct.kick(v_, a_, direct.f32(0.5e-4))
+        st[:] = [p_, v_, a_]
+    g_ms, w_ms = timeit(step, iters)
+    kn_ms, _ = timeit(lambda: graphops.knn_graph(pos, k), iters)
+    out[f"gnn_n4096_k{k}"] = {"rollout_step_ms_gpu": g_ms, "rollout_step_ms_wall": w_ms, "knn_graph_ms": kn_ms,
+                             "edges": 4096 * k}
+acc = model.predict(pos, torch.cat([vel, m1], 1))
+g_ms, w_ms = timeit(lambda: tr.step(pos, vel, m1, acc, 1e-4), iters)
+out["gnn_n4096_trainer_step_k50"] = {"ms_gpu": g_ms, "ms_wall": w_ms}
+
+torch.manual_seed(0)
+cc = contconv.ContinuousConvModel(in_channels=4, out_channels=3, filter_resolution=[6, 4], radius=1.0, agg="mean",
+                                  self_loops=True, continuous_conv_layers=2, continuous_conv_dim=128,
+                                  encoder_hiddens=[32, 64], encoder_dropout=0.0, decoder_hiddens=[64, 32],
+                                  device="cuda", scale_factor=1e6).eval()
+n = 16384
+scale, deg = degree_scale_for(n)
+pos, vel, m1 = state(n, 1234, scale)
+lists = graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32)
+tr2 = trainer.Trainer(cc, None, device="cuda", dt=1e-4)
+acc = cc.predict(pos, torch.cat([vel, m1], 1))
+g_ms, w_ms = timeit(lambda: tr2.step(pos, vel, m1, acc, 1e-4), max(iters // 2, 3))
+r_ms, _ = timeit(lambda: graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32), max(iters // 2, 3))
+out["contconv_n16384"] = {"rollout_step_ms_gpu": g_ms, "rollout_step_ms_wall": w_ms, "radius_lists_ms": r_ms,
+                          "position_scale": scale, "mean_uncapped_degree": deg,
+                          "edges_capped": int(lists.rowptr[-1]), "max_in_degree": int((lists.rowptr[1:] - lists.rowptr[:-1]).max())}
+print(json.dumps(out, indent=1))
