@@ -55,12 +55,13 @@ def cpu_baseline(n, seed, budget_s, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles-per-gpu", type=int, default=PARTICLES_PER_GPU)
     ap.add_argument("--n-total", type=int, default=0, help="fix the TOTAL particle count (strong scaling)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-surrogates", action="store_true", help="skip the secondary GNN / ContConv rollout timings")
     args = ap.parse_args()
 
     import torch
@@ -177,6 +178,11 @@ def main():
         out["cpu_baseline"] = cpu_baseline(min(n_total, 65536), args.seed, args.cpu_seconds, threads)
     elif world > 1:
         out["cpu_baseline"] = None
+    if world == 1 and not strong and not args.no_surrogates:
+        # secondary legs (BASELINE configs[2], [3]): ms per surrogate rollout step + rollout MSE
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_surrogates
+        out["secondary"] = bench_surrogates.run(10)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -267,3 +267,36 @@ def test_trainer_step_and_rollout(gpu_device):
         assert err < 1e-4 * np.abs(df[c].astype(float)).max()
     mse = trainer.rollout_mse(df)
     assert len(mse) == steps and (mse["pos_mse"] < 1e-10).all()
+
+
+def test_test_from_dir_on_a_generated_csv(tmp_path, gpu_device):
+    """End to end: a dataset CSV in the reference's wire format (s01-dataset-generation.py:108-125)
+    written from the HIP integrator -> datautils -> Trainer.test_from_dir -> the reference's two
+    result frames (trainer.py:197-200)."""
+    import csv
+    import gnn
+    import trainer
+    from galaxify import simulation
+    from nbd.plummer import generate_plummer
+    steps, dt = 5, 0.01
+    path = tmp_path / "data"
+    path.mkdir()
+    with open(path / "output_file_1.csv", "w", newline="") as f:
+        wr = csv.writer(f)
+        wr.writerow(["scene", "scene_type", "step", "step_time", "mass", "x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az", "u", "k"])
+        for scene, n in enumerate((20, 33)):
+            p, v, m = generate_plummer(n, seed=scene)
+            sim = simulation.LeapFrogSimulator(positions=p, velocities=v, masses=m, dt=dt, device="cuda")
+            for st in sim.run(steps):
+                for i in range(n):
+                    wr.writerow([scene, "plummer", st.step, st.step_time, m[i], *st.positions[i].tolist(),
+                                 *st.velocities[i].tolist(), *st.accelerations[i].tolist(), st.u_energy, st.k_energy])
+    torch.manual_seed(0)
+    model = gnn.GraphModel(input_dim=4, gnn_dim=16, message_passing_steps=2, aggr="mean", neighbors=4, device="cuda")
+    tr = trainer.Trainer(model, optimizer=None, device="cuda", dt=dt)
+    df_step, df_roll = tr.test_from_dir(str(path), sim_steps=steps)
+    assert list(df_step.columns) == ["loss", "step_time"] and len(df_step) == 2
+    assert list(df_roll.columns) == ["pos_rmse", "vel_rmse", "acc_rmse"] and len(df_roll) == 2 * steps
+    assert np.isfinite(df_roll.values).all() and (df_roll.loc[("output_file_1.csv", 0, 0)][["pos_rmse", "vel_rmse"]] == 0).all()
+    with pytest.raises(NotImplementedError):
+        tr.train_from_dir(str(path), 1, 1, 0)

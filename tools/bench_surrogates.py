@@ -46,45 +46,69 @@ def degree_scale_for(n, target=32.0, seed=1234):
     return mid, deg
 
 
-out = {}
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-torch.manual_seed(0)
-model = gnn.GraphModel(input_dim=4, node_encoder_dims=None, gnn_dim=64, message_passing_steps=2, aggr="mean",
-                       output_hiddens=None, device="cuda", neighbors=10, scale_factor=1e6)
-tr = trainer.Trainer(model, None, device="cuda", dt=1e-4)
-pos, vel, m1 = state(4096, 1234)
-for k in (32, 50):
-    acc = model.predict(pos, torch.cat([vel, m1], 1), neighbors=k)
-    st = [pos, vel, acc]
-    def step():
-        p_, v_ = st[0].clone(), st[1].clone()
-        from nbd import direct
-        direct.kick_drift(p_, v_, st[2], None, direct.f32(0.5e-4), direct.f32(1e-4))
-        a_ = model.predict(p_, torch.cat([v_, m1], 1), neighbors=k)
-        direct.kick(v_, a_, direct.f32(0.5e-4))
-        st[:] = [p_, v_, a_]
-    g_ms, w_ms = timeit(step, iters)
-    kn_ms, _ = timeit(lambda: graphops.knn_graph(pos, k), iters)
-    out[f"gnn_n4096_k{k}"] = {"rollout_step_ms_gpu": g_ms, "rollout_step_ms_wall": w_ms, "knn_graph_ms": kn_ms,
-                             "edges": 4096 * k}
-acc = model.predict(pos, torch.cat([vel, m1], 1))
-g_ms, w_ms = timeit(lambda: tr.step(pos, vel, m1, acc, 1e-4), iters)
-out["gnn_n4096_trainer_step_k50"] = {"ms_gpu": g_ms, "ms_wall": w_ms}
+def rollout_mse_vs_direct(model, n, k, steps, dt=0.01, seed=1234):
+    """BASELINE 'rollout MSE': surrogate rollout (Trainer.step) against the direct-force HIP integrator
+    from the same initial state, true MSE over particles x xyz at the last step. With the random-init
+    weights used here this exercises the harness, not a trained model's quality."""
+    from galaxify import simulation
+    p, v, m = generate_plummer(n, seed=seed)
+    sim = simulation.LeapFrogSimulator(positions=p, velocities=v, masses=m, dt=dt, calc_energy=False, device="cuda")
+    pos, vel, m1 = state(n, seed)
+    tr = trainer.Trainer(model, None, device="cuda", dt=dt)
+    kw = {"neighbors": k} if k else {}
+    acc = model.predict(pos, torch.cat([vel, m1], 1), **kw)
+    for _ in range(steps):
+        sim.step()
+        pos, vel, acc = tr.step(pos, vel, m1, acc, dt)
+    return {"steps": steps, "pos_mse": ((pos - sim.positions) ** 2).mean().item(),
+            "vel_mse": ((vel - sim.velocities) ** 2).mean().item(),
+            "acc_mse": ((acc - sim.accelerations) ** 2).mean().item(), "weights": "random init (seed 0)"}
 
-torch.manual_seed(0)
-cc = contconv.ContinuousConvModel(in_channels=4, out_channels=3, filter_resolution=[6, 4], radius=1.0, agg="mean",
-                                  self_loops=True, continuous_conv_layers=2, continuous_conv_dim=128,
-                                  encoder_hiddens=[32, 64], encoder_dropout=0.0, decoder_hiddens=[64, 32],
-                                  device="cuda", scale_factor=1e6).eval()
-n = 16384
-scale, deg = degree_scale_for(n)
-pos, vel, m1 = state(n, 1234, scale)
-lists = graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32)
-tr2 = trainer.Trainer(cc, None, device="cuda", dt=1e-4)
-acc = cc.predict(pos, torch.cat([vel, m1], 1))
-g_ms, w_ms = timeit(lambda: tr2.step(pos, vel, m1, acc, 1e-4), max(iters // 2, 3))
-r_ms, _ = timeit(lambda: graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32), max(iters // 2, 3))
-out["contconv_n16384"] = {"rollout_step_ms_gpu": g_ms, "rollout_step_ms_wall": w_ms, "radius_lists_ms": r_ms,
-                          "position_scale": scale, "mean_uncapped_degree": deg,
-                          "edges_capped": int(lists.rowptr[-1]), "max_in_degree": int((lists.rowptr[1:] - lists.rowptr[:-1]).max())}
-print(json.dumps(out, indent=1))
+
+def run(iters=20):
+    out = {}
+    torch.manual_seed(0)
+    model = gnn.GraphModel(input_dim=4, node_encoder_dims=None, gnn_dim=64, message_passing_steps=2, aggr="mean",
+                           output_hiddens=None, device="cuda", neighbors=10, scale_factor=1e6)
+    tr = trainer.Trainer(model, None, device="cuda", dt=1e-4)
+    pos, vel, m1 = state(4096, 1234)
+    for k in (32, 50):
+        acc = model.predict(pos, torch.cat([vel, m1], 1), neighbors=k)
+        st = [pos, vel, acc]
+        def step():
+            p_, v_ = st[0].clone(), st[1].clone()
+            from nbd import direct
+            direct.kick_drift(p_, v_, st[2], None, direct.f32(0.5e-4), direct.f32(1e-4))
+            a_ = model.predict(p_, torch.cat([v_, m1], 1), neighbors=k)
+            direct.kick(v_, a_, direct.f32(0.5e-4))
+            st[:] = [p_, v_, a_]
+        g_ms, w_ms = timeit(step, iters)
+        kn_ms, _ = timeit(lambda: graphops.knn_graph(pos, k), iters)
+        out[f"gnn_n4096_k{k}"] = {"rollout_step_ms_gpu": g_ms, "rollout_step_ms_wall": w_ms, "knn_graph_ms": kn_ms,
+                                 "edges": 4096 * k}
+    acc = model.predict(pos, torch.cat([vel, m1], 1))
+    g_ms, w_ms = timeit(lambda: tr.step(pos, vel, m1, acc, 1e-4), iters)
+    out["gnn_n4096_trainer_step_k50"] = {"ms_gpu": g_ms, "ms_wall": w_ms}
+
+    torch.manual_seed(0)
+    cc = contconv.ContinuousConvModel(in_channels=4, out_channels=3, filter_resolution=[6, 4], radius=1.0, agg="mean",
+                                      self_loops=True, continuous_conv_layers=2, continuous_conv_dim=128,
+                                      encoder_hiddens=[32, 64], encoder_dropout=0.0, decoder_hiddens=[64, 32],
+                                      device="cuda", scale_factor=1e6).eval()
+    n = 16384
+    scale, deg = degree_scale_for(n)
+    pos, vel, m1 = state(n, 1234, scale)
+    lists = graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32)
+    tr2 = trainer.Trainer(cc, None, device="cuda", dt=1e-4)
+    acc = cc.predict(pos, torch.cat([vel, m1], 1))
+    g_ms, w_ms = timeit(lambda: tr2.step(pos, vel, m1, acc, 1e-4), max(iters // 2, 3))
+    r_ms, _ = timeit(lambda: graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32), max(iters // 2, 3))
+    out["contconv_n16384"] = {"rollout_step_ms_gpu": g_ms, "rollout_step_ms_wall": w_ms, "radius_lists_ms": r_ms,
+                              "position_scale": scale, "mean_uncapped_degree": deg,
+                              "edges_capped": int(lists.rowptr[-1]), "max_in_degree": int((lists.rowptr[1:] - lists.rowptr[:-1]).max())}
+    out["gnn_n4096_rollout_mse_vs_direct"] = rollout_mse_vs_direct(model, 4096, None, 10)
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 20), indent=1))
