@@ -68,6 +68,39 @@ __device__ __forceinline__ void interact(const f4 p, const f2 xi, const f2 yi, c
   az = __builtin_elementwise_fma(w, dz, az);
 }
 
+// Four sources at once for the un-masked kernel: same arithmetic as interact(), but the eight
+// v_rsq_f32 are issued back to back (one asm block). Switching between the quarter-rate
+// transcendental unit and the packed-math stream costs issue cycles on gfx950 (3 fma : 1 rsq mixes
+// run ~10 % under the sum of their parts, tools/ubench_valu.hip), so the switches are batched.
+__device__ __forceinline__ void interact4(const f4* __restrict__ buf, const f2 xi, const f2 yi, const f2 zi,
+                                          const f2 e2, f2& ax, f2& ay, f2& az) {
+  f4 p[4];
+  f2 dx[4], dy[4], dz[4], r2[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    p[u] = buf[u];
+    dx[u] = f2{p[u].x, p[u].x} - xi; dy[u] = f2{p[u].y, p[u].y} - yi; dz[u] = f2{p[u].z, p[u].z} - zi;
+    r2[u] = __builtin_elementwise_fma(dx[u], dx[u], e2);
+    r2[u] = __builtin_elementwise_fma(dy[u], dy[u], r2[u]);
+    r2[u] = __builtin_elementwise_fma(dz[u], dz[u], r2[u]);
+  }
+  asm volatile("v_rsq_f32 %0, %0\n\tv_rsq_f32 %1, %1\n\tv_rsq_f32 %2, %2\n\tv_rsq_f32 %3, %3\n\t"
+               "v_rsq_f32 %4, %4\n\tv_rsq_f32 %5, %5\n\tv_rsq_f32 %6, %6\n\tv_rsq_f32 %7, %7"
+               : "+v"(r2[0].x), "+v"(r2[0].y), "+v"(r2[1].x), "+v"(r2[1].y), "+v"(r2[2].x), "+v"(r2[2].y),
+                 "+v"(r2[3].x), "+v"(r2[3].y));
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const f2 s = r2[u];                       // now (r^2 + eps^2)^(-1/2)
+    const f2 zm = {p[u].z, p[u].w};
+    f2 m_s;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(m_s) : "v"(zm), "v"(s));
+    const f2 w = (s * s) * m_s;
+    ax = __builtin_elementwise_fma(w, dx[u], ax);
+    ay = __builtin_elementwise_fma(w, dy[u], ay);
+    az = __builtin_elementwise_fma(w, dz[u], az);
+  }
+}
+
 // grid = (target groups of 128, slabs); block = 256.
 // Wave (blockIdx.y, w) handles source chunks [jw*cpw, (jw+1)*cpw) with jw = blockIdx.y*4 + w.
 template <bool MASKED>
@@ -103,9 +136,14 @@ __global__ __launch_bounds__(64 * kWaves) void accel_kernel(
     }
     const f4* buf = stage + b * kChunk;
     const int j0 = c * kChunk;
+    if (MASKED) {
 #pragma unroll 4
-    for (int j = 0; j < kChunk; ++j)
-      interact<MASKED>(buf[j], xi, yi, zi, e2, ax, ay, az, j0 + j, tgt_off + i0, tgt_off + i1, n_src);
+      for (int j = 0; j < kChunk; ++j)
+        interact<true>(buf[j], xi, yi, zi, e2, ax, ay, az, j0 + j, tgt_off + i0, tgt_off + i1, n_src);
+    } else {
+#pragma unroll 1
+      for (int j = 0; j < kChunk; j += 4) interact4(buf + j, xi, yi, zi, e2, ax, ay, az);
+    }
   }
 
   // wavefront partials -> LDS -> one coalesced (128 x 3) store per workgroup
@@ -240,13 +278,17 @@ AccelPlan plan_accel(int n_src, int n_tgt) {
   AccelPlan p;
   p.groups = ceil_div(n_tgt, kTgtPerWG);
   p.n_chunks = ceil_div(n_src, kChunk);
-  // fill 256 CUs x 8 workgroups; keep >= 4 chunks per wave; workgroup count a multiple of 2048
-  int want = ceil_div(2048, p.groups);
-  int cap = p.n_chunks / (4 * kWaves);
-  if (cap < 1) cap = 1;
-  if (cap > kMaxSlabs) cap = kMaxSlabs;
-  p.slabs = want < cap ? want : cap;
-  if (p.slabs < 1) p.slabs = 1;
+  // Source split across workgroups. Preferred: ~4 residency rounds (8192 workgroups; measured 2-3 %
+  // faster than exactly one round at N = 65 536, the tail is balanced dynamically) with >= 16 chunks
+  // (1024 sources) per wave. If that cannot even fill the chip once (few targets), go down to one
+  // chunk per wave to get as close to 2048 workgroups = 8 per CU as the problem allows.
+  const int want_fill = ceil_div(2048, p.groups), want_pref = ceil_div(8192, p.groups);
+  const int cap_pref = p.n_chunks / (16 * kWaves), cap_fill = p.n_chunks / kWaves;
+  int slabs = want_pref < cap_pref ? want_pref : cap_pref;
+  if (slabs < want_fill) slabs = want_fill < cap_fill ? want_fill : cap_fill;
+  if (slabs > kMaxSlabs) slabs = kMaxSlabs;
+  if (slabs < 1) slabs = 1;
+  p.slabs = slabs;
   p.cpw = ceil_div(p.n_chunks, p.slabs * kWaves);
   return p;
 }

@@ -50,10 +50,10 @@ def test_host_only_queries():
     assert b"workspace" in L.nbd_strerror(-2)
     g, s, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert L.nbd_accel_plan(65536, 65536, g, s, c) == 0
-    # 512 target groups x 4 slabs x 4 waves = 8192 waves = 8 per SIMD on 256 CUs
-    assert (g.value, s.value, c.value) == (512, 4, 64)
+    # 512 target groups x 16 slabs = 8192 workgroups (4 residency rounds of 8 per CU), 16 chunks per wave
+    assert (g.value, s.value, c.value) == (512, 16, 16)
     assert L.nbd_accel_plan(0, 5, None, None, None) == -1
-    assert L.nbd_step_workspace_bytes(65536) == 4 * 65536 * 12
+    assert L.nbd_step_workspace_bytes(65536) == 16 * 65536 * 12
     for n_src, n_tgt in [(3, 3), (1000, 1000), (65536, 8192), (524288, 65536), (100, 7)]:
         assert L.nbd_accel_plan(n_src, n_tgt, g, s, c) == 0
         chunks = (n_src + 63) // 64
