@@ -57,12 +57,15 @@ __device__ __forceinline__ void interact(const f4 p, const f2 xi, const f2 yi, c
     s.x = (live && j != i0) ? s.x : 0.0f;
     s.y = (live && j != i1) ? s.y : 0.0f;
   }
-  // u = m_j * s with m_j broadcast from the HIGH half of the {z,m} register pair; hipcc does
-  // not fold that splat into op_sel by itself (it inserts a v_mov), hence the one asm line.
+  // w = m_j * s^3 with m_j broadcast from the HIGH half of the {z,m} register pair; hipcc does not
+  // fold that splat into op_sel by itself (it inserts a v_mov), hence the one asm line. The asm
+  // multiply takes s^3 (an ordinary VALU result), never s itself: gfx950 needs a wait state between
+  // a transcendental result and its VALU consumer, and hipcc pads that only for instructions it
+  // can see (an asm consumer right behind v_rsq_f32/v_rcp_f32 reads a stale register).
   const f2 zm = {p.z, p.w};
-  f2 u;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(u) : "v"(zm), "v"(s));
-  const f2 w = (s * s) * u;  // m_j (r^2 + eps^2)^(-3/2)
+  const f2 s3 = (s * s) * s;
+  f2 w;  // m_j (r^2 + eps^2)^(-3/2)
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(w) : "v"(zm), "v"(s3));
   ax = __builtin_elementwise_fma(w, dx, ax);
   ay = __builtin_elementwise_fma(w, dy, ay);
   az = __builtin_elementwise_fma(w, dz, az);
@@ -92,9 +95,9 @@ __device__ __forceinline__ void interact4(const f4* __restrict__ buf, const f2 x
   for (int u = 0; u < 4; ++u) {
     const f2 s = r2[u];                       // now (r^2 + eps^2)^(-1/2)
     const f2 zm = {p[u].z, p[u].w};
-    f2 m_s;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(m_s) : "v"(zm), "v"(s));
-    const f2 w = (s * s) * m_s;
+    const f2 s3 = (s * s) * s;                // compiler-visible consumers of the rsq results (hazard-padded)
+    f2 w;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(w) : "v"(zm), "v"(s3));
     ax = __builtin_elementwise_fma(w, dx[u], ax);
     ay = __builtin_elementwise_fma(w, dy[u], ay);
     az = __builtin_elementwise_fma(w, dz[u], az);
@@ -216,60 +219,120 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const 
   if (i < n) y[i] = __fadd_rn(y[i], __fmul_rn(c, x[i]));
 }
 
-// ---- energies (simulation.py:91-115). One lane per target i, sources broadcast through LDS
-// as in K1; only j > i contributes (triu(1), :113). fp32 per-pair terms, fp64 accumulation.
-__global__ __launch_bounds__(256) void energy_kernel(const f4* __restrict__ posm, const float* __restrict__ vel,
-                                                     int n, int n_pad, float soft, float g,
-                                                     double* __restrict__ partial_u, double* __restrict__ partial_k) {
-  __shared__ f4 tile[256];
-  __shared__ double red_u[4], red_k[4];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const f4 me = posm[min(i, n - 1)];
-  double u = 0.0;
-  // sources j >= first index of this block are the only ones that can satisfy j > i
-  for (int j0 = blockIdx.x * 256; j0 < n_pad; j0 += 256) {
-    __syncthreads();
-    if (j0 + (int)threadIdx.x < n_pad) tile[threadIdx.x] = posm[j0 + threadIdx.x];
-    __syncthreads();
-    const int cnt = min(256, n - j0);
-    float acc = 0.f;
-    for (int jj = 0; jj < cnt; ++jj) {
-      const f4 p = tile[jj];
-      const float dx = p.x - me.x, dy = p.y - me.y, dz = p.z - me.z;
-      const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      const float dist = __fadd_rn(__fsqrt_rn(d2), soft);
-      const float term = __fdiv_rn(__fmul_rn(-g, __fmul_rn(p.w, me.w)), dist);
-      acc += (j0 + jj > i) ? term : 0.f;
-    }
-    u += (double)acc;
+// ---- energies (simulation.py:91-115). U = sum_{i<j} -G m_i m_j / (|r_ij| + eps), K = sum 0.5 m v^2.
+// Same streaming structure as K1 (two targets per lane in packed registers, wave-private LDS-DMA
+// chunks, J-split over waves and slabs) restricted to the upper triangle: a target group only
+// walks the source chunks at or above its own first index; the (at most three) chunks that
+// straddle the diagonal take the masked path (j > i), the rest run mask-free. Per pair
+// 8 packed ops + 1 v_mov + 2 v_sqrt_f32 + 2 v_rcp_f32. fp32 per-lane partial sums, fp64 across lanes/blocks.
+template <bool MASKED>
+__device__ __forceinline__ void energy_pair(const f4 p, const f2 xi, const f2 yi, const f2 zi, const f2 soft,
+                                            f2& u, int j, int i0, int i1, int n) {
+  const f2 dx = f2{p.x, p.x} - xi, dy = f2{p.y, p.y} - yi, dz = f2{p.z, p.z} - zi;
+  f2 d2 = dx * dx;
+  d2 = __builtin_elementwise_fma(dy, dy, d2);
+  d2 = __builtin_elementwise_fma(dz, dz, d2);
+  const f2 den = f2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)} + soft;   // |r| + eps (:105)
+  const f2 inv = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+  f2 t = f2{p.w, p.w} * inv;                  // m_j / den (plain C: the consumer of v_rcp_f32 must be
+                                              // visible to hipcc's hazard padding -- see interact())
+  if (MASKED) {                               // triu(1): strictly above the diagonal (:113)
+    t.x = (j > i0 && j < n) ? t.x : 0.f;
+    t.y = (j > i1 && j < n) ? t.y : 0.f;
   }
+  u += t;
+}
+
+__global__ __launch_bounds__(64 * kWaves) void energy_kernel(const f4* __restrict__ posm, int n, int n_chunks,
+                                                             float soft_, int all_masked,
+                                                             double* __restrict__ partial_u) {
+  __shared__ f4 lds[kWaves * 2 * kChunk + 8];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t_base = blockIdx.x * kTgtPerWG;
+  const int i0 = t_base + lane, i1 = t_base + 64 + lane;
+  const f4 t0 = posm[min(i0, n - 1)], t1 = posm[min(i1, n - 1)];
+  const f2 xi = {t0.x, t1.x}, yi = {t0.y, t1.y}, zi = {t0.z, t1.z};
+  f2 u = {0.f, 0.f};
+  f2 soft = {soft_, soft_};
+  asm volatile("" : "+v"(soft));
+  // this block's share of the chunks [first chunk of the group, n_chunks), split over slabs x waves
+  const int c_lo = t_base / kChunk;
+  const int span = n_chunks - c_lo;
+  const int parts = gridDim.y * kWaves;
+  const int cpw = (span + parts - 1) / parts;
+  const int jw = blockIdx.y * kWaves + wave;
+  const int c_begin = min(c_lo + jw * cpw, n_chunks), c_end = min(c_begin + cpw, n_chunks);
+  const int c_diag_end = (t_base + kTgtPerWG + kChunk - 1) / kChunk;      // chunks below this touch j <= i
+  f4* stage = &lds[wave * 2 * kChunk];
+  const f4* s_lane = posm + lane;
+  if (c_begin < c_end)
+    __builtin_amdgcn_global_load_lds(GPTR(s_lane + (size_t)c_begin * kChunk), LPTR(stage), 16, 0, 0);
+  for (int c = c_begin; c < c_end; ++c) {
+    const int b = (c - c_begin) & 1;
+    if (c + 1 < c_end) {
+      __builtin_amdgcn_global_load_lds(GPTR(s_lane + (size_t)(c + 1) * kChunk), LPTR(stage + (b ^ 1) * kChunk), 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const f4* buf = stage + b * kChunk;
+    const int j0 = c * kChunk;
+    if (all_masked || c < c_diag_end || c == n_chunks - 1) {     // diagonal chunks and the padded tail
+#pragma unroll 4
+      for (int j = 0; j < kChunk; ++j) energy_pair<true>(buf[j], xi, yi, zi, soft, u, j0 + j, i0, i1, n);
+    } else {
+#pragma unroll 4
+      for (int j = 0; j < kChunk; ++j) energy_pair<false>(buf[j], xi, yi, zi, soft, u, j0 + j, i0, i1, n);
+    }
+  }
+  // U contribution of this wave: sum_i m_i u_i  (the -G factor is applied by the final kernel)
+  double acc = 0.0;
+  if (i0 < n) acc += (double)t0.w * (double)u.x;
+  if (i1 < n) acc += (double)t1.w * (double)u.y;
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  double* red = reinterpret_cast<double*>(&lds[kWaves * 2 * kChunk]);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    partial_u[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void kinetic_kernel(const f4* __restrict__ posm, const float* __restrict__ vel,
+                                                      int n, double* __restrict__ partial_k) {
+  __shared__ double red[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
   double k = 0.0;
   if (i < n) {
     const float vx = vel[3 * i], vy = vel[3 * i + 1], vz = vel[3 * i + 2];
-    k = (double)(0.5f * me.w * ((vx * vx + vy * vy) + vz * vz));
-  } else {
-    u = 0.0;
+    const float v2 = __fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz));
+    k = (double)__fmul_rn(__fmul_rn(0.5f, posm[i].w), v2);                // 0.5 * m * |v|^2 (:100)
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    u += __shfl_down(u, off);
-    k += __shfl_down(k, off);
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { red_u[wave] = u; red_k[wave] = k; }
+  for (int off = 32; off > 0; off >>= 1) k += __shfl_down(k, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = k;
+  __syncthreads();
+  if (threadIdx.x == 0) partial_k[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void energy_final_kernel(const double* __restrict__ pu, int nu,
+                                                           const double* __restrict__ pk, int nk, float g,
+                                                           double* __restrict__ out) {
+  __shared__ double ru[4], rk[4];
+  double u = 0.0, k = 0.0;
+  for (int b = threadIdx.x; b < nu; b += 256) u += pu[b];
+  for (int b = threadIdx.x; b < nk; b += 256) k += pk[b];
+  for (int off = 32; off > 0; off >>= 1) { u += __shfl_down(u, off); k += __shfl_down(k, off); }
+  if ((threadIdx.x & 63) == 0) { ru[threadIdx.x >> 6] = u; rk[threadIdx.x >> 6] = k; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    partial_u[blockIdx.x] = (red_u[0] + red_u[1]) + (red_u[2] + red_u[3]);
-    partial_k[blockIdx.x] = (red_k[0] + red_k[1]) + (red_k[2] + red_k[3]);
+    out[0] = -(double)g * ((ru[0] + ru[1]) + (ru[2] + ru[3]));
+    out[1] = (rk[0] + rk[1]) + (rk[2] + rk[3]);
   }
 }
 
-__global__ __launch_bounds__(64) void energy_final_kernel(const double* __restrict__ pu,
-                                                          const double* __restrict__ pk, int nb,
-                                                          double* __restrict__ out) {
-  double u = 0.0, k = 0.0;
-  for (int b = threadIdx.x; b < nb; b += 64) { u += pu[b]; k += pk[b]; }
-  for (int off = 32; off > 0; off >>= 1) { u += __shfl_down(u, off); k += __shfl_down(k, off); }
-  if (threadIdx.x == 0) { out[0] = u; out[1] = k; }
+inline int energy_slabs(int groups) {
+  int s = (4096 + groups - 1) / groups;        // ~2 residency rounds; the triangle is balanced dynamically
+  return s < 1 ? 1 : (s > 32 ? 32 : s);
 }
 
 struct AccelPlan { int groups, slabs, n_chunks, cpw; };
@@ -464,7 +527,9 @@ int nbd_euler_step_f32(float* pos, float* vel, float* acc_out, const float* mass
 }
 
 size_t nbd_energy_workspace_bytes(int n) {
-  return n <= 0 ? 0 : (size_t)ceil_div(n, 256) * 2 * sizeof(double);
+  if (n <= 0) return 0;
+  const int groups = ceil_div(n, kTgtPerWG);
+  return ((size_t)groups * energy_slabs(groups) + (size_t)ceil_div(n, 256)) * sizeof(double);
 }
 
 int nbd_energy_f32(const float* posm, const float* vel, int n, float softening, float g_const,
@@ -473,15 +538,19 @@ int nbd_energy_f32(const float* posm, const float* vel, int n, float softening, 
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) return check(hipMemsetAsync(out_uk, 0, 2 * sizeof(double), st));
   if (!posm || !vel || misaligned16(posm)) return NBD_E_BADARG;
-  const int nb = ceil_div(n, 256);
   if (!workspace || workspace_bytes < nbd_energy_workspace_bytes(n)) return NBD_E_WORKSPACE;
+  const int groups = ceil_div(n, kTgtPerWG), slabs = energy_slabs(groups), nk = ceil_div(n, 256);
   double* pu = static_cast<double*>(workspace);
-  double* pk = pu + nb;
-  energy_kernel<<<nb, 256, 0, st>>>(reinterpret_cast<const f4*>(posm), vel, n, nbd_posm_padded_len(n),
-                                    softening, g_const, pu, pk);
+  double* pk = pu + (size_t)groups * slabs;
+  const f4* pm = reinterpret_cast<const f4*>(posm);
+  energy_kernel<<<dim3(groups, slabs), 64 * kWaves, 0, st>>>(pm, n, ceil_div(n, kChunk), softening,
+                                                           softening > 0.f ? 0 : 1, pu);
   int rc = launch_status();
   if (rc) return rc;
-  energy_final_kernel<<<1, 64, 0, st>>>(pu, pk, nb, out_uk);
+  kinetic_kernel<<<nk, 256, 0, st>>>(pm, vel, n, pk);
+  rc = launch_status();
+  if (rc) return rc;
+  energy_final_kernel<<<1, 256, 0, st>>>(pu, groups * slabs, pk, nk, g_const, out_uk);
   return launch_status();
 }
 

@@ -155,10 +155,16 @@ class BaseSimulator:
             return states
         n_loc = self.part.n_local
         per_step = 3 * n_loc * 3 * 4
-        chunk = max(1, min(steps, (256 << 20) // max(per_step, 1)))
-        stage = torch.empty((chunk, 3, n_loc, 3), dtype=torch.float32).pin_memory()
+        chunk = max(1, min(max(steps, 32), (64 << 20) // max(per_step, 1)))
+        # pinned staging is expensive to create (page-locking): keep it across run() calls
+        cached = getattr(self, "_run_stage", None)
+        if cached is None or cached[0].shape[0] < chunk:
+            cached = (torch.empty((chunk, 3, n_loc, 3), dtype=torch.float32).pin_memory(),
+                      torch.empty((chunk, 2), dtype=torch.float64).pin_memory())
+            self._run_stage = cached
+        stage, uk_host = cached
+        chunk = stage.shape[0]
         uk_dev = torch.zeros((chunk, 2), dtype=torch.float64, device=self.device)
-        uk_host = torch.empty((chunk, 2), dtype=torch.float64).pin_memory()
         done = 0
         while done < steps:
             m = min(chunk, steps - done)
