@@ -78,11 +78,18 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with `python -m torch.distributed.run "
                      "--nproc-per-node N ...` (one process per GPU)")
         args.gpus = world
+    # NBD_BENCH_SHARE_GPU=1 + NBD_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a 1-GPU box
+    share = os.environ.get("NBD_BENCH_SHARE_GPU") == "1"
+    local_rank = 0 if share else local_rank
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL
+        backend = os.environ.get("NBD_DIST_BACKEND", "nccl")                           # nccl = RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     n_total = args.n_total or args.particles_per_gpu * world
