@@ -282,3 +282,25 @@ def test_two_rank_range_partition_on_gpu_matches_single_rank(n, tmp_path, gpu_de
         assert row_rel(got[key], _np(ref)) < 2e-6, key
     u, k = sim.compute_energies()
     assert abs(got["u"] - u) < 1e-6 * abs(u) and abs(got["k"] - k) < 1e-6 * abs(k)
+
+
+def test_full_size_all_rows_against_c_oracle_f64(gpu_device):
+    """BASELINE config 2, every one of the 65 536 rows: HIP force vs the C oracle in fp64 (OpenMP on
+    the host, ~10 s). Tolerance = the reference's own fp32-vs-fp64 distance (8.7e-7 measured)
+    with margin; one leapfrog step then moves positions/velocities within the 1e-5 bar."""
+    from nbd.plummer import generate_plummer
+    from oracle import c_oracle
+    n = 65536
+    p, v, m = generate_plummer(n, seed=1234)
+    sim = _mk("LeapFrogSimulator", dict(pos=p, vel=v, mass=m, g_const=1.0, softening=0.1, dt=0.01))
+    ref = c_oracle.acc_f64(p, m, 1.0, 0.1)
+    assert row_rel(_np(sim.accelerations), ref) < 3e-6
+    assert global_rel(_np(sim.accelerations), ref) < 5e-7
+    # one KDK step in fp64 from the fp32 inputs, force at the drifted positions from the C oracle
+    p32, v32 = p.astype(np.float32).astype(np.float64), v.astype(np.float32).astype(np.float64)
+    vh = v32 + 0.005 * ref
+    x1 = p32 + 0.01 * vh
+    a1 = c_oracle.acc_f64(x1.astype(np.float32), m, 1.0, 0.1)
+    v1 = vh + 0.005 * a1
+    sim.step()
+    assert row_rel(_np(sim.positions), x1) < TOL and row_rel(_np(sim.velocities), v1) < TOL
