@@ -183,10 +183,12 @@ int nbd_layernorm_f32(const float* x, int ldx, int c, const float* gamma, const 
  *      window_e * trilinear_weight_e(cell) * feat[centre_e][i],   cell = (z*D + y)*D + x,
  * window/ball_to_cube/grid_sample(align_corners=True) exactly as contconv.py:30-33,53-78,85-90, so
  * that ContinuousConv = scatter_mean(...) = rowscale * (a_out . filters.reshape(D^3*I, O)).
- * rowptr/centres: CSR by aggregation target (nbd_radius_transpose_*). D <= 15. */
+ * rowptr/centres: CSR by aggregation target (nbd_radius_transpose_*). D <= 15.
+ * Rows [node_begin, node_begin + n) are produced into a_out[0 .. n): callers bin + contract in node
+ * chunks whose A block stays resident in the 256 MiB Infinity Cache instead of round-tripping HBM. */
 int nbd_contconv_bin_f32(const float* pos, const float* feat, int ldf, int in_channels, const int* rowptr,
-                         const int* centres, int n, int filter_resolution, float radius_sq, float* a_out,
-                         nbd_stream_t stream);
+                         const int* centres, int node_begin, int n, int filter_resolution, float radius_sq,
+                         float* a_out, nbd_stream_t stream);
 
 /* scale[i] from the CSR degree d_i: mode 0 = 1/max(d,1), 1 = d, 2 = (d > 0). */
 int nbd_degree_scale_f32(const int* rowptr, int n, int mode, float* scale, nbd_stream_t stream);

@@ -27,6 +27,11 @@ from nbd import graphops, nnops
 from nbd._lib import NbdError
 
 
+# Node-chunked bin+contract was measured and rejected: chunks small enough for the Infinity Cache leave
+# the GEMM too few row blocks (N=16 384: 3.0 ms un-chunked, 3.7 ms at 512 MB chunks, 7-9 ms at <= 256 MB).
+A_CHUNK_BYTES = int(__import__("os").environ.get("NBD_CONTCONV_CHUNK_MB", str(1 << 20))) << 20
+
+
 class ContinuousConv(nn.Module):
     def __init__(self, in_channels, out_channels, filter_resolution=4, radius=0.5, agg="mean"):
         super().__init__()
@@ -58,9 +63,23 @@ class ContinuousConv(nn.Module):
             if centres.numel() == 0:
                 centres = torch.zeros(1, dtype=torch.int32, device=positions.device)
         r2 = float(np.float32(self.radius ** 2))                       # contconv.py:86: python double -> fp32
-        a = nnops.contconv_bin(positions.contiguous(), features, rowptr, centres, self.filter_resolution, r2)
         scale = nnops.degree_scale(rowptr, n, 0, positions.device) if self.agg == "mean" else None
-        return nnops.linear(a, self.weight_t() if wt is None else wt, None, act=act, out=out, rowscale=scale)
+        wt = self.weight_t() if wt is None else wt
+        if out is None:
+            out = torch.empty((n, self.out_channels), dtype=torch.float32, device=positions.device)
+        # bin + contract in node chunks: the chunk's A block (<= A_CHUNK_BYTES) is produced and consumed
+        # while it sits in the 256 MiB Infinity Cache, and the buffer is reused chunk after chunk
+        kc = self.filter_resolution ** 3 * self.in_channels
+        rows = max(128, (A_CHUNK_BYTES // (4 * kc)) // 128 * 128)
+        pos_c = positions.contiguous()
+        a_buf = torch.empty((min(rows, n), kc), dtype=torch.float32, device=positions.device)
+        for lo in range(0, n, rows):
+            cnt = min(rows, n - lo)
+            nnops.contconv_bin(pos_c, features, rowptr, centres, self.filter_resolution, r2, out=a_buf,
+                               node_begin=lo, count=cnt)
+            nnops.linear(a_buf[:cnt], wt, None, act=act, out=out[lo:lo + cnt],
+                         rowscale=None if scale is None else scale[lo:lo + cnt])
+        return out
 
 
 class ContinuousConvModel(nn.Module):

@@ -26,6 +26,15 @@ __device__ __forceinline__ float dist2(const float* __restrict__ pos, int j, flo
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
+// lane l <- lane l-1 across the whole wave (lane 0 <- `lane0`): one DPP move (wave_shr:1, GFX9) instead of
+// the LDS round trip __shfl_up compiles to -- the sorted-insert chain below is latency-bound on it.
+__device__ __forceinline__ int shift_up1(int v, int lane0) {
+  return __builtin_amdgcn_update_dpp(lane0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float shift_up1(float v, float lane0) {
+  return __builtin_bit_cast(float, shift_up1(__builtin_bit_cast(int, v), __builtin_bit_cast(int, lane0)));
+}
+
 // ---- kNN: the wave keeps the current best 64*R (d2, j) pairs sorted across lanes (rank = r*64+lane).
 template <int R>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_kernel(
@@ -47,15 +56,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_kernel(
   float thr = __builtin_inff();                // d2 of the current kk-th best
   const int thr_r = (kk - 1) >> 6, thr_lane = (kk - 1) & 63;
 
+  // candidate positions are prefetched one chunk ahead: the ballot/insert chain of chunk c hides the
+  // L2 latency of chunk c+1 (the kernel is latency-bound: one wave per centre, 64 chunks at N = 4096)
+  float nx = 0.f, ny = 0.f, nz = 0.f;
+  if (lo + lane < hi) { nx = pos[3 * (lo + lane)]; ny = pos[3 * (lo + lane) + 1]; nz = pos[3 * (lo + lane) + 2]; }
   for (int c0 = lo; c0 < hi; c0 += 64) {
     const int j = c0 + lane;
+    const float cx = nx, cy = ny, cz = nz;
+    const int jn_ = j + 64;
+    if (jn_ < hi) { nx = pos[3 * jn_]; ny = pos[3 * jn_ + 1]; nz = pos[3 * jn_ + 2]; }
     float d = __builtin_inff();
-    if (j < hi && (loop || j != i)) d = dist2(pos, j, xi, yi, zi);
+    if (j < hi && (loop || j != i)) {
+      const float dx = cx - xi, dy = cy - yi, dz = cz - zi;
+      d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    }
     unsigned long long m = __ballot(d < thr);
     while (m) {
       const int b = __builtin_ctzll(m);        // lowest candidate index first
       m &= m - 1;
-      const float dn = __shfl(d, b);
+      const float dn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), b));
       if (!(dn < thr)) continue;               // thr may have dropped inside this chunk
       const int jn = c0 + b;
       int p = 0;                               // insertion rank: after every entry with d2 <= dn
@@ -63,20 +82,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_kernel(
       for (int r = 0; r < R; ++r) p += __builtin_popcountll(__ballot(bd[r] <= dn));
 #pragma unroll
       for (int r = R - 1; r >= 0; --r) {
-        float ud = __shfl_up(bd[r], 1);
-        int uj = __shfl_up(bj[r], 1);
-        if (r > 0) {
-          const float cd = __shfl(bd[r - 1], 63);
-          const int cj = __shfl(bj[r - 1], 63);
-          if (lane == 0) { ud = cd; uj = cj; }
+        float cd = 0.f;
+        int cj = 0;
+        if (r > 0) {                                   // carry: last lane of the previous register
+          cd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bd[r - 1]), 63));
+          cj = __builtin_amdgcn_readlane(bj[r - 1], 63);
         }
+        const float ud = shift_up1(bd[r], cd);
+        const int uj = shift_up1(bj[r], cj);
         const int rank = r * 64 + lane;
         if (rank > p) { bd[r] = ud; bj[r] = uj; }
         else if (rank == p) { bd[r] = dn; bj[r] = jn; }
       }
       float t = 0.f;
 #pragma unroll
-      for (int r = 0; r < R; ++r) if (r == thr_r) t = __shfl(bd[r], thr_lane);
+      for (int r = 0; r < R; ++r)
+        if (r == thr_r) t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bd[r]), thr_lane));
       thr = t;
     }
   }

@@ -316,9 +316,9 @@ struct EdgeGeo { int c, ix, iy, iz; float tx, ty, tz, window; };
 
 __global__ __launch_bounds__(64) void contconv_bin_kernel(
     const float* __restrict__ pos, const float* __restrict__ feat, int ldf, int I, const int* __restrict__ rowptr,
-    const int* __restrict__ centres, int n, int D, float r2max, float* __restrict__ A) {
+    const int* __restrict__ centres, int node_begin, int D, float r2max, float* __restrict__ A) {
   extern __shared__ float img[];            // [D*D][64] slab image, then 64 EdgeGeo records
-  const int node = blockIdx.x, cg = blockIdx.y, lane = threadIdx.x;
+  const int node = node_begin + blockIdx.x, cg = blockIdx.y, lane = threadIdx.x;
   const int ch = cg * 64 + lane;
   const int slab_cells = D * D;
   EdgeGeo* geo = reinterpret_cast<EdgeGeo*>(img + slab_cells * 64);
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64) void contconv_bin_kernel(
       __builtin_amdgcn_wave_barrier();
     }
     if (ch < I) {
-      float* dst = A + ((size_t)node * D * slab_cells + (size_t)z * slab_cells) * I + ch;
+      float* dst = A + ((size_t)blockIdx.x * D * slab_cells + (size_t)z * slab_cells) * I + ch;
       for (int c = 0; c < slab_cells; ++c) { dst[(size_t)c * I] = img[c * 64 + lane]; img[c * 64 + lane] = 0.f; }
     } else {
       for (int c = 0; c < slab_cells; ++c) img[c * 64 + lane] = 0.f;
@@ -421,9 +421,15 @@ int nbd_linear_f32(const float* x, int ldx, const float* w, int ldw, const float
   const BigPlan bp = plan_big(n_rows, n_cols, k);
   if (vec && bp.use && (bp.slices == 1 || (workspace && workspace_bytes >= bp.ws))) {
     const size_t shmem = 2 * (G2_BM + G2_BN) * G2_LD * sizeof(float);     // 73 728 B
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_big_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return (int)e;
+    // > 64 KiB of dynamic LDS needs the attribute; it is a per-function constant, set once (idempotent,
+    // so the unsynchronised flag is benign) and kept out of later calls so they can be graph-captured
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_big_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
     dim3 grid(ceil_div(n_rows, G2_BM), ceil_div(n_cols, G2_BN), bp.slices);
     float* slabs = static_cast<float*>(workspace);
     linear_big_kernel<<<grid, 256, shmem, st>>>(x, ldx, w, ldw, bias, rowscale, bias_rowscale, act, y, ldy, n_rows,
@@ -460,16 +466,16 @@ int nbd_layernorm_f32(const float* x, int ldx, int c, const float* gamma, const 
 }
 
 int nbd_contconv_bin_f32(const float* pos, const float* feat, int ldf, int in_channels, const int* rowptr,
-                         const int* centres, int n, int filter_resolution, float radius_sq, float* a_out,
-                         nbd_stream_t stream) {
-  if (n < 0 || in_channels <= 0 || filter_resolution < 2) return NBD_E_BADARG;
+                         const int* centres, int node_begin, int n, int filter_resolution, float radius_sq,
+                         float* a_out, nbd_stream_t stream) {
+  if (n < 0 || node_begin < 0 || in_channels <= 0 || filter_resolution < 2) return NBD_E_BADARG;
   if (n == 0) return 0;
   if (!pos || !feat || !rowptr || !centres || !a_out || ldf < in_channels) return NBD_E_BADARG;
   const size_t shmem = (size_t)filter_resolution * filter_resolution * 64 * sizeof(float) + 64 * sizeof(EdgeGeo);
   if (shmem > 64 * 1024) return NBD_E_UNSUPPORTED;       // D <= 15
   dim3 grid(n, ceil_div(in_channels, 64));
-  contconv_bin_kernel<<<grid, 64, shmem, (hipStream_t)stream>>>(pos, feat, ldf, in_channels, rowptr, centres, n,
-                                                                filter_resolution, radius_sq, a_out);
+  contconv_bin_kernel<<<grid, 64, shmem, (hipStream_t)stream>>>(pos, feat, ldf, in_channels, rowptr, centres,
+                                                                node_begin, filter_resolution, radius_sq, a_out);
   return status();
 }
 

@@ -83,8 +83,8 @@ SIGNATURES = {
                                            c_void_p, c_int, c_void_p]),
     "nbd_layernorm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
                                   c_void_p]),
-    "nbd_contconv_bin_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float,
-                                     c_void_p, c_void_p]),
+    "nbd_contconv_bin_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                     c_float, c_void_p, c_void_p]),
     "nbd_degree_scale_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 
@@ -95,6 +95,11 @@ def lib() -> ctypes.CDLL:
     """The loaded library; raises NbdError (never falls back) if it is not built."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            try:                      # a fresh checkout has sources only: compile now if hipcc is here
+                build()
+            except Exception:
+                pass
         if not os.path.exists(LIB_PATH):
             raise NbdError(
                 f"{LIB_PATH} not found: the HIP extension is not built. Run "

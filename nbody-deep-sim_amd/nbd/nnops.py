@@ -82,23 +82,28 @@ def layernorm(x, gamma, beta, eps, out=None):
     return out
 
 
-def contconv_bin(pos, feat, rowptr, centres, d, radius_sq, out=None):
-    """A (n, d^3 * I): feature-side trilinear binning of ContinuousConv (contconv.py:80-93)."""
+def contconv_bin(pos, feat, rowptr, centres, d, radius_sq, out=None, node_begin=0, count=None):
+    """A (count, d^3 * I): feature-side trilinear binning of ContinuousConv (contconv.py:80-93) for the
+    nodes [node_begin, node_begin + count)."""
     n, i_ch = feat.shape
+    count = n - node_begin if count is None else count
     ldf = _mat(feat, "feat")
     if pos.shape != (n, 3) or pos.dtype != torch.float32 or not pos.is_contiguous():
         raise _lib.NbdError("pos must be contiguous fp32 (n,3)")
     if rowptr.dtype != torch.int32 or rowptr.numel() != n + 1 or centres.dtype != torch.int32:
         raise _lib.NbdError("rowptr int32 [n+1] / centres int32 required")
+    if node_begin < 0 or count < 0 or node_begin + count > n:
+        raise _lib.NbdError(f"node range [{node_begin}, {node_begin + count}) outside [0, {n})")
     kc = d * d * d * i_ch
     if out is None:
-        out = torch.empty((n, kc), dtype=torch.float32, device=feat.device)
-    if tuple(out.shape) != (n, kc) or not out.is_contiguous():
-        raise _lib.NbdError(f"A must be contiguous {(n, kc)}")
+        out = torch.empty((count, kc), dtype=torch.float32, device=feat.device)
+    if out.dim() != 2 or out.shape[0] < count or out.shape[1] != kc or not out.is_contiguous():
+        raise _lib.NbdError(f"A must be contiguous (>= {count}, {kc})")
     with torch.cuda.device(feat.device):
         _lib.check(_lib.lib().nbd_contconv_bin_f32(pos.data_ptr(), feat.data_ptr(), ldf, i_ch, rowptr.data_ptr(),
-                                                   centres.data_ptr(), n, d, float(radius_sq), out.data_ptr(),
-                                                   _lib.current_stream(feat.device)), "nbd_contconv_bin_f32")
+                                                   centres.data_ptr(), node_begin, count, d, float(radius_sq),
+                                                   out.data_ptr(), _lib.current_stream(feat.device)),
+                   "nbd_contconv_bin_f32")
     return out
 
 

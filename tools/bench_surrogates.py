@@ -89,6 +89,10 @@ def run(iters=20):
     acc = model.predict(pos, torch.cat([vel, m1], 1))
     g_ms, w_ms = timeit(lambda: tr.step(pos, vel, m1, acc, 1e-4), iters)
     out["gnn_n4096_trainer_step_k50"] = {"ms_gpu": g_ms, "ms_wall": w_ms}
+    adv = tr._capture_step(pos, vel, m1, acc, 1e-4)
+    if adv is not None:
+        g_ms, w_ms = timeit(adv, iters)
+        out["gnn_n4096_trainer_step_k50_hipgraph"] = {"ms_gpu": g_ms, "ms_wall": w_ms}
 
     torch.manual_seed(0)
     cc = contconv.ContinuousConvModel(in_channels=4, out_channels=3, filter_resolution=[6, 4], radius=1.0, agg="mean",
@@ -102,8 +106,10 @@ def run(iters=20):
     tr2 = trainer.Trainer(cc, None, device="cuda", dt=1e-4)
     acc = cc.predict(pos, torch.cat([vel, m1], 1))
     g_ms, w_ms = timeit(lambda: tr2.step(pos, vel, m1, acc, 1e-4), max(iters // 2, 3))
+    adv = tr2._capture_step(pos, vel, m1, acc, 1e-4)
+    cc_graph = timeit(adv, max(iters // 2, 3)) if adv is not None else (None, None)
     r_ms, _ = timeit(lambda: graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32), max(iters // 2, 3))
-    out["contconv_n16384"] = {"rollout_step_ms_gpu": g_ms, "rollout_step_ms_wall": w_ms, "radius_lists_ms": r_ms,
+    out["contconv_n16384"] = {"rollout_step_ms_gpu": g_ms, "rollout_step_ms_wall": w_ms, "rollout_step_ms_gpu_hipgraph": cc_graph[0], "radius_lists_ms": r_ms,
                               "position_scale": scale, "mean_uncapped_degree": deg,
                               "edges_capped": int(lists.rowptr[-1]), "max_in_degree": int((lists.rowptr[1:] - lists.rowptr[:-1]).max())}
     out["gnn_n4096_rollout_mse_vs_direct"] = rollout_mse_vs_direct(model, 4096, None, 10)
