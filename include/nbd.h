@@ -190,6 +190,41 @@ int nbd_contconv_bin_f32(const float* pos, const float* feat, int ldf, int in_ch
                          const int* centres, int node_begin, int n, int filter_resolution, float radius_sq,
                          float* a_out, nbd_stream_t stream);
 
+/* One whole EdgeConv layer of GraphModel.forward (gnn.py:75-93,140-148) in ONE launch, one node per
+ * wave: s_i = aggr_j tanh(P_i + Q_j); y_i = W2 s_i + beta_i b2 (beta = [deg>0] for mean, deg for sum);
+ * then the epilogue. At the reference's sizes the forward pass is launch/latency bound, so this
+ * replaces 3 launches per layer (and LayerNorm + head) of the general path; same arithmetic. */
+#define NBD_GNN_WRITE_X 0    /* out[i][0..h)   = y_i                      (ldout: column slice ok)    */
+#define NBD_GNN_NEXT_PQ 1    /* out[i][0..ep_out) = w_ep y_i + b_ep       (next layer's [P|Q])        */
+#define NBD_GNN_FINAL_HEAD 2 /* out[i][0..ep_out) = w_ep LayerNorm([enc_i || y_i]) + b_ep, ep_out<=8 */
+#define NBD_GNN_FINAL_LN 3   /* out[i][0..e+h) = LayerNorm([enc_i || y_i])                            */
+typedef struct nbd_gnn_layer_args {
+  const int* rowptr;      /* [n+1] edges grouped by target, or NULL: exactly fixed_k edges per node */
+  const int64_t* src;     /* source node j of every edge (edge_index[0])                            */
+  int fixed_k, n;
+  const float* pq;        /* [n][ldpq] = [P (h) | Q (h)], or NULL: form P/Q from x on the fly       */
+  int ldpq;
+  const float* x;         /* [n][ldx], first f columns (f <= 8) -- used when pq == NULL             */
+  int ldx, f;
+  const float* wpq;       /* [2h][f] rows P then Q = [W1a - W1b ; W1b]; bpq [h] = b1                */
+  const float* bpq;
+  int h, aggr;            /* channels (<= 128); 0 = sum, 1 = mean                                    */
+  const float* w2t;       /* [h][h] = W2 TRANSPOSED (in x out: w2t[k][o] = W2[o][k]), b2 [h]          */
+  const float* b2;
+  int epilogue;           /* NBD_GNN_*                                                               */
+  const float* w_ep;      /* NEXT_PQ: [h][ep_out] (TRANSPOSED);  FINAL_HEAD: [ep_out][e+h]          */
+  const float* b_ep;
+  int ep_out;
+  const float* enc;       /* FINAL_*: encoder output [n][ldenc], e columns (e <= 256)                */
+  int ldenc, e;
+  const float* ln_g;      /* LayerNorm weight / bias [e+h]                                           */
+  const float* ln_b;
+  float ln_eps;
+  float* out;
+  int ldout;
+} nbd_gnn_layer_args;
+int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream);
+
 /* scale[i] from the CSR degree d_i: mode 0 = 1/max(d,1), 1 = d, 2 = (d > 0). */
 int nbd_degree_scale_f32(const int* rowptr, int n, int mode, float* scale, nbd_stream_t stream);
 

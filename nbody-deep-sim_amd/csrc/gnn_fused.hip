@@ -1,0 +1,286 @@
+// gnn_fused.hip -- one launch per EdgeConv layer of the GNN surrogate (gnn.py:75-93,130-148), gfx950.
+//
+// At the reference's sizes (N = 4096, H = 64) every dense block of the GNN is a few microseconds of
+// work, so the forward pass is bounded by launches and dependent kernel latencies, not by FLOPs
+// (tools/ubench_linear.py: 8-10 us per tiny Linear, 11-16 us per aggregation). This kernel therefore
+// keeps one node per wave (lane = channel) from the edge aggregation to the layer's output:
+//
+//   S_i      = aggr_j tanh(P_i + Q_j)                       (EdgeConv after the per-node factoring)
+//   y_i      = W2 S_i + beta_i b2                           (beta = 1 / deg / [deg>0], see nbd.h)
+//   then one of
+//     NEXT_PQ     pq'_i = Wpq' y_i + bpq'                   (the next layer's [P|Q], gnn.py:140-141)
+//     WRITE_X     x'_i  = y_i                               (into a column slice: replaces torch.cat)
+//     FINAL_HEAD  out_i = Wh LayerNorm([enc_i || y_i]) + bh (gnn.py:144-148, out_dim <= 8)
+//     FINAL_LN    z_i   = LayerNorm([enc_i || y_i])         (an MLP head then runs on z)
+//
+// P/Q come either from a [N][2H] buffer or, for a first layer with F <= 8 input features, are formed
+// on the fly from x (8 FMAs per edge instead of a 256-B row gather). The small matrices (W2^T and the
+// epilogue's) are staged once per workgroup in LDS as [k][out] so that lane = out reads are
+// conflict-free; the per-node mat-vecs broadcast the k-th input with v_readlane (no LDS, no shuffles).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nbd.h"
+
+namespace {
+
+constexpr int kFMax = 8;        // on-the-fly P/Q: input features, zero padded
+constexpr int kMaxR = 2;        // channels per lane: H <= 128
+constexpr int kMaxZR = 4;       // concat width per lane: E + H <= 256
+constexpr int kMaxOut = 8;
+
+__device__ __forceinline__ float lane_bcast(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// tanh(x) = 1 - 2 / (2^(2x log2 e) + 1): v_exp_f32 + v_rcp_f32 + 3 VALU instead of libm's ~40-instruction
+// tanhf. The E x H tanh evaluations are what bounds the EdgeConv aggregation (8.4 M at N=4096, k=32,
+// H=64), so this is the kernel's roofline lever. Absolute error <= ~2e-7 (1-ulp exp2/rcp and one
+// cancellation at ulp(1)); saturates to +-1 exactly for large |x|, NaN stays NaN.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// y[out] += sum_k in_k * Wt[k][out]  (in: lane = k over RIN registers, zero beyond K; Wt rows are
+// zero-padded to 64*RIN in LDS, so the trip count is a compile-time constant and the loop unrolls)
+template <int RIN, int ROUT>
+__device__ __forceinline__ void matvec(const float (&in)[RIN], const float* __restrict__ wt, int n_out, int lane,
+                                       float (&out)[ROUT]) {
+#pragma unroll
+  for (int r = 0; r < RIN; ++r) {
+#pragma unroll 8
+    for (int l = 0; l < 64; ++l) {
+      const float v = lane_bcast(in[r], l);
+      const float* row = wt + (r * 64 + l) * n_out;
+#pragma unroll
+      for (int ro = 0; ro < ROUT; ++ro) {
+        const int o = ro * 64 + lane;
+        if (o < n_out) out[ro] = __builtin_fmaf(v, row[o], out[ro]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+namespace {
+
+template <int R>
+__global__ __launch_bounds__(256) void gnn_layer_kernel(const nbd_gnn_layer_args a) {
+  extern __shared__ float smem[];
+  const int H = a.h;
+  constexpr int KP = 64 * R;               // mat-vec depth, zero padded
+  float* w2t = smem;                       // [KP][H]   (a.w2t is already W2 transposed: [k][out])
+  float* ept = smem + KP * H;              // [KP][n_ep] epilogue matrix (NEXT_PQ only)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_ep = a.epilogue == NBD_GNN_NEXT_PQ ? a.ep_out : 0;
+  for (int idx = threadIdx.x; idx < KP * H; idx += 256) w2t[idx] = idx < H * H ? a.w2t[idx] : 0.f;
+  for (int idx = threadIdx.x; idx < KP * n_ep; idx += 256) ept[idx] = idx < H * n_ep ? a.w_ep[idx] : 0.f;
+  __syncthreads();
+
+  // on-the-fly P/Q weights of this lane's channels (first layer, F <= 8)
+  float wp[R][kFMax], wq[R][kFMax], bp[R];
+  if (a.pq == nullptr) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int h = r * 64 + lane;
+      bp[r] = h < H ? a.bpq[h] : 0.f;
+#pragma unroll
+      for (int f = 0; f < kFMax; ++f) {
+        const bool ok = h < H && f < a.f;
+        wp[r][f] = ok ? a.wpq[(size_t)h * a.f + f] : 0.f;
+        wq[r][f] = ok ? a.wpq[(size_t)(H + h) * a.f + f] : 0.f;
+      }
+    }
+  }
+
+  for (int node = blockIdx.x * 4 + wave; node < a.n; node += gridDim.x * 4) {
+    const int e0 = a.rowptr ? a.rowptr[node] : node * a.fixed_k;
+    const int e1 = a.rowptr ? a.rowptr[node + 1] : (node + 1) * a.fixed_k;
+    const int deg = e1 - e0;
+    float p[R], s[R];
+    if (a.pq) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; p[r] = h < H ? a.pq[(size_t)node * a.ldpq + h] : 0.f; }
+    } else {
+      float xi[kFMax];
+#pragma unroll
+      for (int f = 0; f < kFMax; ++f) xi[f] = f < a.f ? a.x[(size_t)node * a.ldx + f] : 0.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float acc = bp[r];
+#pragma unroll
+        for (int f = 0; f < kFMax; ++f) acc = __builtin_fmaf(wp[r][f], xi[f], acc);
+        p[r] = acc;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) s[r] = 0.f;
+    // edges in chunks of 64: one coalesced index load, then wave-uniform j's, four edges in flight
+    for (int eb = e0; eb < e1; eb += 64) {
+      const int cnt = min(64, e1 - eb);
+      const int jv = lane < cnt ? (int)a.src[eb + lane] : 0;
+      for (int t = 0; t < cnt; t += 4) {
+        int j[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = __builtin_amdgcn_readlane(jv, min(t + u, cnt - 1));
+        if (a.pq) {
+          float q[4][R];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const int h = r * 64 + lane;
+              q[u][r] = h < H ? a.pq[(size_t)j[u] * a.ldpq + H + h] : 0.f;
+            }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const float v = fast_tanh(__fadd_rn(p[r], q[u][r]));
+              s[r] += (t + u < cnt) ? v : 0.f;
+            }
+        } else {
+          float xj[4][kFMax];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int f = 0; f < kFMax; ++f) xj[u][f] = f < a.f ? a.x[(size_t)j[u] * a.ldx + f] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              float q = 0.f;
+#pragma unroll
+              for (int f = 0; f < kFMax; ++f) q = __builtin_fmaf(wq[r][f], xj[u][f], q);
+              const float v = fast_tanh(__fadd_rn(p[r], q));
+              s[r] += (t + u < cnt) ? v : 0.f;
+            }
+        }
+      }
+    }
+    if (a.aggr == 1) {
+      const float inv = 1.0f / (float)max(deg, 1);
+#pragma unroll
+      for (int r = 0; r < R; ++r) s[r] *= inv;
+    }
+    // y = W2 S + beta b2
+    const float beta = a.aggr == 1 ? (deg > 0 ? 1.f : 0.f) : (float)deg;
+    float y[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; y[r] = h < H ? beta * a.b2[h] : 0.f; }
+    matvec<R, R>(s, w2t, H, lane, y);
+
+    if (a.epilogue == NBD_GNN_WRITE_X) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; if (h < H) a.out[(size_t)node * a.ldout + h] = y[r]; }
+    } else if (a.epilogue == NBD_GNN_NEXT_PQ) {
+      float o[2 * R];
+#pragma unroll
+      for (int r = 0; r < 2 * R; ++r) { const int c = r * 64 + lane; o[r] = c < n_ep ? a.b_ep[c] : 0.f; }
+      matvec<R, 2 * R>(y, ept, n_ep, lane, o);
+#pragma unroll
+      for (int r = 0; r < 2 * R; ++r) { const int c = r * 64 + lane; if (c < n_ep) a.out[(size_t)node * a.ldout + c] = o[r]; }
+    } else {
+      // LayerNorm over [enc (E) || y (H)] without materialising the concatenation
+      const int E = a.e, C = E + H;
+      float enc[kMaxZR];
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < kMaxZR; ++r) {
+        const int c = r * 64 + lane;
+        enc[r] = c < E ? a.enc[(size_t)node * a.ldenc + c] : 0.f;
+        sum += enc[r];
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) sum += (r * 64 + lane < H) ? y[r] : 0.f;
+      const float mean = wave_sum(sum) / (float)C;
+      float var = 0.f;
+#pragma unroll
+      for (int r = 0; r < kMaxZR; ++r) { const float d = enc[r] - mean; var += (r * 64 + lane < E) ? d * d : 0.f; }
+#pragma unroll
+      for (int r = 0; r < R; ++r) { const float d = y[r] - mean; var += (r * 64 + lane < H) ? d * d : 0.f; }
+      const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)C + a.ln_eps);
+      float ze[kMaxZR], zy[R];
+#pragma unroll
+      for (int r = 0; r < kMaxZR; ++r) {
+        const int c = r * 64 + lane;
+        ze[r] = c < E ? (enc[r] - mean) * rstd * a.ln_g[c] + a.ln_b[c] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int h = r * 64 + lane;
+        zy[r] = h < H ? (y[r] - mean) * rstd * a.ln_g[E + h] + a.ln_b[E + h] : 0.f;
+      }
+      if (a.epilogue == NBD_GNN_FINAL_LN) {
+#pragma unroll
+        for (int r = 0; r < kMaxZR; ++r) { const int c = r * 64 + lane; if (c < E) a.out[(size_t)node * a.ldout + c] = ze[r]; }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; if (h < H) a.out[(size_t)node * a.ldout + E + h] = zy[r]; }
+      } else {  // FINAL_HEAD: out[d] = sum_c z[c] Wh[d][c] + bh[d]
+        for (int d = 0; d < a.ep_out; ++d) {
+          const float* wrow = a.w_ep + (size_t)d * C;
+          float part = 0.f;
+#pragma unroll
+          for (int r = 0; r < kMaxZR; ++r) { const int c = r * 64 + lane; if (c < E) part = __builtin_fmaf(ze[r], wrow[c], part); }
+#pragma unroll
+          for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; if (h < H) part = __builtin_fmaf(zy[r], wrow[E + h], part); }
+          part = wave_sum(part);
+          if (lane == 0) a.out[(size_t)node * a.ldout + d] = part + a.b_ep[d];
+        }
+      }
+    }
+  }
+}
+
+inline int status() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : (int)e; }
+
+}  // namespace
+
+extern "C" {
+
+int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
+  if (!args) return NBD_E_BADARG;
+  const nbd_gnn_layer_args a = *args;
+  if (a.n < 0 || a.h <= 0 || a.aggr < 0 || a.aggr > 1) return NBD_E_BADARG;
+  if (a.n == 0) return 0;
+  if (a.h > 64 * kMaxR) return NBD_E_UNSUPPORTED;
+  if (!a.w2t || !a.b2 || !a.out || (!a.rowptr && a.fixed_k < 0)) return NBD_E_BADARG;
+  if (!a.src && (a.rowptr || a.fixed_k > 0)) return NBD_E_BADARG;
+  if (a.pq) { if (a.ldpq < 2 * a.h) return NBD_E_BADARG; }
+  else { if (!a.x || !a.wpq || !a.bpq || a.f <= 0 || a.ldx < a.f) return NBD_E_BADARG; if (a.f > kFMax) return NBD_E_UNSUPPORTED; }
+  int n_ep = 0;
+  switch (a.epilogue) {
+    case NBD_GNN_WRITE_X: if (a.ldout < a.h) return NBD_E_BADARG; break;
+    case NBD_GNN_NEXT_PQ:
+      if (!a.w_ep || !a.b_ep || a.ep_out <= 0 || a.ldout < a.ep_out) return NBD_E_BADARG;
+      if (a.ep_out > 2 * 64 * kMaxR || a.ep_out > 2 * 64 * ((a.h + 63) / 64)) return NBD_E_UNSUPPORTED;
+      n_ep = a.ep_out; break;
+    case NBD_GNN_FINAL_HEAD:
+    case NBD_GNN_FINAL_LN:
+      if (a.e < 0 || (a.e > 0 && (!a.enc || a.ldenc < a.e)) || !a.ln_g || !a.ln_b) return NBD_E_BADARG;
+      if (a.e > 64 * kMaxZR) return NBD_E_UNSUPPORTED;
+      if (a.epilogue == NBD_GNN_FINAL_HEAD) {
+        if (!a.w_ep || !a.b_ep || a.ep_out <= 0 || a.ldout < a.ep_out) return NBD_E_BADARG;
+        if (a.ep_out > kMaxOut) return NBD_E_UNSUPPORTED;
+      } else if (a.ldout < a.e + a.h) return NBD_E_BADARG;
+      break;
+    default: return NBD_E_BADARG;
+  }
+  const int kp = 64 * ((a.h + 63) / 64);
+  const size_t shmem = ((size_t)kp * a.h + (size_t)kp * n_ep) * sizeof(float);
+  if (shmem > 64 * 1024) return NBD_E_UNSUPPORTED;   // H = 64: 48 KiB; H = 128 fits only without NEXT_PQ
+  int blocks = (a.n + 3) / 4;
+  if (blocks > 512) blocks = 512;                    // >= 2 nodes per wave amortise the weight staging
+  hipStream_t st = (hipStream_t)stream;
+  if (a.h <= 64) gnn_layer_kernel<1><<<blocks, 256, shmem, st>>>(a);
+  else gnn_layer_kernel<2><<<blocks, 256, shmem, st>>>(a);
+  return status();
+}
+
+}  // extern "C"

@@ -146,6 +146,8 @@ class GraphModel(torch.nn.Module):
         else:
             self.output = Linear(out_dim, output_dim)
         self._cache = _WeightCache(self)
+        self.use_fused = True          # one launch per EdgeConv layer when the shapes allow (csrc/gnn_fused.hip)
+        self._fused_out = None
         self.to(device)
 
     def get_config(self):
@@ -165,7 +167,9 @@ class GraphModel(torch.nn.Module):
             bpq = torch.cat([b1, torch.zeros_like(b1)]).contiguous()
             layers.append((wpq, bpq, g.nn[2].weight.detach().contiguous(), g.nn[2].bias.detach().contiguous()))
         enc = self.node_encoder.folded() if isinstance(self.node_encoder, MLP) else None
-        return {"enc": enc, "layers": layers, "head": head_chain(self.output)}
+        # transposed copies ([in][out]) for the fused layer kernel's LDS mat-vecs
+        fused = [(wpq.t().contiguous(), w2.t().contiguous()) for (wpq, _, w2, _) in layers]
+        return {"enc": enc, "layers": layers, "head": head_chain(self.output), "fused_t": fused}
 
     # ------------------------------------------------------------------ forward (gnn.py:130-148)
     def forward(self, data):
@@ -204,8 +208,10 @@ class GraphModel(torch.nn.Module):
             brs = torch.full((n,), val, dtype=torch.float32, device=x7.device)
         else:
             brs = nnops.degree_scale(rowptr, n, brs_mode, x7.device)
-        x = enc_view
         aggr = "mean" if self.aggr == "mean" else "sum"
+        if self.use_fused and self._forward_fused(w, enc_view, n, h, rowptr, src, fixed_k, aggr, cat_buf):
+            return self._fused_out
+        x = enc_view
         for li, (wpq, bpq, w2, b2) in enumerate(w["layers"]):
             pq = nnops.linear(x, wpq, bpq)                                        # (n, 2H) = [P | Q]
             s = nnops.edgeconv_aggregate(pq, h, rowptr, src, fixed_k, aggr)
@@ -214,6 +220,54 @@ class GraphModel(torch.nn.Module):
         ln = nnops.layernorm(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
                              self.layer_norm.eps)
         return run_chain(ln, w["head"])
+
+    def _forward_fused(self, w, enc, n, h, rowptr, src, fixed_k, aggr, cat_buf):
+        """One nbd_gnn_layer_f32 launch per EdgeConv layer (aggregation + W2 + next [P|Q] or
+        LayerNorm + head). Returns False, having launched nothing, if a shape is outside the fused
+        kernel's limits; the general path above then runs."""
+        layers, head = w["layers"], w["head"]
+        e = enc.shape[1]
+        dev = enc.device
+        n_layers = len(layers)
+        single_head = len(head) == 1 and head[0][0].shape[0] <= 8
+        # feasibility first, so that a refusal never leaves a half-run forward behind
+        if h > 128 or e > 256:
+            return False
+        for li in range(n_layers):
+            ep_cols = 2 * h if li < n_layers - 1 else 0
+            kp = 64 * ((h + 63) // 64)
+            if (kp * h + kp * ep_cols) * 4 > 64 * 1024:
+                return False
+        ln_g, ln_b = self.layer_norm.weight.detach(), self.layer_norm.bias.detach()
+        pq = None
+        if e > 8:                                           # first [P|Q] as a plain Linear
+            pq = nnops.linear(enc, layers[0][0], layers[0][1])
+        for li, (wpq, bpq, w2, b2) in enumerate(layers):
+            kw = dict(n=n, h=h, aggr=aggr, rowptr=rowptr, src=src, fixed_k=fixed_k, w2t=w["fused_t"][li][1], b2=b2)
+            if pq is not None:
+                kw["pq"] = pq
+            else:
+                kw.update(x=enc, f=e, wpq=wpq, bpq=layers[li][1][:h].contiguous())
+            if li < n_layers - 1:
+                nxt = torch.empty((n, 2 * h), dtype=torch.float32, device=dev)
+                ok = nnops.gnn_layer(epilogue="next_pq", w_ep=w["fused_t"][li + 1][0], b_ep=layers[li + 1][1],
+                                     ep_out=2 * h, out=nxt, **kw)
+                pq = nxt
+            elif single_head:
+                out = torch.empty((n, head[0][0].shape[0]), dtype=torch.float32, device=dev)
+                ok = nnops.gnn_layer(epilogue="final_head", w_ep=head[0][0], b_ep=head[0][1],
+                                     ep_out=head[0][0].shape[0], enc=enc, e=e, ln_g=ln_g, ln_b=ln_b,
+                                     ln_eps=self.layer_norm.eps, out=out, **kw)
+                self._fused_out = out
+            else:
+                z = torch.empty((n, e + h), dtype=torch.float32, device=dev)
+                ok = nnops.gnn_layer(epilogue="final_ln", enc=enc, e=e, ln_g=ln_g, ln_b=ln_b,
+                                     ln_eps=self.layer_norm.eps, out=z, **kw)
+                if ok:
+                    self._fused_out = run_chain(z, head)
+            if not ok:
+                raise NbdError("fused GNN layer refused a shape its feasibility check accepted")
+        return True
 
     # ------------------------------------------------------------------ inference API
     def predict(self, pos, feat, neighbors=None):

@@ -37,6 +37,17 @@ def build(verbose: bool = False) -> str:
     return LIB_PATH
 
 
+class GnnLayerArgs(ctypes.Structure):
+    """Mirror of `nbd_gnn_layer_args` (include/nbd.h), field for field."""
+    _fields_ = [("rowptr", c_void_p), ("src", c_void_p), ("fixed_k", c_int), ("n", c_int),
+                ("pq", c_void_p), ("ldpq", c_int),
+                ("x", c_void_p), ("ldx", c_int), ("f", c_int), ("wpq", c_void_p), ("bpq", c_void_p),
+                ("h", c_int), ("aggr", c_int), ("w2t", c_void_p), ("b2", c_void_p),
+                ("epilogue", c_int), ("w_ep", c_void_p), ("b_ep", c_void_p), ("ep_out", c_int),
+                ("enc", c_void_p), ("ldenc", c_int), ("e", c_int), ("ln_g", c_void_p), ("ln_b", c_void_p),
+                ("ln_eps", c_float), ("out", c_void_p), ("ldout", c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/nbd.h one to one (tests check the two agree)
 _F = POINTER(c_float)
 SIGNATURES = {
@@ -86,6 +97,7 @@ SIGNATURES = {
     "nbd_contconv_bin_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_float, c_void_p, c_void_p]),
     "nbd_degree_scale_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "nbd_gnn_layer_f32": (c_int, [POINTER(GnnLayerArgs), c_void_p]),
 }
 
 _lib = None

@@ -2,6 +2,8 @@
 unit inner stride; row strides are passed through so column slices of wider buffers work."""
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -113,3 +115,36 @@ def degree_scale(rowptr, n, mode, device):
         _lib.check(_lib.lib().nbd_degree_scale_f32(rowptr.data_ptr(), n, mode, out.data_ptr(),
                                                    _lib.current_stream(device)), "nbd_degree_scale_f32")
     return out
+
+
+EPILOGUE = {"write_x": 0, "next_pq": 1, "final_head": 2, "final_ln": 3}
+
+
+def gnn_layer(*, n, h, aggr, rowptr, src, fixed_k, w2t, b2, epilogue, out, pq=None, x=None, f=0, wpq=None, bpq=None,
+              w_ep=None, b_ep=None, ep_out=0, enc=None, e=0, ln_g=None, ln_b=None, ln_eps=1e-5):
+    """One fused EdgeConv layer (nbd_gnn_layer_f32). Returns False (nothing launched) when the shape is
+    outside what the fused kernel supports, so the caller can take the general multi-kernel path."""
+    a = _lib.GnnLayerArgs()
+    dev = out.device
+    kp = 64 * ((h + 63) // 64)
+    if h > 128 or (pq is None and f > 8) or (kp * h + kp * (ep_out if epilogue == "next_pq" else 0)) * 4 > 64 * 1024:
+        return False
+    if epilogue == "final_head" and ep_out > 8:
+        return False
+    if epilogue in ("final_head", "final_ln") and e > 256:
+        return False
+    for t in (w2t, b2, wpq, bpq, w_ep, b_ep, ln_g, ln_b):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda):
+            raise _lib.NbdError("gnn_layer: weights must be contiguous fp32 CUDA tensors")
+    a.rowptr, a.src, a.fixed_k, a.n = _lib.ptr(rowptr), _lib.ptr(src), fixed_k, n
+    a.pq, a.ldpq = _lib.ptr(pq), (_mat(pq, "pq") if pq is not None else 0)
+    a.x, a.ldx, a.f = _lib.ptr(x), (_mat(x, "x") if x is not None else 0), f
+    a.wpq, a.bpq = _lib.ptr(wpq), _lib.ptr(bpq)
+    a.h, a.aggr, a.w2t, a.b2 = h, AGGR[aggr], w2t.data_ptr(), b2.data_ptr()
+    a.epilogue, a.w_ep, a.b_ep, a.ep_out = EPILOGUE[epilogue], _lib.ptr(w_ep), _lib.ptr(b_ep), ep_out
+    a.enc, a.ldenc, a.e = _lib.ptr(enc), (_mat(enc, "enc") if enc is not None else 0), e
+    a.ln_g, a.ln_b, a.ln_eps = _lib.ptr(ln_g), _lib.ptr(ln_b), float(ln_eps)
+    a.out, a.ldout = out.data_ptr(), _mat(out, "out")
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().nbd_gnn_layer_f32(ctypes.byref(a), _lib.current_stream(dev)), "nbd_gnn_layer_f32")
+    return True

@@ -136,6 +136,8 @@ def _copy_state(dst, src):
     dict(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", neighbors=10),            # published (gnn_experiment.py:61-72)
     dict(input_dim=4, gnn_dim=32, message_passing_steps=3, aggr="sum", neighbors=5, output_hiddens=[16, 8]),
     dict(input_dim=7, gnn_dim=48, message_passing_steps=1, aggr="mean", neighbors=8, node_encoder_dims=[20, 24]),
+    dict(input_dim=7, gnn_dim=128, message_passing_steps=2, aggr="sum", neighbors=6),       # H = 128: general path only
+    dict(input_dim=4, gnn_dim=100, message_passing_steps=1, aggr="mean", neighbors=70, output_dim=5),
 ])
 def test_gnn_forward_matches_oracle(cfg, gpu_device):
     import gnn
@@ -151,16 +153,23 @@ def test_gnn_forward_matches_oracle(cfg, gpu_device):
     ei = so.knn_graph(pos, cfg["neighbors"])
     with torch.no_grad():
         ref = ora.forward_graph(x7, ei)
-    got = model.predict_graph(Data(x=x7.cuda(), edge_index=ei.cuda())).cpu()
-    assert global_rel(got, ref) < TOL and row_rel(got, ref) < 10 * TOL
+    for fused in (True, False):                 # one-launch-per-layer kernel and the general path
+        model.use_fused = fused
+        got = model.predict_graph(Data(x=x7.cuda(), edge_index=ei.cuda())).cpu()
+        assert global_rel(got, ref) < TOL and row_rel(got, ref) < 10 * TOL, fused
+        d = Data(x=x7.cuda(), edge_index=ei.cuda()); d._regular_k = cfg["neighbors"]
+        assert global_rel(model.predict_graph(d).cpu(), ref) < TOL, fused
+    model.use_fused = True
     # ragged graph (arbitrary edge order, a node without edges): general CSR path
     keep = torch.rand(ei.shape[1], generator=torch.Generator().manual_seed(3)) < 0.7
     keep &= ei[1] != 13
     ei2 = ei[:, keep][:, torch.randperm(int(keep.sum()), generator=torch.Generator().manual_seed(4))]
     with torch.no_grad():
         ref2 = ora.forward_graph(x7, ei2)
-    got2 = model.predict_graph(Data(x=x7.cuda(), edge_index=ei2.cuda())).cpu()
-    assert global_rel(got2, ref2) < TOL
+    for fused in (True, False):
+        model.use_fused = fused
+        got2 = model.predict_graph(Data(x=x7.cuda(), edge_index=ei2.cuda())).cpu()
+        assert global_rel(got2, ref2) < TOL, fused
 
 
 def test_gnn_predict_uses_k50_like_reference(gpu_device):

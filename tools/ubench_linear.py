@@ -31,3 +31,21 @@ print(f"layernorm: {t(lambda: nnops.layernorm(x, g, g, 1e-5, out=o)):.2f} us")
 a = torch.randn(n, 3).cuda(); v = torch.randn(n, 3).cuda()
 from nbd import direct
 print(f"kick: {t(lambda: direct.kick(v, a, 0.1)):.2f} us")
+
+# whole GNN predict (published shape) under graph replay: pure GPU time of the kernel sequence
+import gnn
+torch.manual_seed(0)
+model = gnn.GraphModel(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", device="cuda", neighbors=10).eval()
+feat = torch.randn(n, 4).cuda()
+for kk in (32, 50):
+    for fused in (True, False):
+        model.use_fused = fused
+        with torch.no_grad():
+            print(f"GNN predict k={kk} fused={fused}: {t(lambda: model.predict(pos, feat, neighbors=kk), 20):.1f} us")
+from nbd.data import Data
+ei = graphops.knn_graph(pos, 32)
+d = Data(x=torch.cat([pos, feat], 1), edge_index=ei); d._regular_k = 32
+for fused in (True, False):
+    model.use_fused = fused
+    with torch.no_grad():
+        print(f"GNN forward only (graph given, k=32) fused={fused}: {t(lambda: model.forward(d), 20):.1f} us")
