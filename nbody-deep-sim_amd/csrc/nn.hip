@@ -320,11 +320,41 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // Trilinear weights follow F.grid_sample(align_corners=True) with coordinate component 0 indexing
 // filter axis 2 (x fastest) and component 2 indexing axis 0: cell = (z*D + y)*D + x  (contconv.py:62-75).
 struct EdgeGeo { int c, ix, iy, iz; float tx, ty, tz, window; };
+constexpr int kGeoCache = 256;     // edge geometries kept in LDS per node (in-degree above this: recomputed per slab)
 
+__device__ __forceinline__ EdgeGeo edge_geometry(const float* __restrict__ pos, int c, float xn, float yn, float zn,
+                                                 float r2max, float half) {
+  EdgeGeo g;
+  g.c = c;
+  // r = positions[col] - positions[row] (contconv.py:84): centre minus this node
+  const float rx = pos[3 * c] - xn, ry = pos[3 * c + 1] - yn, rz = pos[3 * c + 2] - zn;
+  const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz));
+  const float qq = 1.0f - d2 / r2max;
+  g.window = (d2 < r2max) ? qq * qq * qq : 0.f;                  // contconv.py:85-87
+  const float nrm = sqrtf(d2);
+  const float sc = tanhf(nrm) / (nrm + 1e-8f);                   // ball_to_cube (contconv.py:30-33)
+  const float gx = (rx * sc + 1.0f) * half, gy = (ry * sc + 1.0f) * half, gz = (rz * sc + 1.0f) * half;
+  const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+  g.ix = (int)fx; g.iy = (int)fy; g.iz = (int)fz;
+  g.tx = gx - fx; g.ty = gy - fy; g.tz = gz - fz;
+  return g;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Variants measured at N = 16 384, D = 6 / 4 (tools/bench_surrogates.py + rocprofv3): whole 216-cell image
+// per wave (55 KB LDS, 2 waves/CU) 2390 / 490 us; z-slab images with the geometry recomputed per slab
+// 586 / 368 us; this version (geometry cached once per node, only the edges that touch the slab are
+// visited, two feature rows in flight) 552 / 310 us; staging the chunk's feature rows in LDS (27 KB per
+// wave) 850 / 420 us -- the kernel lives on the number of waves in flight, so LDS stays small.
 __global__ __launch_bounds__(64) void contconv_bin_kernel(
     const float* __restrict__ pos, const float* __restrict__ feat, int ldf, int I, const int* __restrict__ rowptr,
     const int* __restrict__ centres, int node_begin, int D, float r2max, float* __restrict__ A) {
-  extern __shared__ float img[];            // [D*D][64] slab image, then 64 EdgeGeo records
+  extern __shared__ float img[];            // [D*D][64] slab image, then kGeoCache EdgeGeo records
   const int node = node_begin + blockIdx.x, cg = blockIdx.y, lane = threadIdx.x;
   const int ch = cg * 64 + lane;
   const int slab_cells = D * D;
@@ -332,45 +362,56 @@ __global__ __launch_bounds__(64) void contconv_bin_kernel(
   const float xn = pos[3 * node], yn = pos[3 * node + 1], zn = pos[3 * node + 2];
   const float half = (float)(D - 1) / 2.0f;
   const int e0 = rowptr[node], e1 = rowptr[node + 1];
+  const bool cached = (e1 - e0) <= kGeoCache;
   for (int c = 0; c < slab_cells; ++c) img[c * 64 + lane] = 0.f;
+  if (cached) {       // every edge's geometry once (lane = edge), reused by all D slabs
+    for (int e = e0 + lane; e < e1; e += 64) geo[e - e0] = edge_geometry(pos, centres[e], xn, yn, zn, r2max, half);
+    wave_lds_sync();
+  }
   for (int z = 0; z < D; ++z) {
     for (int eb = e0; eb < e1; eb += 64) {
       const int cnt = min(64, e1 - eb);
-      if (lane < cnt) {
-        EdgeGeo g;
-        g.c = centres[eb + lane];
-        // r = positions[col] - positions[row] (contconv.py:84): centre minus this node
-        const float rx = pos[3 * g.c] - xn, ry = pos[3 * g.c + 1] - yn, rz = pos[3 * g.c + 2] - zn;
-        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz));
-        const float qq = 1.0f - d2 / r2max;
-        g.window = (d2 < r2max) ? qq * qq * qq : 0.f;                  // contconv.py:85-87
-        const float nrm = sqrtf(d2);
-        const float sc = tanhf(nrm) / (nrm + 1e-8f);                   // ball_to_cube (contconv.py:30-33)
-        const float gx = (rx * sc + 1.0f) * half, gy = (ry * sc + 1.0f) * half, gz = (rz * sc + 1.0f) * half;
-        const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
-        g.ix = (int)fx; g.iy = (int)fy; g.iz = (int)fz;
-        g.tx = gx - fx; g.ty = gy - fy; g.tz = gz - fz;
-        geo[lane] = g;
+      const int gbase = cached ? eb - e0 : 0;
+      if (!cached) {
+        if (lane < cnt) geo[lane] = edge_geometry(pos, centres[eb + lane], xn, yn, zn, r2max, half);
+        wave_lds_sync();
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      for (int e = 0; e < cnt; ++e) {
-        const EdgeGeo g = geo[e];                                      // wave-uniform LDS broadcast
-        const int az = z - g.iz;                                       // 0 or 1 if this edge touches slab z
-        if ((az != 0 && az != 1) || g.window == 0.f) continue;
-        const float wz = (az ? g.tz : 1.0f - g.tz) * g.window;
-        const float f = (ch < I) ? feat[(size_t)g.c * ldf + ch] * wz : 0.f;
+      // edges of this chunk that touch slab z (iz == z or iz + 1 == z) and carry weight
+      bool act = false;
+      if (lane < cnt) {
+        const int az = z - geo[gbase + lane].iz;
+        act = (az == 0 || az == 1) && geo[gbase + lane].window != 0.f;
+      }
+      unsigned long long m = __ballot(act);
+      while (m) {                                   // two active edges per trip: their feature loads overlap
+        const int ea = __builtin_ctzll(m); m &= m - 1;
+        const bool two = m != 0;
+        const int eb2 = two ? __builtin_ctzll(m) : ea;
+        if (two) m &= m - 1;
+        const EdgeGeo g0 = geo[gbase + ea], g1 = geo[gbase + eb2];     // wave-uniform LDS broadcasts
+        float f0 = 0.f, f1 = 0.f;
+        if (ch < I) { f0 = feat[(size_t)g0.c * ldf + ch]; f1 = feat[(size_t)g1.c * ldf + ch]; }
+        if (!two) f1 = 0.f;
+        f0 *= ((z - g0.iz) ? g0.tz : 1.0f - g0.tz) * g0.window;
+        f1 *= ((z - g1.iz) ? g1.tz : 1.0f - g1.tz) * g1.window;
 #pragma unroll
         for (int corner = 0; corner < 4; ++corner) {
           const int ax = corner & 1, ay = corner >> 1;
-          const int cx = g.ix + ax, cy = g.iy + ay;
+          const int cx = g0.ix + ax, cy = g0.iy + ay;
           if (cx < 0 || cx >= D || cy < 0 || cy >= D) continue;        // zero padding of grid_sample
-          const float w = (ax ? g.tx : 1.0f - g.tx) * (ay ? g.ty : 1.0f - g.ty);
-          img[(cy * D + cx) * 64 + lane] += w * f;
+          img[(cy * D + cx) * 64 + lane] += (ax ? g0.tx : 1.0f - g0.tx) * (ay ? g0.ty : 1.0f - g0.ty) * f0;
+        }
+        if (two) {
+#pragma unroll
+          for (int corner = 0; corner < 4; ++corner) {
+            const int ax = corner & 1, ay = corner >> 1;
+            const int cx = g1.ix + ax, cy = g1.iy + ay;
+            if (cx < 0 || cx >= D || cy < 0 || cy >= D) continue;
+            img[(cy * D + cx) * 64 + lane] += (ax ? g1.tx : 1.0f - g1.tx) * (ay ? g1.ty : 1.0f - g1.ty) * f1;
+          }
         }
       }
-      __builtin_amdgcn_wave_barrier();
+      if (!cached) __builtin_amdgcn_wave_barrier();
     }
     if (ch < I) {
       float* dst = A + ((size_t)blockIdx.x * D * slab_cells + (size_t)z * slab_cells) * I + ch;
@@ -478,7 +519,7 @@ int nbd_contconv_bin_f32(const float* pos, const float* feat, int ldf, int in_ch
   if (n < 0 || node_begin < 0 || in_channels <= 0 || filter_resolution < 2) return NBD_E_BADARG;
   if (n == 0) return 0;
   if (!pos || !feat || !rowptr || !centres || !a_out || ldf < in_channels) return NBD_E_BADARG;
-  const size_t shmem = (size_t)filter_resolution * filter_resolution * 64 * sizeof(float) + 64 * sizeof(EdgeGeo);
+  const size_t shmem = (size_t)filter_resolution * filter_resolution * 64 * sizeof(float) + kGeoCache * sizeof(EdgeGeo);
   if (shmem > 64 * 1024) return NBD_E_UNSUPPORTED;       // D <= 15
   dim3 grid(n, ceil_div(in_channels, 64));
   contconv_bin_kernel<<<grid, 64, shmem, (hipStream_t)stream>>>(pos, feat, ldf, in_channels, rowptr, centres,
