@@ -134,8 +134,17 @@ int nbd_knn_graph_f32(const float* pos, int n, int k, int loop, const int* seg_l
  * nbr[i][0..deg[i]) = the first max_num_neighbors indices j (ascending) with d2 < radius_sq
  * (strict), j == i iff loop; last[i] = the largest listed j (-1 if none). No host sync needed. */
 int nbd_radius_search_f32(const float* pos, int n, float radius_sq, int loop, int max_num_neighbors,
-                          const int* seg_lo, const int* seg_hi, int* nbr, int* deg, int* last,
+                          const int* seg_lo, const int* seg_hi, int* nbr, int* deg, int* last, int* indeg,
                           nbd_stream_t stream);
+/* indeg (optional, int32 [n], zeroed by the call): indeg[j] = number of lists that hold j -- the
+ * in-degree the transpose needs, counted with integer atomics while the lists are built.
+ *
+ * O(E) transpose of the lists (what the ContinuousConv pipeline uses): with rowptr = exclusive scan
+ * of indeg, centres[rowptr[j] ..] = the centres c whose list holds j, ascending (scatter through an
+ * atomic cursor, then a per-row rank sort: deterministic). cursor: int32 [n] scratch; scratch: int32
+ * [>= E] scratch. Same result as the two nbd_radius_transpose_*_f32 scans below. */
+int nbd_radius_transpose_lists(const int* nbr, const int* deg, int n, int cap, const int* rowptr, int* cursor,
+                               int* scratch, int* centres, nbd_stream_t stream);
 
 /* Transposed adjacency of those capped lists: indeg[j] = number of centres c whose list holds j;
  * after an exclusive scan, centres[rowptr[j] ..] = those c, ascending. This is the grouping

@@ -213,6 +213,13 @@ __global__ __launch_bounds__(256) void kick_drift_kernel(float* __restrict__ pos
   if (posm) posm[i] = pm;
 }
 
+// zero fill by kernel, not hipMemsetAsync: memset nodes captured into a hipGraph were observed not to
+// re-execute on replay on this stack (see csrc/graph.hip), and every entry point here must be capturable
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                    float c, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -430,7 +437,10 @@ int nbd_accel_f32(const float* posm_src, int n_src, const float* posm_tgt, int n
   if (n_tgt == 0) return 0;
   if (!acc_out || !posm_tgt || misaligned16(posm_tgt)) return NBD_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (n_src == 0) return check(hipMemsetAsync(acc_out, 0, (size_t)n_tgt * 3 * sizeof(float), st));
+  if (n_src == 0) {
+    zero_f32_kernel<<<ceil_div(n_tgt * 3, 256), 256, 0, st>>>(acc_out, (size_t)n_tgt * 3);
+    return launch_status();
+  }
   if (!posm_src || misaligned16(posm_src)) return NBD_E_BADARG;
   const AccelPlan p = plan_accel(n_src, n_tgt);
   if (p.slabs == 1)
@@ -536,7 +546,10 @@ int nbd_energy_f32(const float* posm, const float* vel, int n, float softening, 
                    double* out_uk, void* workspace, size_t workspace_bytes, nbd_stream_t stream) {
   if (n < 0 || !out_uk) return NBD_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (n == 0) return check(hipMemsetAsync(out_uk, 0, 2 * sizeof(double), st));
+  if (n == 0) {
+    zero_f32_kernel<<<1, 256, 0, st>>>(reinterpret_cast<float*>(out_uk), 4);   // two doubles
+    return launch_status();
+  }
   if (!posm || !vel || misaligned16(posm)) return NBD_E_BADARG;
   if (!workspace || workspace_bytes < nbd_energy_workspace_bytes(n)) return NBD_E_WORKSPACE;
   const int groups = ceil_div(n, kTgtPerWG), slabs = energy_slabs(groups), nk = ceil_div(n, 256);

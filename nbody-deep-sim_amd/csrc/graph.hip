@@ -115,7 +115,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_kernel(
 // ---- radius: first `cap` hits in index order -> ELL lists nbr[n][cap], deg[n], last[n]
 __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_kernel(
     const float* __restrict__ pos, int n, float r2, int loop, int cap, const int* __restrict__ seg_lo,
-    const int* __restrict__ seg_hi, int* __restrict__ nbr, int* __restrict__ deg, int* __restrict__ last) {
+    const int* __restrict__ seg_hi, int* __restrict__ nbr, int* __restrict__ deg, int* __restrict__ last,
+    int* __restrict__ indeg) {
   const int i = blockIdx.x * kWavesPerBlock + wave_id();
   if (i >= n) return;
   const int lane = threadIdx.x & 63;
@@ -128,7 +129,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_kernel(
     if (j < hi && (loop || j != i)) hit = dist2(pos, j, xi, yi, zi) < r2;
     const unsigned long long m = __ballot(hit);
     const int slot = count + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-    if (hit && slot < cap) nbr[(size_t)i * cap + slot] = j;
+    if (hit && slot < cap) {
+      nbr[(size_t)i * cap + slot] = j;
+      if (indeg) atomicAdd(&indeg[j], 1);          // integer counts: order-independent, deterministic
+    }
     const int taken = min(__builtin_popcountll(m), cap - count);
     if (taken > 0) {                                // index of the taken-th set bit = last listed j
       unsigned long long mm = m;
@@ -169,6 +173,37 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_transpose_kernel(
     count += __builtin_popcountll(m);
   }
   if (!FILL && lane == 0) indeg[j] = count;
+}
+
+// ---- O(E) transpose of the capped lists (replaces the two O(N^2) radius_transpose passes on the hot
+// path): scatter every listed (c -> j) into row j through an atomic cursor, then sort each row's
+// centres ascending so the result is deterministic and identical to the scanning version.
+__global__ __launch_bounds__(256) void transpose_scatter_kernel(const int* __restrict__ nbr, const int* __restrict__ deg,
+                                                               int n, int cap, const int* __restrict__ rowptr,
+                                                               int* __restrict__ cursor, int* __restrict__ centres) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int c = t / cap, s = t - c * cap;
+  if (c >= n || s >= deg[c]) return;
+  const int j = nbr[(size_t)c * cap + s];
+  centres[rowptr[j] + atomicAdd(&cursor[j], 1)] = c;
+}
+
+// one wave per row, out of place: rank of x = number of row entries below it (entries are distinct
+// centre indices); lane k handles entries k, k+64, ...; the comparison operand is a wave-uniform load
+__global__ __launch_bounds__(64 * kWavesPerBlock) void sort_rows_kernel(const int* __restrict__ rowptr, int n,
+                                                                        const int* __restrict__ unsorted,
+                                                                        int* __restrict__ centres) {
+  const int j = blockIdx.x * kWavesPerBlock + wave_id();
+  if (j >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int b = rowptr[j], d = rowptr[j + 1] - b;
+  for (int k0 = 0; k0 < d; k0 += 64) {
+    const int k = k0 + lane;
+    const int x = k < d ? unsorted[b + k] : 0x7fffffff;
+    int rank = 0;
+    for (int k2 = 0; k2 < d; ++k2) rank += (unsorted[b + k2] < x) ? 1 : 0;
+    if (k < d) centres[b + rank] = x;
+  }
 }
 
 // exclusive scan of int32 counts into ptr[0..n] (single workgroup; n up to a few million)
@@ -212,6 +247,14 @@ __global__ __launch_bounds__(256) void ell_to_edges_kernel(const int* __restrict
   edge_index[e_total + e] = i;
 }
 
+// Zero fill as a kernel of our own: hipMemsetAsync nodes captured into a hipGraph did not re-execute on
+// replay on this stack (ROCm 7.2 + torch 2.10 stream capture) -- the counters below then kept their
+// previous values, the second replay doubled every in-degree and the scatter ran off its buffer.
+__global__ __launch_bounds__(256) void zero_i32_kernel(int* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int status() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : (int)e; }
 
@@ -237,13 +280,31 @@ int nbd_knn_graph_f32(const float* pos, int n, int k, int loop, const int* seg_l
 }
 
 int nbd_radius_search_f32(const float* pos, int n, float radius_sq, int loop, int max_num_neighbors,
-                          const int* seg_lo, const int* seg_hi, int* nbr, int* deg, int* last,
+                          const int* seg_lo, const int* seg_hi, int* nbr, int* deg, int* last, int* indeg,
                           nbd_stream_t stream) {
   if (n < 0 || max_num_neighbors < 0 || (seg_lo == nullptr) != (seg_hi == nullptr)) return NBD_E_BADARG;
   if (n == 0) return 0;
   if (!pos || !deg || !last || (max_num_neighbors > 0 && !nbr)) return NBD_E_BADARG;
-  radius_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, (hipStream_t)stream>>>(
-      pos, n, radius_sq, loop, max_num_neighbors, seg_lo, seg_hi, nbr, deg, last);
+  hipStream_t st = (hipStream_t)stream;
+  if (indeg) zero_i32_kernel<<<ceil_div(n, 256), 256, 0, st>>>(indeg, n);
+  radius_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
+      pos, n, radius_sq, loop, max_num_neighbors, seg_lo, seg_hi, nbr, deg, last, indeg);
+  return status();
+}
+
+int nbd_radius_transpose_lists(const int* nbr, const int* deg, int n, int cap, const int* rowptr, int* cursor,
+                               int* scratch, int* centres, nbd_stream_t stream) {
+  if (n < 0 || cap < 0) return NBD_E_BADARG;
+  if (n == 0 || cap == 0) return 0;
+  if (!nbr || !deg || !rowptr || !cursor || !scratch || !centres) return NBD_E_BADARG;
+  const long long total = (long long)n * cap;
+  if (total > 0x7fffffffLL) return NBD_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  zero_i32_kernel<<<ceil_div(n, 256), 256, 0, st>>>(cursor, n);
+  transpose_scatter_kernel<<<ceil_div((int)total, 256), 256, 0, st>>>(nbr, deg, n, cap, rowptr, cursor, scratch);
+  int rc = status();
+  if (rc) return rc;
+  sort_rows_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(rowptr, n, scratch, centres);
   return status();
 }
 

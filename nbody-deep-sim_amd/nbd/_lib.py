@@ -79,7 +79,9 @@ SIGNATURES = {
     "nbd_knn_graph_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_void_p, c_void_p]),
     "nbd_radius_search_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                      c_void_p, c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nbd_radius_transpose_lists": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p]),
     "nbd_radius_transpose_count_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),
     "nbd_radius_transpose_fill_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,

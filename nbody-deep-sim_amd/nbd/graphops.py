@@ -76,7 +76,7 @@ def radius_r2(r: float) -> float:
 
 
 def radius_lists(pos: torch.Tensor, r: float, batch=None, loop: bool = False, max_num_neighbors: int = 32,
-                 transpose: bool = True) -> RadiusLists:
+                 transpose: bool = True, scan_transpose: bool = False) -> RadiusLists:
     n = pos.shape[0]
     _chk(pos, (n, 3), "pos")
     dev = pos.device
@@ -89,18 +89,27 @@ def radius_lists(pos: torch.Tensor, r: float, batch=None, loop: bool = False, ma
     L, st = _lib.lib(), _stream(dev)
     rowptr = centres = None
     with torch.cuda.device(dev):
-        _lib.check(L.nbd_radius_search_f32(pos.data_ptr(), n, r2, int(loop), cap, _lib.ptr(lo), _lib.ptr(hi),
-                                           nbr.data_ptr(), deg.data_ptr(), last.data_ptr(), st), "nbd_radius_search_f32")
-        if transpose:
+        if not transpose:
+            _lib.check(L.nbd_radius_search_f32(pos.data_ptr(), n, r2, int(loop), cap, _lib.ptr(lo), _lib.ptr(hi),
+                                               nbr.data_ptr(), deg.data_ptr(), last.data_ptr(), None, st),
+                       "nbd_radius_search_f32")
+        else:
             indeg = torch.empty(n, dtype=torch.int32, device=dev)
             rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
             centres = torch.empty(max(n * cap, 1), dtype=torch.int32, device=dev)   # E <= n*cap: no sync needed
-            _lib.check(L.nbd_radius_transpose_count_f32(pos.data_ptr(), n, r2, int(loop), _lib.ptr(lo), _lib.ptr(hi),
-                                                        last.data_ptr(), indeg.data_ptr(), st), "radius_transpose_count")
+            _lib.check(L.nbd_radius_search_f32(pos.data_ptr(), n, r2, int(loop), cap, _lib.ptr(lo), _lib.ptr(hi),
+                                               nbr.data_ptr(), deg.data_ptr(), last.data_ptr(), indeg.data_ptr(), st),
+                       "nbd_radius_search_f32")
             _lib.check(L.nbd_exclusive_scan_i32(indeg.data_ptr(), n, rowptr.data_ptr(), st), "exclusive_scan")
-            _lib.check(L.nbd_radius_transpose_fill_f32(pos.data_ptr(), n, r2, int(loop), _lib.ptr(lo), _lib.ptr(hi),
-                                                       last.data_ptr(), rowptr.data_ptr(), centres.data_ptr(), st),
-                       "radius_transpose_fill")
+            if scan_transpose:      # O(N^2) scanning transpose (kept as the independent cross-check)
+                _lib.check(L.nbd_radius_transpose_fill_f32(pos.data_ptr(), n, r2, int(loop), _lib.ptr(lo), _lib.ptr(hi),
+                                                           last.data_ptr(), rowptr.data_ptr(), centres.data_ptr(), st),
+                           "radius_transpose_fill")
+            else:                   # O(E): scatter + per-row sort
+                scratch = torch.empty_like(centres)
+                _lib.check(L.nbd_radius_transpose_lists(nbr.data_ptr(), deg.data_ptr(), n, cap, rowptr.data_ptr(),
+                                                        indeg.data_ptr(), scratch.data_ptr(), centres.data_ptr(), st),
+                           "nbd_radius_transpose_lists")
     return RadiusLists(n, cap, nbr, deg, last, rowptr, centres)
 
 

@@ -68,12 +68,13 @@ def test_radius_graph_bit_exact(n, r, loop, cap, gpu_device):
     got = graphops.radius_graph(pos.cuda(), r, loop=loop, max_num_neighbors=cap).cpu()
     assert torch.equal(got, ref)
     # the transposed lists are the same edges sorted (stably) by edge_index[0]
-    lists = graphops.radius_lists(pos.cuda(), r, loop=loop, max_num_neighbors=cap)
     order = torch.sort(ref[0], stable=True).indices
     e = ref.shape[1]
-    assert int(lists.rowptr[-1]) == e
-    assert torch.equal(lists.centres[:e].cpu().to(torch.int64), ref[1][order])
-    assert torch.equal(lists.rowptr.cpu().to(torch.int64)[1:], torch.cumsum(torch.bincount(ref[0], minlength=n), 0))
+    for scan in (False, True):      # O(E) scatter+sort transpose and the O(N^2) scanning one must agree
+        lists = graphops.radius_lists(pos.cuda(), r, loop=loop, max_num_neighbors=cap, scan_transpose=scan)
+        assert int(lists.rowptr[-1]) == e
+        assert torch.equal(lists.centres[:e].cpu().to(torch.int64), ref[1][order])
+        assert torch.equal(lists.rowptr.cpu().to(torch.int64)[1:], torch.cumsum(torch.bincount(ref[0], minlength=n), 0))
 
 
 def test_radius_graph_batched(gpu_device):
@@ -309,3 +310,31 @@ def test_test_from_dir_on_a_generated_csv(tmp_path, gpu_device):
     assert np.isfinite(df_roll.values).all() and (df_roll.loc[("output_file_1.csv", 0, 0)][["pos_rmse", "vel_rmse"]] == 0).all()
     with pytest.raises(NotImplementedError):
         tr.train_from_dir(str(path), 1, 1, 0)
+
+
+@pytest.mark.parametrize("kind", ["gnn", "contconv"])
+def test_hipgraph_rollout_step_equals_eager(kind, gpu_device):
+    """Trainer._capture_step replays the captured step several times (state advances inside the graph);
+    every replay must equal the eager Trainer.step bit for bit -- in particular counters that are
+    zeroed inside the captured region have to be re-zeroed on every replay."""
+    import contconv
+    import gnn
+    import trainer
+    torch.manual_seed(5)
+    if kind == "gnn":
+        model = gnn.GraphModel(input_dim=4, gnn_dim=32, message_passing_steps=2, aggr="mean", neighbors=10, device="cuda")
+    else:
+        model = contconv.ContinuousConvModel(in_channels=4, out_channels=3, filter_resolution=[4, 3], radius=1.0, agg="mean",
+                                             continuous_conv_layers=2, continuous_conv_dim=16, encoder_hiddens=[8],
+                                             decoder_hiddens=[8], device="cuda").eval()
+    tr = trainer.Trainer(model, None, device="cuda", dt=0.01)
+    pos, vel, m = _plummer_pos(900, 21)
+    pos, vel, m1 = pos.cuda(), vel.cuda(), (m * 900)[:, None].cuda()
+    acc = model.predict(pos, torch.cat([vel, m1], 1))
+    adv = tr._capture_step(pos, vel, m1, acc, 0.01)
+    assert adv is not None
+    p, v, a = pos, vel, acc
+    for i in range(4):
+        p, v, a = tr.step(p, v, m1, a, 0.01)
+        gp, gv, ga = adv()
+        assert torch.equal(gp, p) and torch.equal(gv, v) and torch.equal(ga, a), (kind, i)

@@ -23,6 +23,11 @@ def state(n, seed, scale=1.0):
     return pos, vel, m1
 
 
+def _trace(msg):
+    if os.environ.get("NBD_TRACE"):
+        torch.cuda.synchronize(); print("trace:", msg, file=sys.stderr, flush=True)
+
+
 def timeit(fn, iters, warm=3):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
@@ -72,6 +77,7 @@ def run(iters=20):
                            output_hiddens=None, device="cuda", neighbors=10, scale_factor=1e6)
     tr = trainer.Trainer(model, None, device="cuda", dt=1e-4)
     pos, vel, m1 = state(4096, 1234)
+    _trace("gnn model built")
     for k in (32, 50):
         acc = model.predict(pos, torch.cat([vel, m1], 1), neighbors=k)
         st = [pos, vel, acc]
@@ -86,32 +92,41 @@ def run(iters=20):
         kn_ms, _ = timeit(lambda: graphops.knn_graph(pos, k), iters)
         out[f"gnn_n4096_k{k}"] = {"rollout_step_ms_gpu": g_ms, "rollout_step_ms_wall": w_ms, "knn_graph_ms": kn_ms,
                                  "edges": 4096 * k}
+    _trace("gnn k loops done")
     acc = model.predict(pos, torch.cat([vel, m1], 1))
     g_ms, w_ms = timeit(lambda: tr.step(pos, vel, m1, acc, 1e-4), iters)
+    _trace("gnn trainer step timed")
     out["gnn_n4096_trainer_step_k50"] = {"ms_gpu": g_ms, "ms_wall": w_ms}
     adv = tr._capture_step(pos, vel, m1, acc, 1e-4)
     if adv is not None:
         g_ms, w_ms = timeit(adv, iters)
         out["gnn_n4096_trainer_step_k50_hipgraph"] = {"ms_gpu": g_ms, "ms_wall": w_ms}
 
+    _trace("gnn graph timed")
     torch.manual_seed(0)
     cc = contconv.ContinuousConvModel(in_channels=4, out_channels=3, filter_resolution=[6, 4], radius=1.0, agg="mean",
                                       self_loops=True, continuous_conv_layers=2, continuous_conv_dim=128,
                                       encoder_hiddens=[32, 64], encoder_dropout=0.0, decoder_hiddens=[64, 32],
                                       device="cuda", scale_factor=1e6).eval()
     n = 16384
+    _trace("contconv model built")
     scale, deg = degree_scale_for(n)
+    _trace("degree scale found")
     pos, vel, m1 = state(n, 1234, scale)
     lists = graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32)
     tr2 = trainer.Trainer(cc, None, device="cuda", dt=1e-4)
     acc = cc.predict(pos, torch.cat([vel, m1], 1))
+    _trace("contconv first predict")
     g_ms, w_ms = timeit(lambda: tr2.step(pos, vel, m1, acc, 1e-4), max(iters // 2, 3))
+    _trace("contconv step timed")
     adv = tr2._capture_step(pos, vel, m1, acc, 1e-4)
     cc_graph = timeit(adv, max(iters // 2, 3)) if adv is not None else (None, None)
+    _trace("contconv graph timed")
     r_ms, _ = timeit(lambda: graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32), max(iters // 2, 3))
     out["contconv_n16384"] = {"rollout_step_ms_gpu": g_ms, "rollout_step_ms_wall": w_ms, "rollout_step_ms_gpu_hipgraph": cc_graph[0], "radius_lists_ms": r_ms,
                               "position_scale": scale, "mean_uncapped_degree": deg,
                               "edges_capped": int(lists.rowptr[-1]), "max_in_degree": int((lists.rowptr[1:] - lists.rowptr[:-1]).max())}
+    _trace("radius lists timed")
     out["gnn_n4096_rollout_mse_vs_direct"] = rollout_mse_vs_direct(model, 4096, None, 10)
     return out
 
