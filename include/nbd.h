@@ -192,7 +192,7 @@ int nbd_layernorm_f32(const float* x, int ldx, int c, const float* gamma, const 
  *      window_e * trilinear_weight_e(cell) * feat[centre_e][i],   cell = (z*D + y)*D + x,
  * window/ball_to_cube/grid_sample(align_corners=True) exactly as contconv.py:30-33,53-78,85-90, so
  * that ContinuousConv = scatter_mean(...) = rowscale * (a_out . filters.reshape(D^3*I, O)).
- * rowptr/centres: CSR by aggregation target (nbd_radius_transpose_*). D <= 15.
+ * rowptr/centres: CSR by aggregation target (nbd_radius_transpose_*). D <= 10.
  * Rows [node_begin, node_begin + n) are produced into a_out[0 .. n): callers bin + contract in node
  * chunks whose A block stays resident in the 256 MiB Infinity Cache instead of round-tripping HBM. */
 int nbd_contconv_bin_f32(const float* pos, const float* feat, int ldf, int in_channels, const int* rowptr,

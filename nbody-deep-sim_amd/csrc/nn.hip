@@ -348,22 +348,28 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // Variants measured at N = 16 384, D = 6 / 4 (tools/bench_surrogates.py + rocprofv3): whole 216-cell image
 // per wave (55 KB LDS, 2 waves/CU) 2390 / 490 us; z-slab images with the geometry recomputed per slab
-// 586 / 368 us; this version (geometry cached once per node, only the edges that touch the slab are
-// visited, two feature rows in flight) 552 / 310 us; staging the chunk's feature rows in LDS (27 KB per
-// wave) 850 / 420 us -- the kernel lives on the number of waves in flight, so LDS stays small.
+// 586 / 368 us; geometry cached once per node, only the edges that touch the slab visited, two feature
+// rows in flight 552 / 310 us; staging the chunk's feature rows in LDS (27 KB per wave) 850 / 420 us --
+// the kernel lives on the number of waves in flight and on instructions per byte, hence CPL channels
+// per lane (one wave covers 64*CPL channels with 8-byte LDS/global accesses).
+template <int CPL>
 __global__ __launch_bounds__(64) void contconv_bin_kernel(
     const float* __restrict__ pos, const float* __restrict__ feat, int ldf, int I, const int* __restrict__ rowptr,
     const int* __restrict__ centres, int node_begin, int D, float r2max, float* __restrict__ A) {
-  extern __shared__ float img[];            // [D*D][64] slab image, then kGeoCache EdgeGeo records
+  typedef float vec __attribute__((ext_vector_type(CPL)));
+  extern __shared__ float img_raw[];        // [D*D][64] vec slab image, then kGeoCache EdgeGeo records
+  vec* img = reinterpret_cast<vec*>(img_raw);
   const int node = node_begin + blockIdx.x, cg = blockIdx.y, lane = threadIdx.x;
-  const int ch = cg * 64 + lane;
+  const int ch = (cg * 64 + lane) * CPL;                 // first of this lane's CPL consecutive channels
   const int slab_cells = D * D;
   EdgeGeo* geo = reinterpret_cast<EdgeGeo*>(img + slab_cells * 64);
   const float xn = pos[3 * node], yn = pos[3 * node + 1], zn = pos[3 * node + 2];
   const float half = (float)(D - 1) / 2.0f;
   const int e0 = rowptr[node], e1 = rowptr[node + 1];
   const bool cached = (e1 - e0) <= kGeoCache;
-  for (int c = 0; c < slab_cells; ++c) img[c * 64 + lane] = 0.f;
+  const bool live = ch + CPL <= I;                       // host guarantees I % CPL == 0
+  const vec zero = {};
+  for (int c = 0; c < slab_cells; ++c) img[c * 64 + lane] = zero;
   if (cached) {       // every edge's geometry once (lane = edge), reused by all D slabs
     for (int e = e0 + lane; e < e1; e += 64) geo[e - e0] = edge_geometry(pos, centres[e], xn, yn, zn, r2max, half);
     wave_lds_sync();
@@ -389,9 +395,12 @@ __global__ __launch_bounds__(64) void contconv_bin_kernel(
         const int eb2 = two ? __builtin_ctzll(m) : ea;
         if (two) m &= m - 1;
         const EdgeGeo g0 = geo[gbase + ea], g1 = geo[gbase + eb2];     // wave-uniform LDS broadcasts
-        float f0 = 0.f, f1 = 0.f;
-        if (ch < I) { f0 = feat[(size_t)g0.c * ldf + ch]; f1 = feat[(size_t)g1.c * ldf + ch]; }
-        if (!two) f1 = 0.f;
+        vec f0 = zero, f1 = zero;
+        if (live) {
+          f0 = *reinterpret_cast<const vec*>(feat + (size_t)g0.c * ldf + ch);
+          f1 = *reinterpret_cast<const vec*>(feat + (size_t)g1.c * ldf + ch);
+        }
+        if (!two) f1 = zero;
         f0 *= ((z - g0.iz) ? g0.tz : 1.0f - g0.tz) * g0.window;
         f1 *= ((z - g1.iz) ? g1.tz : 1.0f - g1.tz) * g1.window;
 #pragma unroll
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(64) void contconv_bin_kernel(
           const int ax = corner & 1, ay = corner >> 1;
           const int cx = g0.ix + ax, cy = g0.iy + ay;
           if (cx < 0 || cx >= D || cy < 0 || cy >= D) continue;        // zero padding of grid_sample
-          img[(cy * D + cx) * 64 + lane] += (ax ? g0.tx : 1.0f - g0.tx) * (ay ? g0.ty : 1.0f - g0.ty) * f0;
+          img[(cy * D + cx) * 64 + lane] += ((ax ? g0.tx : 1.0f - g0.tx) * (ay ? g0.ty : 1.0f - g0.ty)) * f0;
         }
         if (two) {
 #pragma unroll
@@ -407,17 +416,20 @@ __global__ __launch_bounds__(64) void contconv_bin_kernel(
             const int ax = corner & 1, ay = corner >> 1;
             const int cx = g1.ix + ax, cy = g1.iy + ay;
             if (cx < 0 || cx >= D || cy < 0 || cy >= D) continue;
-            img[(cy * D + cx) * 64 + lane] += (ax ? g1.tx : 1.0f - g1.tx) * (ay ? g1.ty : 1.0f - g1.ty) * f1;
+            img[(cy * D + cx) * 64 + lane] += ((ax ? g1.tx : 1.0f - g1.tx) * (ay ? g1.ty : 1.0f - g1.ty)) * f1;
           }
         }
       }
       if (!cached) __builtin_amdgcn_wave_barrier();
     }
-    if (ch < I) {
+    if (live) {
       float* dst = A + ((size_t)blockIdx.x * D * slab_cells + (size_t)z * slab_cells) * I + ch;
-      for (int c = 0; c < slab_cells; ++c) { dst[(size_t)c * I] = img[c * 64 + lane]; img[c * 64 + lane] = 0.f; }
+      for (int c = 0; c < slab_cells; ++c) {
+        *reinterpret_cast<vec*>(dst + (size_t)c * I) = img[c * 64 + lane];
+        img[c * 64 + lane] = zero;
+      }
     } else {
-      for (int c = 0; c < slab_cells; ++c) img[c * 64 + lane] = 0.f;
+      for (int c = 0; c < slab_cells; ++c) img[c * 64 + lane] = zero;
     }
   }
 }
@@ -519,11 +531,20 @@ int nbd_contconv_bin_f32(const float* pos, const float* feat, int ldf, int in_ch
   if (n < 0 || node_begin < 0 || in_channels <= 0 || filter_resolution < 2) return NBD_E_BADARG;
   if (n == 0) return 0;
   if (!pos || !feat || !rowptr || !centres || !a_out || ldf < in_channels) return NBD_E_BADARG;
-  const size_t shmem = (size_t)filter_resolution * filter_resolution * 64 * sizeof(float) + kGeoCache * sizeof(EdgeGeo);
-  if (shmem > 64 * 1024) return NBD_E_UNSUPPORTED;       // D <= 15
-  dim3 grid(n, ceil_div(in_channels, 64));
-  contconv_bin_kernel<<<grid, 64, shmem, (hipStream_t)stream>>>(pos, feat, ldf, in_channels, rowptr, centres,
-                                                                node_begin, filter_resolution, radius_sq, a_out);
+  // two channels per lane (8-byte accesses) when the layout allows it: even I, even ldf, 8-byte aligned bases
+  const bool cpl2 = in_channels % 2 == 0 && ldf % 2 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(a_out)) & 7) == 0;
+  const int cpl = cpl2 ? 2 : 1;
+  const size_t shmem = (size_t)filter_resolution * filter_resolution * 64 * cpl * sizeof(float) + kGeoCache * sizeof(EdgeGeo);
+  if (shmem > 64 * 1024) return NBD_E_UNSUPPORTED;       // D <= 10
+  dim3 grid(n, ceil_div(in_channels, 64 * cpl));
+  hipStream_t st = (hipStream_t)stream;
+  if (cpl2)
+    contconv_bin_kernel<2><<<grid, 64, shmem, st>>>(pos, feat, ldf, in_channels, rowptr, centres, node_begin,
+                                                    filter_resolution, radius_sq, a_out);
+  else
+    contconv_bin_kernel<1><<<grid, 64, shmem, st>>>(pos, feat, ldf, in_channels, rowptr, centres, node_begin,
+                                                    filter_resolution, radius_sq, a_out);
   return status();
 }
 
