@@ -72,9 +72,11 @@ class Trainer:
             torch.cuda.synchronize()
             return None
 
-        def advance():
+        def advance(clone=True):
+            """One captured step. clone=False hands back the graph's own state buffers: valid only until
+            the next call (evaluate_rollout copies them into its table right away)."""
             graph.replay()
-            return s_pos.clone(), s_vel.clone(), s_acc.clone()
+            return (s_pos.clone(), s_vel.clone(), s_acc.clone()) if clone else (s_pos, s_vel, s_acc)
         return advance
 
     # ------------------------------------------------------------------ trainer.py:228-344
@@ -99,7 +101,7 @@ class Trainer:
         graphed = self._capture_step(pos, vel, m, pred_accs, dt) if (self.use_hip_graph and sim_steps > 4) else None
         for step in range(1, sim_steps):
             if graphed is not None:
-                (pos, vel, pred_accs), ev = timed(graphed)
+                (pos, vel, pred_accs), ev = timed(lambda: graphed(clone=False))
             else:
                 (pos, vel, pred_accs), ev = timed(lambda: self.step(pos, vel, m, pred_accs, dt))
             events.append(ev)
