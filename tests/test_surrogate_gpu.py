@@ -284,23 +284,23 @@ def test_test_from_dir_on_a_generated_csv(tmp_path, gpu_device):
     written from the HIP integrator -> datautils -> Trainer.test_from_dir -> the reference's two
     result frames (trainer.py:197-200)."""
     import csv
+    import importlib.util
     import gnn
     import trainer
-    from galaxify import simulation
-    from nbd.plummer import generate_plummer
+    from conftest import PKG
     steps, dt = 5, 0.01
     path = tmp_path / "data"
     path.mkdir()
-    with open(path / "output_file_1.csv", "w", newline="") as f:
-        wr = csv.writer(f)
-        wr.writerow(["scene", "scene_type", "step", "step_time", "mass", "x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az", "u", "k"])
-        for scene, n in enumerate((20, 33)):
-            p, v, m = generate_plummer(n, seed=scene)
-            sim = simulation.LeapFrogSimulator(positions=p, velocities=v, masses=m, dt=dt, device="cuda")
-            for st in sim.run(steps):
-                for i in range(n):
-                    wr.writerow([scene, "plummer", st.step, st.step_time, m[i], *st.positions[i].tolist(),
-                                 *st.velocities[i].tolist(), *st.accelerations[i].tolist(), st.u_energy, st.k_energy])
+    spec = importlib.util.spec_from_file_location("s01", f"{PKG}/s01-dataset-generation.py")
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    out_csv = str(path / "output_file_1.csv")
+    cli.main(["--integrator", "leapfrog", "--n-bodies", "20", "33", "--sim-type", "spiral", "--steps", str(steps),
+              "--dt", str(dt), "--g", "1.0", "--softening", "0.1", "--seed", "3", "--output", out_csv, "--device", "cuda"])
+    rows = list(csv.DictReader(open(out_csv, newline="")))
+    assert list(rows[0].keys()) == cli.FIELDNAMES and len(rows) == (20 + 33) * steps
+    assert {r["scene"] for r in rows} == {"0", "1"} and rows[0]["scene_type"] == "spiral" and rows[0]["step"] == "0"
+    assert float(rows[0]["mass"]) == pytest.approx(0.01) and abs(float(rows[0]["x"])) < 1e-3   # body 0 = central black hole
     torch.manual_seed(0)
     model = gnn.GraphModel(input_dim=4, gnn_dim=16, message_passing_steps=2, aggr="mean", neighbors=4, device="cuda")
     tr = trainer.Trainer(model, optimizer=None, device="cuda", dt=dt)
