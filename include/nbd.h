@@ -183,6 +183,15 @@ size_t nbd_linear_workspace_bytes(int n_rows, int n_cols, int k);
 int nbd_edgeconv_aggregate_f32(const float* pq, int ldpq, int h, const int* rowptr, const int64_t* src,
                                int fixed_k, int n, int aggr, float* s, int lds, nbd_stream_t stream);
 
+/* EdgeConv with aggr = "max" (PyG's own default; gnn.py:79-93 passes the user's aggr through): the
+ * second Linear cannot be hoisted out of a max, so messages are materialised per edge,
+ * m[e] = tanh(P_tgt[e] + Q_src[e]) (edges grouped by target), nbd_linear_f32 runs over the E rows and
+ * nbd_segment_reduce_f32 reduces each target's rows (mode 0 = sum, 1 = mean, 2 = max; empty -> 0). */
+int nbd_edge_messages_f32(const float* pq, int ldpq, int h, const int64_t* src, const int64_t* tgt, int64_t n_edges,
+                          float* m, int ldm, nbd_stream_t stream);
+int nbd_segment_reduce_f32(const float* m, int ldm, int h, const int* rowptr, int n, int mode, float* out, int ldo,
+                           nbd_stream_t stream);
+
 /* torch.nn.LayerNorm over the last dim (gnn.py:146, contconv.py:233); gamma/beta may be NULL. */
 int nbd_layernorm_f32(const float* x, int ldx, int c, const float* gamma, const float* beta, float eps, float* y,
                       int ldy, int n, nbd_stream_t stream);

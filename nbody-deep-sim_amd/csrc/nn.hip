@@ -285,6 +285,41 @@ __global__ __launch_bounds__(256) void edgeconv_aggregate_kernel(
   }
 }
 
+// EdgeConv with a NON-linear aggregation (max) cannot hoist the second Linear out of the edge sum, so
+// the messages are materialised: m_e = tanh(P_i + Q_j) per edge (rows grouped by target), the second
+// Linear runs over the E rows (nbd_linear_f32), and the rows of each target are reduced.
+__global__ __launch_bounds__(256) void edge_messages_kernel(const float* __restrict__ PQ, int ldpq, int H,
+                                                            const int64_t* __restrict__ src,
+                                                            const int64_t* __restrict__ tgt, int64_t n_edges,
+                                                            float* __restrict__ M, int ldm) {
+  const int64_t e = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (e >= n_edges) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = tgt[e], j = src[e];
+  for (int h = lane; h < H; h += 64)
+    M[(size_t)e * ldm + h] = tanhf(__fadd_rn(PQ[(size_t)i * ldpq + h], PQ[(size_t)j * ldpq + H + h]));
+}
+
+// out[i] = reduce over rows rowptr[i] .. rowptr[i+1] of M (0 = sum, 1 = mean, 2 = max; empty -> 0)
+__global__ __launch_bounds__(256) void segment_reduce_kernel(const float* __restrict__ M, int ldm, int H,
+                                                             const int* __restrict__ rowptr, int n, int mode,
+                                                             float* __restrict__ out, int ldo) {
+  const int i = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int e0 = rowptr[i], e1 = rowptr[i + 1];
+  for (int h = lane; h < H; h += 64) {
+    float acc = mode == 2 ? -__builtin_inff() : 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const float v = M[(size_t)e * ldm + h];
+      acc = mode == 2 ? fmaxf(acc, v) : acc + v;
+    }
+    if (mode == 1) acc = acc / (float)max(e1 - e0, 1);
+    if (e1 == e0) acc = 0.f;
+    out[(size_t)i * ldo + h] = acc;
+  }
+}
+
 // ------------------------------------------------------------------ LayerNorm (one wave per row)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ X, int ldx, int C,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -513,6 +548,25 @@ int nbd_edgeconv_aggregate_f32(const float* pq, int ldpq, int h, const int* rowp
   if (!src && (rowptr || fixed_k > 0)) return NBD_E_BADARG;
   edgeconv_aggregate_kernel<<<ceil_div(n, 4), 256, 0, (hipStream_t)stream>>>(pq, ldpq, h, rowptr, src, fixed_k, n,
                                                                             aggr, s, lds);
+  return status();
+}
+
+int nbd_edge_messages_f32(const float* pq, int ldpq, int h, const int64_t* src, const int64_t* tgt, int64_t n_edges,
+                          float* m, int ldm, nbd_stream_t stream) {
+  if (n_edges < 0 || h <= 0) return NBD_E_BADARG;
+  if (n_edges == 0) return 0;
+  if (!pq || !src || !tgt || !m || ldpq < 2 * h || ldm < h) return NBD_E_BADARG;
+  if (n_edges > 0x7fffffffLL * 4) return NBD_E_UNSUPPORTED;
+  edge_messages_kernel<<<(unsigned)((n_edges + 3) / 4), 256, 0, (hipStream_t)stream>>>(pq, ldpq, h, src, tgt, n_edges, m, ldm);
+  return status();
+}
+
+int nbd_segment_reduce_f32(const float* m, int ldm, int h, const int* rowptr, int n, int mode, float* out, int ldo,
+                           nbd_stream_t stream) {
+  if (n < 0 || h <= 0 || mode < 0 || mode > 2) return NBD_E_BADARG;
+  if (n == 0) return 0;
+  if (!rowptr || !out || ldo < h || (!m && ldm != 0) || ldm < h) return NBD_E_BADARG;
+  segment_reduce_kernel<<<ceil_div(n, 4), 256, 0, (hipStream_t)stream>>>(m, ldm, h, rowptr, n, mode, out, ldo);
   return status();
 }
 

@@ -121,9 +121,9 @@ class GraphModel(torch.nn.Module):
         self.gnn_dim = gnn_dim
         self.encoder_dropout = encoder_dropout
         self.scale_factor = scale_factor
-        if aggr not in ("sum", "add", "mean"):
-            raise NotImplementedError(f"aggr={aggr!r}: this build factors EdgeConv's second Linear through the "
-                                      "aggregation, which needs a linear aggregation (sum/add/mean)")
+        if aggr not in ("sum", "add", "mean", "max"):
+            raise NotImplementedError(f"aggr={aggr!r}: supported aggregations are sum/add/mean (second Linear "
+                                      "hoisted out of the edge sum) and max (per-edge messages materialised)")
         if node_encoder_dims:                                                     # gnn.py:56-65
             self.node_encoder = MLP([input_dim] + list(node_encoder_dims) + [gnn_dim], norm=None,
                                     dropout=encoder_dropout)
@@ -208,6 +208,8 @@ class GraphModel(torch.nn.Module):
             brs = torch.full((n,), val, dtype=torch.float32, device=x7.device)
         else:
             brs = nnops.degree_scale(rowptr, n, brs_mode, x7.device)
+        if self.aggr == "max":
+            return self._forward_max(w, enc_view, gnn_view, cat_buf, n, h, rowptr, src, fixed_k, ei)
         aggr = "mean" if self.aggr == "mean" else "sum"
         if self.use_fused and self._forward_fused(w, enc_view, n, h, rowptr, src, fixed_k, aggr, cat_buf):
             return self._fused_out
@@ -217,6 +219,27 @@ class GraphModel(torch.nn.Module):
             s = nnops.edgeconv_aggregate(pq, h, rowptr, src, fixed_k, aggr)
             last = li == len(w["layers"]) - 1
             x = nnops.linear(s, w2, b2, bias_rowscale=brs, out=gnn_view if last else None)
+        ln = nnops.layernorm(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
+                             self.layer_norm.eps)
+        return run_chain(ln, w["head"])
+
+    def _forward_max(self, w, enc_view, gnn_view, cat_buf, n, h, rowptr, src, fixed_k, ei):
+        """aggr="max": x_i' = max_j (W2 tanh(P_i + Q_j) + b2); nodes without edges get 0 (PyG fills empty
+        max-aggregations with 0)."""
+        dev = enc_view.device
+        if rowptr is None:
+            rowptr = torch.arange(0, (n + 1) * fixed_k, max(fixed_k, 1), dtype=torch.int32, device=dev)[:n + 1] \
+                if fixed_k > 0 else torch.zeros(n + 1, dtype=torch.int32, device=dev)
+            tgt = torch.arange(n, device=dev, dtype=torch.int64).repeat_interleave(max(fixed_k, 0))
+        else:
+            tgt = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64),
+                                          (rowptr[1:] - rowptr[:-1]).to(torch.int64))
+        x = enc_view
+        for li, (wpq, bpq, w2, b2) in enumerate(w["layers"]):
+            pq = nnops.linear(x, wpq, bpq)
+            msg = nnops.linear(nnops.edge_messages(pq, h, src, tgt), w2, b2)
+            last = li == len(w["layers"]) - 1
+            x = nnops.segment_reduce(msg, rowptr, n, "max", out=gnn_view if last else None)
         ln = nnops.layernorm(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
                              self.layer_norm.eps)
         return run_chain(ln, w["head"])

@@ -94,6 +94,8 @@ SIGNATURES = {
     "nbd_linear_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "nbd_edgeconv_aggregate_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_void_p, c_int, c_void_p]),
+    "nbd_edge_messages_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
+    "nbd_segment_reduce_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "nbd_layernorm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
                                   c_void_p]),
     "nbd_contconv_bin_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,

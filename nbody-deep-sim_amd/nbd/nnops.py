@@ -71,6 +71,32 @@ def edgeconv_aggregate(pq, h, rowptr, src, fixed_k, aggr, out=None):
     return out
 
 
+def edge_messages(pq, h, src, tgt):
+    """(E, h) rows tanh(P_tgt + Q_src) for edges already grouped by target."""
+    e = src.numel()
+    ld = _mat(pq, "pq")
+    m = torch.empty((e, h), dtype=torch.float32, device=pq.device)
+    for t in (src, tgt):
+        if t.dtype != torch.int64 or not t.is_contiguous() or t.numel() != e:
+            raise _lib.NbdError("src/tgt must be contiguous int64 of equal length")
+    with torch.cuda.device(pq.device):
+        _lib.check(_lib.lib().nbd_edge_messages_f32(pq.data_ptr(), ld, h, src.data_ptr(), tgt.data_ptr(), e,
+                                                    m.data_ptr(), h, _lib.current_stream(pq.device)),
+                   "nbd_edge_messages_f32")
+    return m
+
+
+def segment_reduce(m, rowptr, n, mode, out=None):
+    h = m.shape[1]
+    if out is None:
+        out = torch.empty((n, h), dtype=torch.float32, device=m.device)
+    with torch.cuda.device(m.device):
+        _lib.check(_lib.lib().nbd_segment_reduce_f32(m.data_ptr(), _mat(m, "m") if m.shape[0] else h, h,
+                                                     rowptr.data_ptr(), n, AGGR[mode], out.data_ptr(), _mat(out, "out"),
+                                                     _lib.current_stream(m.device)), "nbd_segment_reduce_f32")
+    return out
+
+
 def layernorm(x, gamma, beta, eps, out=None):
     n, c = x.shape
     ldx = _mat(x, "x")

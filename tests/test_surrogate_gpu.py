@@ -139,6 +139,7 @@ def _copy_state(dst, src):
     dict(input_dim=7, gnn_dim=48, message_passing_steps=1, aggr="mean", neighbors=8, node_encoder_dims=[20, 24]),
     dict(input_dim=7, gnn_dim=128, message_passing_steps=2, aggr="sum", neighbors=6),       # H = 128: general path only
     dict(input_dim=4, gnn_dim=100, message_passing_steps=1, aggr="mean", neighbors=70, output_dim=5),
+    dict(input_dim=4, gnn_dim=40, message_passing_steps=2, aggr="max", neighbors=9),          # PyG EdgeConv's own default
 ])
 def test_gnn_forward_matches_oracle(cfg, gpu_device):
     import gnn
@@ -239,6 +240,17 @@ def test_contconv_model_matches_oracle(gpu_device):
     assert global_rel(model2.predict(pos.cuda(), feat.cuda()).cpu(), ora2.predict(pos, feat)) < TOL
     with pytest.raises(AttributeError):
         contconv.ContinuousConvModel(filter_resolution=4)
+    # a batch of three graphs (eval_graph_batch path: radius search restricted to batch segments)
+    from nbd.data import Data
+    b = _batch(600, [250, 1, 349])
+    x7 = torch.cat([pos, feat], 1)
+    with torch.no_grad():
+        ref_b = ora.forward_x(x7, batch=b)
+    got_b = model.forward(Data(x=x7.cuda(), batch=b.cuda())).cpu()
+    assert global_rel(got_b, ref_b) < TOL
+    y = torch.randn(600, 3)
+    rmse, mse, secs = model.eval_graph_batch(Data(x=x7.cuda(), batch=b.cuda(), y=y.cuda()))
+    assert mse == pytest.approx(torch.nn.functional.mse_loss(ref_b, y).item(), rel=1e-4) and rmse == pytest.approx(mse ** 0.5, rel=1e-5) and secs > 0
 
 
 # ------------------------------------------------------------------ Trainer

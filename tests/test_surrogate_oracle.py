@@ -173,7 +173,7 @@ def test_state_dicts_are_interchangeable_with_reference_layout():
     assert c.contconv[0].filters.shape == (6, 6, 6, 128, 128) and c.contconv[1].filters.shape == (4, 4, 4, 128, 128)
     assert c.layer_norm.normalized_shape == (256,) and c.neighbors == 0
     with pytest.raises(NotImplementedError):
-        gnn.GraphModel(aggr="max")
+        gnn.GraphModel(aggr="min")
     with pytest.raises(NotImplementedError):
         g.compute_loss(None)
 
