@@ -193,7 +193,8 @@ def test_gnn_predict_uses_k50_like_reference(gpu_device):
 
 
 # ------------------------------------------------------------------ ContinuousConv
-@pytest.mark.parametrize("agg,D,I,O", [("mean", 4, 8, 16), ("sum", 6, 4, 8), ("mean", 3, 70, 40)])
+@pytest.mark.parametrize("agg,D,I,O", [("mean", 4, 8, 16), ("sum", 6, 4, 8), ("mean", 3, 70, 40),
+                                       ("mean", 4, 32, 128), ("sum", 3, 64, 96), ("mean", 5, 128, 130), ("mean", 2, 96, 20)])
 def test_contconv_layer_matches_oracle(agg, D, I, O, gpu_device):
     """One ContinuousConv layer vs the oracle, which calls F.grid_sample exactly as contconv.py:73-75."""
     import contconv
@@ -208,7 +209,12 @@ def test_contconv_layer_matches_oracle(agg, D, I, O, gpu_device):
     with torch.no_grad():
         ref = ora(pos, feat, ei)
         got = layer(pos.cuda(), feat.cuda(), edge_index=ei.cuda()).cpu()
-    assert global_rel(got, ref) < TOL and row_rel(got, ref) < 10 * TOL
+        assert global_rel(got, ref) < TOL and row_rel(got, ref) < 10 * TOL
+        # uncapped dense graph: in-degree up to 150, many pairs per (node, filter cell)
+        ei_d = so.radius_graph(pos[:150], 3.0, loop=True, max_num_neighbors=150)
+        ref_d = ora(pos[:150], feat[:150], ei_d)
+        got_d = layer(pos[:150].cuda(), feat[:150].contiguous().cuda(), edge_index=ei_d.cuda()).cpu()
+        assert global_rel(got_d, ref_d) < TOL
 
 
 def test_contconv_model_matches_oracle(gpu_device):
