@@ -176,7 +176,11 @@ class BaseSimulator:
                 e1.record()
                 events.append((e0, e1))
                 if self.calc_energy:
-                    if self.part.world_size == 1:  # posm already holds the post-drift positions
+                    if self.part.world_size == 1:
+                        # energies of the state AFTER the step (simulation.py:131-133). The leapfrog step
+                        # leaves posm = current positions; the Euler step packs before its drift, so repack.
+                        if not isinstance(self, LeapFrogSimulator):
+                            direct.pack_posm(self.positions, self.masses, out=self._posm)
                         direct.energy(self._posm, self.velocities, self.n, direct.f32(self.softening),
                                       self._g, out_uk=uk_dev[s])
                     else:

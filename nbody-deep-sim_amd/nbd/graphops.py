@@ -38,7 +38,10 @@ def _segments(batch: torch.Tensor | None, n: int, device):
 def knn_graph(x: torch.Tensor, k: int, batch: torch.Tensor | None = None, loop: bool = False) -> torch.Tensor:
     """int64 edge_index [2, E]: per centre i its k nearest j (ascending (d2, j)); row 0 = j, row 1 = i."""
     n = x.shape[0]
-    pos = x[:, :3].contiguous() if x.shape[1] != 3 else x
+    if x.dim() != 2 or x.shape[1] != 3:
+        raise _lib.NbdError(f"knn_graph: this build searches 3-D positions (n,3) as the reference does "
+                            f"(gnn.py:13), got {tuple(x.shape)}")
+    pos = x.contiguous()
     _chk(pos, (n, 3), "x")
     dev = pos.device
     lo, hi = _segments(batch, n, dev)

@@ -304,3 +304,19 @@ def test_full_size_all_rows_against_c_oracle_f64(gpu_device):
     v1 = vh + 0.005 * a1
     sim.step()
     assert row_rel(_np(sim.positions), x1) < TOL and row_rel(_np(sim.velocities), v1) < TOL
+
+
+def test_euler_run_reports_post_step_energies(gpu_device):
+    """run() must report U, K of the state AFTER each step for every integrator (simulation.py:131-133);
+    the Euler step packs its sources before the drift, so the energy pass has to repack."""
+    from oracle import galaxify_oracle as go
+    g = load_golden("direct_plummer_n64")
+    for cls, adv in (("EulerSimulator", "euler_step"), ("LeapFrogSimulator", "leapfrog_step")):
+        states = _mk(cls, g).run(3)
+        ora = go.OracleSimulator(positions=g["pos"], velocities=g["vel"], masses=g["mass"], g_const=float(g["g_const"]),
+                                 softening=float(g["softening"]), dt=float(g["dt"]))
+        for st in states:
+            getattr(ora, adv)()
+            u, k = ora.compute_energies()
+            assert abs(st.u_energy - u) <= 2e-5 * abs(u) and abs(st.k_energy - k) <= 2e-6 * abs(k), cls
+            assert row_rel(st.positions.numpy(), ora.positions.numpy()) < TOL
