@@ -172,12 +172,17 @@ def main():
             "launch_plan": plan,
         },
         "roofline": {
-            "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            # compute roofline ("mfma" in the harness's two-way hbm|mfma taxonomy): the kernel itself is fp32
+            # VALU -- all-pairs gravity has no dense contraction for MFMA -- and on MI355X the fp32 vector
+            # peak and the fp32 MFMA peak are the same 157.3 TFLOP/s, so the fraction is unambiguous
+            "bound": "mfma", "compute_unit": "fp32 VALU (v_pk_fma_f32 / v_rsq_f32), no MFMA instructions",
+            "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
             "kernel": "accel_kernel<false>", "kernel_ms": k_ms, "flop_per_pair": FLOP_PER_PAIR,
             "pairs_per_launch": pairs_per_launch,
-            "note": "fp32 VALU-issue bound (no dense contraction: MFMA not applicable); peak = fp32 vector "
-                    "peak = fp32 MFMA peak. Issue ceiling is 2 pairs/clk/SIMD = 62% of this peak at 2.4 GHz",
+            "note": "compute-bound on fp32 VALU issue (no dense contraction: MFMA not applicable); peak = fp32 "
+                    "vector peak = fp32 MFMA peak. 20 flop/pair accounting; the instruction stream's own ceiling "
+                    "is 2 pairs/clk/SIMD = 62% of this peak at 2.4 GHz",
         },
     }
     if args.cpu_seconds > 0 and world == 1:

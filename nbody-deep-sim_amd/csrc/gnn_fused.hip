@@ -28,6 +28,7 @@ constexpr int kFMax = 8;        // on-the-fly P/Q: input features, zero padded
 constexpr int kMaxR = 2;        // channels per lane: H <= 128
 constexpr int kMaxZR = 4;       // concat width per lane: E + H <= 256
 constexpr int kMaxOut = 8;
+constexpr int kEF = 8;          // edges (neighbour rows) in flight per wave
 
 __device__ __forceinline__ float lane_bcast(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
@@ -121,38 +122,39 @@ __global__ __launch_bounds__(256) void gnn_layer_kernel(const nbd_gnn_layer_args
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) s[r] = 0.f;
-    // edges in chunks of 64: one coalesced index load, then wave-uniform j's, four edges in flight
+    // edges in chunks of 64: one coalesced index load, then wave-uniform j's, kEF neighbour rows in flight
+    // (the loop is a chain of L2 round trips at 2 waves/SIMD: depth is what hides them)
     for (int eb = e0; eb < e1; eb += 64) {
       const int cnt = min(64, e1 - eb);
       const int jv = lane < cnt ? (int)a.src[eb + lane] : 0;
-      for (int t = 0; t < cnt; t += 4) {
-        int j[4];
+      for (int t = 0; t < cnt; t += kEF) {
+        int j[kEF];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) j[u] = __builtin_amdgcn_readlane(jv, min(t + u, cnt - 1));
+        for (int u = 0; u < kEF; ++u) j[u] = __builtin_amdgcn_readlane(jv, min(t + u, cnt - 1));
         if (a.pq) {
-          float q[4][R];
+          float q[kEF][R];
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < kEF; ++u)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
               const int h = r * 64 + lane;
               q[u][r] = h < H ? a.pq[(size_t)j[u] * a.ldpq + H + h] : 0.f;
             }
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < kEF; ++u)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
               const float v = fast_tanh(__fadd_rn(p[r], q[u][r]));
               s[r] += (t + u < cnt) ? v : 0.f;
             }
         } else {
-          float xj[4][kFMax];
+          float xj[kEF][kFMax];
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < kEF; ++u)
 #pragma unroll
             for (int f = 0; f < kFMax; ++f) xj[u][f] = f < a.f ? a.x[(size_t)j[u] * a.ldx + f] : 0.f;
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < kEF; ++u)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
               float q = 0.f;
