@@ -58,13 +58,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_kernel(
 
   // candidate positions are prefetched one chunk ahead: the ballot/insert chain of chunk c hides the
   // L2 latency of chunk c+1 (the kernel is latency-bound: one wave per centre, 64 chunks at N = 4096)
-  float nx = 0.f, ny = 0.f, nz = 0.f;
-  if (lo + lane < hi) { nx = pos[3 * (lo + lane)]; ny = pos[3 * (lo + lane) + 1]; nz = pos[3 * (lo + lane) + 2]; }
+  // (loads are unconditional with a clamped index: a predicated load makes hipcc wait for it on the spot)
+  const int j_first = min(lo + lane, hi - 1);
+  float nx = pos[3 * j_first], ny = pos[3 * j_first + 1], nz = pos[3 * j_first + 2];
   for (int c0 = lo; c0 < hi; c0 += 64) {
     const int j = c0 + lane;
     const float cx = nx, cy = ny, cz = nz;
-    const int jn_ = j + 64;
-    if (jn_ < hi) { nx = pos[3 * jn_]; ny = pos[3 * jn_ + 1]; nz = pos[3 * jn_ + 2]; }
+    const int jn_ = min(j + 64, hi - 1);
+    nx = pos[3 * jn_]; ny = pos[3 * jn_ + 1]; nz = pos[3 * jn_ + 2];
     float d = __builtin_inff();
     if (j < hi && (loop || j != i)) {
       const float dx = cx - xi, dy = cy - yi, dz = cz - zi;
