@@ -356,3 +356,40 @@ def test_hipgraph_rollout_step_equals_eager(kind, gpu_device):
         p, v, a = tr.step(p, v, m1, a, 0.01)
         gp, gv, ga = adv()
         assert torch.equal(gp, p) and torch.equal(gv, v) and torch.equal(ga, a), (kind, i)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 65])
+def test_tiny_systems_match_oracle(n, gpu_device):
+    """Degenerate sizes: a lone body has no kNN edges (EdgeConv -> 0, the head still sees LayerNorm of
+    [x || 0]) and only its self-loop in the radius graph; k larger than n-1; fewer bodies than a wave."""
+    import contconv
+    import gnn
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(n)
+    pos, vel, m = _plummer_pos(max(n, 2), 30 + n)
+    pos, vel, m = pos[:n].contiguous(), vel[:n].contiguous(), m[:n].contiguous()
+    feat = torch.cat([vel, m[:, None]], 1)
+    ora = so.GraphModelOracle(input_dim=4, gnn_dim=16, message_passing_steps=2, aggr="mean", neighbors=3).eval()
+    model = gnn.GraphModel(input_dim=4, gnn_dim=16, message_passing_steps=2, aggr="mean", neighbors=3, device="cuda")
+    _copy_state(model, ora)
+    for fused in (True, False):
+        model.use_fused = fused
+        got = model.predict(pos.cuda(), feat.cuda()).cpu()
+        ref = ora.predict(pos, feat, k=50)
+        assert got.shape == (n, 3) and torch.isfinite(got).all()
+        assert (got - ref).abs().max() < 2e-5 * max(ref.abs().max().item(), 1.0), fused
+    cfg = dict(in_channels=4, out_channels=3, filter_resolution=[3], radius=1.0, agg="mean", self_loops=True,
+               continuous_conv_layers=1, continuous_conv_dim=8, encoder_hiddens=[6], decoder_hiddens=[5])
+    ora_c = so.ContinuousConvModelOracle(**cfg).eval()
+    mod_c = contconv.ContinuousConvModel(device="cuda", **cfg)
+    _copy_state(mod_c, ora_c)
+    got = mod_c.predict(pos.cuda(), feat.cuda()).cpu()
+    ref = ora_c.predict(pos, feat)
+    assert got.shape == (n, 3) and (got - ref).abs().max() < 2e-5 * max(ref.abs().max().item(), 1.0)
+    # no self loops: an isolated body aggregates nothing (scatter mean of an empty set = 0)
+    cfg["self_loops"] = False
+    ora_n = so.ContinuousConvModelOracle(**cfg).eval()
+    mod_n = contconv.ContinuousConvModel(device="cuda", **cfg)
+    _copy_state(mod_n, ora_n)
+    far = pos * 100.0
+    assert (mod_n.predict(far.cuda(), feat.cuda()).cpu() - ora_n.predict(far, feat)).abs().max() < 2e-5
