@@ -70,6 +70,47 @@ def rollout_mse_vs_direct(model, n, k, steps, dt=0.01, seed=1234):
             "acc_mse": ((acc - sim.accelerations) ** 2).mean().item(), "weights": "random init (seed 0)"}
 
 
+def rollout_with_trained_gnn(n=500, steps=200, seed=777):
+    """Rollout of the briefly-trained GNN fixture (tests/golden/gnn_small_trained.pt, published shape) on a
+    held-out spiral galaxy with the reference's test settings (N = 500, G = 4.5e-6, softening 0.05,
+    dt = 1e-4; gnn_experiment.py:24-49,74-78) against the direct-force HIP integrator: true per-step MSE and
+    the reference's own statistic (trainer.py:179-195) at the last step."""
+    import pandas as pd
+    from galaxify import galaxies, simulation
+    from nbd.data import Data
+    path = os.path.join(ROOT, "tests", "golden", "gnn_small_trained.pt")
+    if not os.path.exists(path):
+        return None
+    model = gnn.GraphModel(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", device="cuda", neighbors=10,
+                           scale_factor=1e6)
+    model.load_state_dict(torch.load(path, map_location="cuda"))
+    p, v, m = galaxies.generate_spiral(n_bodies=n, total_mass=1.0, radial_scale=3.0, height_scale=0.3, g_const=4.5e-6,
+                                       black_hole_mass=0.01, seed=seed)
+    sim = simulation.LeapFrogSimulator(positions=p, velocities=v, masses=m, g_const=4.5e-6, softening=0.05, dt=1e-4,
+                                       calc_energy=False, device="cuda")
+    m1 = sim.masses[:, None]
+    xs, ys, st = [], [], []
+    for s in range(steps):                       # ground truth: states after each direct-force step
+        sim.step()
+        xs.append(torch.cat([sim.positions, sim.velocities, m1], 1)); ys.append(sim.accelerations.clone())
+        st.append(torch.full((n,), s, device="cuda"))
+    data = Data(x=torch.cat(xs), y=torch.cat(ys), step=torch.cat(st))
+    tr = trainer.Trainer(model, None, device="cuda", dt=1e-4)
+    df = tr.evaluate_rollout("held_out.csv", data, 0, steps, 1e-4, pd.DataFrame(columns=trainer.ROLLOUT_COLUMNS))
+    mse = trainer.rollout_mse(df).iloc[-1]
+    last = df[df["step"] == steps - 1]
+    ref_stat = {}
+    for name, trio in (("pos", ["x", "y", "z"]), ("vel", ["vx", "vy", "vz"]), ("acc", ["ax", "ay", "az"])):
+        mean_err = [(last[c].astype(float) - last[f"pred_{c}"].astype(float)).mean() for c in trio]
+        ref_stat[name] = float(np.sqrt(np.mean(np.square(mean_err))))
+    acc_rms = float(torch.cat(ys).pow(2).mean().sqrt())
+    return {"n": n, "steps": steps, "weights": "tests/golden/gnn_small_trained.pt (minutes of CPU training)",
+            "true_mse_last_step": {"pos": float(mse["pos_mse"]), "vel": float(mse["vel_mse"]), "acc": float(mse["acc_mse"])},
+            "reference_statistic_last_step": ref_stat, "ground_truth_acc_rms": acc_rms,
+            "mean_step_time_ms": float(df.groupby("step")["step_time"].first().iloc[1:].mean() * 1e3),
+            "reference_published_at_step_999": {"pos": 1.24e-12, "vel": 5.37e-10, "acc": 1.63e-8}}
+
+
 def run(iters=20):
     out = {}
     torch.manual_seed(0)
@@ -128,6 +169,8 @@ def run(iters=20):
                               "edges_capped": int(lists.rowptr[-1]), "max_in_degree": int((lists.rowptr[1:] - lists.rowptr[:-1]).max())}
     _trace("radius lists timed")
     out["gnn_n4096_rollout_mse_vs_direct"] = rollout_mse_vs_direct(model, 4096, None, 10)
+    _trace("random-weight rollout done")
+    out["gnn_trained_rollout_n500"] = rollout_with_trained_gnn()
     return out
 
 
