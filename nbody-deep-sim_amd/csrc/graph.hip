@@ -12,6 +12,7 @@
 // and no atomics, and results are bit-reproducible.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/nbd.h"
 
@@ -37,17 +38,9 @@ __device__ __forceinline__ float shift_up1(float v, float lane0) {
 
 // ---- kNN: the wave keeps the current best 64*R (d2, j) pairs sorted across lanes (rank = r*64+lane).
 template <int R>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void knn_kernel(
-    const float* __restrict__ pos, int n, int k, int loop, const int* __restrict__ seg_lo,
-    const int* __restrict__ seg_hi, const int64_t* __restrict__ out_off, int64_t e_total,
-    int64_t* __restrict__ edge_index) {
-  const int i = blockIdx.x * kWavesPerBlock + wave_id();
-  if (i >= n) return;
+__device__ __forceinline__ void knn_insert_centre(const float* __restrict__ pos, int i, int lo, int hi, int kk, int loop,
+                                                  int64_t base, int64_t e_total, int64_t* __restrict__ edge_index) {
   const int lane = threadIdx.x & 63;
-  const int lo = seg_lo ? seg_lo[i] : 0, hi = seg_hi ? seg_hi[i] : n;
-  const int avail = (hi - lo) - (loop ? 0 : 1);
-  const int kk = min(k, avail);
-  if (kk <= 0) return;
   const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
   float bd[R];
   int bj[R];
@@ -102,13 +95,143 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_kernel(
       thr = t;
     }
   }
-  const int64_t base = out_off ? out_off[i] : (int64_t)i * kk;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int rank = r * 64 + lane;
     if (rank < kk) {
       edge_index[base + rank] = bj[r];             // row 0: neighbour j (source)
       edge_index[e_total + base + rank] = i;       // row 1: centre i (target)
+    }
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void knn_kernel(
+    const float* __restrict__ pos, int n, int k, int loop, const int* __restrict__ seg_lo,
+    const int* __restrict__ seg_hi, const int64_t* __restrict__ out_off, int64_t e_total,
+    int64_t* __restrict__ edge_index) {
+  const int i = blockIdx.x * kWavesPerBlock + wave_id();
+  if (i >= n) return;
+  const int lo = seg_lo ? seg_lo[i] : 0, hi = seg_hi ? seg_hi[i] : n;
+  const int kk = min(k, (hi - lo) - (loop ? 0 : 1));
+  if (kk <= 0) return;
+  knn_insert_centre<R>(pos, i, lo, hi, kk, loop, out_off ? out_off[i] : (int64_t)i * kk, e_total, edge_index);
+}
+
+// ---- kNN, selection form (the default for k <= 200): the insertion kernel above is a chain of ~k ln(N/k)
+// dependent wave-wide inserts; this one has no serial chain.
+//   A  every lane keeps the R smallest d2 of ITS candidates (lane-strided scan, loads pipelined);
+//      the kk-th smallest of those 64*R values bounds the kk-th neighbour distance from above (they are
+//      64*R distinct candidates), found by a rank count over readlane broadcasts;
+//   B  second scan: candidates with d2 <= bound are compacted (ballot prefix) into a per-wave LDS list --
+//      a few tens of entries;
+//   C  every listed candidate counts how many listed ones precede it in (d2, j) order and, if that rank
+//      is < kk, writes its edge directly to slot `rank`.
+// Same ordering rule, so the output is identical to the insertion kernel's (tested); if the list
+// overflows (only possible with hundreds of exactly tied distances) the wave falls back to the
+// insertion form for that centre.
+constexpr int kSelCap = 512;     // LDS list entries per wave
+
+template <int R, int RI>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void knn_select_kernel(
+    const float* __restrict__ pos, int n, int k, int loop, const int* __restrict__ seg_lo,
+    const int* __restrict__ seg_hi, const int64_t* __restrict__ out_off, int64_t e_total,
+    int64_t* __restrict__ edge_index) {
+  __shared__ float ld[kWavesPerBlock][kSelCap];
+  __shared__ int lj[kWavesPerBlock][kSelCap];
+  const int w = wave_id();
+  const int i = blockIdx.x * kWavesPerBlock + w;
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int lo = seg_lo ? seg_lo[i] : 0, hi = seg_hi ? seg_hi[i] : n;
+  const int kk = min(k, (hi - lo) - (loop ? 0 : 1));
+  if (kk <= 0) return;
+  const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+  const float inf = __builtin_inff();
+
+  // A: per-lane R smallest (sorted ascending in m[0..R-1])
+  float m[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) m[r] = inf;
+  for (int c0 = lo; c0 < hi; c0 += 256) {     // four chunks per trip: 12 position loads in flight per lane
+    float px[4], py[4], pz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int jc = min(c0 + 64 * u + lane, hi - 1);
+      px[u] = pos[3 * jc]; py[u] = pos[3 * jc + 1]; pz[u] = pos[3 * jc + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = c0 + 64 * u + lane;
+      const float dx = px[u] - xi, dy = py[u] - yi, dz = pz[u] - zi;
+      float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      if (j >= hi || (!loop && j == i)) d = inf;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { const float lo_v = fminf(m[r], d); d = fmaxf(m[r], d); m[r] = lo_v; }
+    }
+  }
+  // bound = kk-th smallest of the 64*R kept values (ties: any consistent order gives the same VALUE)
+  float bound = inf;
+  if (kk <= 64 * R) {
+    int rank[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) rank[r] = 0;
+    for (int l = 0; l < 64; ++l) {
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m[q]), l));
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          rank[r] += (v < m[r] || (v == m[r] && (q * 64 + l) < (r * 64 + lane))) ? 1 : 0;
+      }
+    }
+    float cand = -inf;     // exactly one (lane, r) has rank == kk-1
+#pragma unroll
+    for (int r = 0; r < R; ++r) cand = rank[r] == kk - 1 ? m[r] : cand;
+    const unsigned long long who = __ballot(cand != -inf);
+    bound = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand), __builtin_ctzll(who)));
+  }
+  // B: compact everything within the bound
+  int count = 0;
+  for (int c0 = lo; c0 < hi; c0 += 256) {
+    float px[4], py[4], pz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int jc = min(c0 + 64 * u + lane, hi - 1);
+      px[u] = pos[3 * jc]; py[u] = pos[3 * jc + 1]; pz[u] = pos[3 * jc + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = c0 + 64 * u + lane;
+      const float dx = px[u] - xi, dy = py[u] - yi, dz = pz[u] - zi;
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      const bool hit = j < hi && (loop || j != i) && d <= bound;
+      const unsigned long long mask = __ballot(hit);
+      const int slot = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+      if (hit && slot < kSelCap) { ld[w][slot] = d; lj[w][slot] = j; }
+      count += __builtin_popcountll(mask);
+    }
+  }
+  const int64_t base = out_off ? out_off[i] : (int64_t)i * kk;
+  if (count > kSelCap) {                     // cannot happen with distinct distances; massive ties can
+    knn_insert_centre<RI>(pos, i, lo, hi, kk, loop, base, e_total, edge_index);
+    return;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // C: rank inside the list; the list is in ascending j, so (d2, j) order = (d2, list position)
+  for (int h0 = 0; h0 < count; h0 += 64) {
+    const int h = h0 + lane;
+    const float dh = h < count ? ld[w][h] : inf;
+    int rank = 0;
+    for (int t = 0; t < count; ++t) {
+      const float dt = ld[w][t];                                   // wave-uniform LDS broadcast
+      rank += (dt < dh || (dt == dh && t < h)) ? 1 : 0;
+    }
+    if (h < count && rank < kk) {
+      edge_index[base + rank] = lj[w][h];
+      edge_index[e_total + base + rank] = i;
     }
   }
 }
@@ -271,7 +394,18 @@ int nbd_knn_graph_f32(const float* pos, int n, int k, int loop, const int* seg_l
   if (k > 256) return NBD_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(ceil_div(n, kWavesPerBlock)), block(64 * kWavesPerBlock);
-  if (k <= 64)
+  // selection form by default; R = kept minima per lane (bound tightness), RI = insertion fallback width.
+  // NBD_KNN_INSERTION=1 forces the insertion form (cross-check / comparison).
+  static const bool force_insert = [] { const char* e = getenv("NBD_KNN_INSERTION"); return e && e[0] == '1'; }();
+  if (!force_insert && k <= 40)
+    knn_select_kernel<1, 1><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
+  else if (!force_insert && k <= 64)
+    knn_select_kernel<2, 1><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
+  else if (!force_insert && k <= 100)
+    knn_select_kernel<2, 2><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
+  else if (!force_insert && k <= 200)
+    knn_select_kernel<4, 4><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
+  else if (k <= 64)
     knn_kernel<1><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
   else if (k <= 128)
     knn_kernel<2><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
