@@ -191,11 +191,15 @@ class BaseSimulator:
                 stage[s, 2].copy_(self.accelerations, non_blocking=True)
             uk_host[:m].copy_(uk_dev[:m], non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()
+            # one pageable copy of the whole chunk (the pinned staging is reused); the states' tensors are
+            # views into it -- 3 m small clones cost several times more in allocation and page faults
+            host = stage[:m].clone()
+            uk = uk_host[:m].tolist()
             for s in range(m):
-                u, k = (uk_host[s, 0].item(), uk_host[s, 1].item()) if self.calc_energy else (None, None)
+                u, k = (uk[s][0], uk[s][1]) if self.calc_energy else (None, None)
                 states.append(SimulationState(
-                    positions=stage[s, 0].clone(), velocities=stage[s, 1].clone(),
-                    accelerations=stage[s, 2].clone(), step=done + s,
+                    positions=host[s, 0], velocities=host[s, 1],
+                    accelerations=host[s, 2], step=done + s,
                     step_time=events[s][0].elapsed_time(events[s][1]) * 1e-3, u_energy=u, k_energy=k))
             done += m
         return states
