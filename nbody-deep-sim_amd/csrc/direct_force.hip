@@ -71,31 +71,34 @@ __device__ __forceinline__ void interact(const f4 p, const f2 xi, const f2 yi, c
   az = __builtin_elementwise_fma(w, dz, az);
 }
 
-// Four sources at once for the un-masked kernel: same arithmetic as interact(), but the eight
-// v_rsq_f32 are issued back to back (one asm block). Switching between the quarter-rate
-// transcendental unit and the packed-math stream costs issue cycles on gfx950 (3 fma : 1 rsq mixes
-// run ~10 % under the sum of their parts, tools/ubench_valu.hip), so the switches are batched.
-__device__ __forceinline__ void interact4(const f4* __restrict__ buf, const f2 xi, const f2 yi, const f2 zi,
-                                          const f2 e2, f2& ax, f2& ay, f2& az) {
-  f4 p[4];
-  f2 dx[4], dy[4], dz[4], r2[4];
+// kU sources at once for the un-masked kernel: same arithmetic as interact(), with the 2*kU v_rsq_f32
+// issued back to back (__builtin_amdgcn_sched_group_barrier on the TRANS class). Switching between the
+// quarter-rate transcendental unit and the packed-math stream costs issue cycles on gfx950 (3 fma : 1
+// rsq mixes run ~10 % under the sum of their parts, tools/ubench_valu.hip), so the switches are
+// batched; the rsq stays a compiler builtin so that hipcc fills the transcendental -> VALU wait state
+// with independent work instead of the s_nop it must put behind an opaque asm block. Measured
+// (tools/k1_variants.hip, N = 65 536): kU = 8 at 90 VGPRs / 5 waves per SIMD beats kU = 4 at 58 VGPRs /
+// 8 waves (1.004 vs 1.010 ms) and an inline-asm rsq block (1.021 ms).
+constexpr int kU = 8;
+__device__ __forceinline__ void interact_block(const f4* __restrict__ buf, const f2 xi, const f2 yi, const f2 zi,
+                                               const f2 e2, f2& ax, f2& ay, f2& az) {
+  f4 p[kU];
+  f2 dx[kU], dy[kU], dz[kU], s[kU];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < kU; ++u) {
     p[u] = buf[u];
     dx[u] = f2{p[u].x, p[u].x} - xi; dy[u] = f2{p[u].y, p[u].y} - yi; dz[u] = f2{p[u].z, p[u].z} - zi;
-    r2[u] = __builtin_elementwise_fma(dx[u], dx[u], e2);
-    r2[u] = __builtin_elementwise_fma(dy[u], dy[u], r2[u]);
-    r2[u] = __builtin_elementwise_fma(dz[u], dz[u], r2[u]);
+    f2 r2 = __builtin_elementwise_fma(dx[u], dx[u], e2);
+    r2 = __builtin_elementwise_fma(dy[u], dy[u], r2);
+    s[u] = __builtin_elementwise_fma(dz[u], dz[u], r2);
   }
-  asm volatile("v_rsq_f32 %0, %0\n\tv_rsq_f32 %1, %1\n\tv_rsq_f32 %2, %2\n\tv_rsq_f32 %3, %3\n\t"
-               "v_rsq_f32 %4, %4\n\tv_rsq_f32 %5, %5\n\tv_rsq_f32 %6, %6\n\tv_rsq_f32 %7, %7"
-               : "+v"(r2[0].x), "+v"(r2[0].y), "+v"(r2[1].x), "+v"(r2[1].y), "+v"(r2[2].x), "+v"(r2[2].y),
-                 "+v"(r2[3].x), "+v"(r2[3].y));
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const f2 s = r2[u];                       // now (r^2 + eps^2)^(-1/2)
+  for (int u = 0; u < kU; ++u) s[u] = f2{__builtin_amdgcn_rsqf(s[u].x), __builtin_amdgcn_rsqf(s[u].y)};
+  __builtin_amdgcn_sched_group_barrier(0x400, 2 * kU, 0);      // 0x400 = TRANS: keep the rsq's together
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
     const f2 zm = {p[u].z, p[u].w};
-    const f2 s3 = (s * s) * s;                // compiler-visible consumers of the rsq results (hazard-padded)
+    const f2 s3 = (s[u] * s[u]) * s[u];          // compiler-visible consumers of the rsq results (hazard-padded)
     f2 w;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(w) : "v"(zm), "v"(s3));
     ax = __builtin_elementwise_fma(w, dx[u], ax);
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(64 * kWaves) void accel_kernel(
         interact<true>(buf[j], xi, yi, zi, e2, ax, ay, az, j0 + j, tgt_off + i0, tgt_off + i1, n_src);
     } else {
 #pragma unroll 1
-      for (int j = 0; j < kChunk; j += 4) interact4(buf + j, xi, yi, zi, e2, ax, ay, az);
+      for (int j = 0; j < kChunk; j += kU) interact_block(buf + j, xi, yi, zi, e2, ax, ay, az);
     }
   }
 

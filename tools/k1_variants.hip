@@ -27,7 +27,11 @@ __device__ __forceinline__ void block_u(const f4* buf, const f2 xi, const f2 yi,
     r2[u] = __builtin_elementwise_fma(dy[u], dy[u], r2[u]);
     r2[u] = __builtin_elementwise_fma(dz[u], dz[u], r2[u]);
   }
-  if (VAR == 1 && U == 4) {
+  if (VAR == 2) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) s[u] = f2{__builtin_amdgcn_rsqf(r2[u].x), __builtin_amdgcn_rsqf(r2[u].y)};
+    __builtin_amdgcn_sched_group_barrier(0x400, 2 * U, 0);   // the 2U transcendentals back to back
+  } else if (VAR == 1 && U == 4) {
     asm volatile("v_rsq_f32 %0, %0\n\tv_rsq_f32 %1, %1\n\tv_rsq_f32 %2, %2\n\tv_rsq_f32 %3, %3\n\t"
                  "v_rsq_f32 %4, %4\n\tv_rsq_f32 %5, %5\n\tv_rsq_f32 %6, %6\n\tv_rsq_f32 %7, %7"
                  : "+v"(r2[0].x), "+v"(r2[0].y), "+v"(r2[1].x), "+v"(r2[1].y), "+v"(r2[2].x), "+v"(r2[2].y), "+v"(r2[3].x), "+v"(r2[3].y));
@@ -39,7 +43,7 @@ __device__ __forceinline__ void block_u(const f4* buf, const f2 xi, const f2 yi,
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const f2 w = (s[u] * s[u]) * mulm(f2{p[u].z, p[u].w}, s[u]);
+    const f2 w = mulm(f2{p[u].z, p[u].w}, (s[u] * s[u]) * s[u]);
     ax = __builtin_elementwise_fma(w, dx[u], ax);
     ay = __builtin_elementwise_fma(w, dy[u], ay);
     az = __builtin_elementwise_fma(w, dz[u], az);
@@ -116,17 +120,11 @@ int main() {
   f4* d; float* out; CK(hipMalloc(&d, n * sizeof(f4))); CK(hipMalloc(&out, (size_t)32 * n * 3 * 4));
   CK(hipMemcpy(d, h.data(), n * sizeof(f4), hipMemcpyHostToDevice));
   std::vector<float> ref;
-  for (int rep = 0; rep < 2; ++rep) {
-    run<0, 4, 4>("U4 W4", d, d, out, n, 4, &ref);
-    run<0, 4, 4>("U4 W4", d, d, out, n, 6, &ref);
-    run<0, 4, 4>("U4 W4", d, d, out, n, 8, &ref);
-    run<0, 4, 4>("U4 W4", d, d, out, n, 12, &ref);
-    run<0, 4, 4>("U4 W4", d, d, out, n, 16, &ref);
-    run<1, 4, 4>("rsq-clustered U4 W4", d, d, out, n, 8, &ref);
-    run<1, 4, 4>("rsq-clustered U4 W4", d, d, out, n, 16, &ref);
-    run<0, 4, 2>("U4 W2", d, d, out, n, 16, &ref);
-    run<0, 4, 2>("U4 W2", d, d, out, n, 32, &ref);
-    run<0, 4, 8>("U4 W8", d, d, out, n, 4, &ref);
+  for (int rep = 0; rep < 3; ++rep) {
+    run<0, 4, 4>("compiler-scheduled U4", d, d, out, n, 16, &ref);
+    run<1, 4, 4>("asm rsq block U4 (product)", d, d, out, n, 16, &ref);
+    run<2, 4, 4>("builtin rsq + sched_group U4", d, d, out, n, 16, &ref);
+    run<2, 8, 4>("builtin rsq + sched_group U8", d, d, out, n, 16, &ref);
   }
   return 0;
 }
