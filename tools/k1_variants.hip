@@ -120,11 +120,12 @@ int main() {
   f4* d; float* out; CK(hipMalloc(&d, n * sizeof(f4))); CK(hipMalloc(&out, (size_t)32 * n * 3 * 4));
   CK(hipMemcpy(d, h.data(), n * sizeof(f4), hipMemcpyHostToDevice));
   std::vector<float> ref;
-  for (int rep = 0; rep < 3; ++rep) {
-    run<0, 4, 4>("compiler-scheduled U4", d, d, out, n, 16, &ref);
-    run<1, 4, 4>("asm rsq block U4 (product)", d, d, out, n, 16, &ref);
+  for (int rep = 0; rep < 2; ++rep) {
     run<2, 4, 4>("builtin rsq + sched_group U4", d, d, out, n, 16, &ref);
-    run<2, 8, 4>("builtin rsq + sched_group U8", d, d, out, n, 16, &ref);
+    for (int slabs : {4, 8, 16, 32}) run<2, 8, 4>("builtin rsq + sched_group U8 W4", d, d, out, n, slabs, &ref);
+    for (int slabs : {8, 16, 32}) run<2, 8, 2>("builtin rsq + sched_group U8 W2", d, d, out, n, slabs, &ref);
+    for (int slabs : {4, 8, 16}) run<2, 8, 8>("builtin rsq + sched_group U8 W8", d, d, out, n, slabs, &ref);
+    for (int slabs : {8, 16, 32}) run<2, 16, 4>("builtin rsq + sched_group U16 W4", d, d, out, n, slabs, &ref);
   }
   return 0;
 }

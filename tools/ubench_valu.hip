@@ -29,6 +29,11 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long lo
         if ((i & 3) == 3) asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));
         else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
       }
+      if (MODE == 9) asm volatile("v_sub_f32_dpp %0, %1, %0 row_ror:3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(b));
+      if (MODE == 10) asm volatile("v_mov_b32_dpp %0, %1 row_ror:3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(b));
+      if (MODE == 11) {  // dpp source freshly written by the previous VALU op of the same wave (hazard: 2 wait states)
+        asm volatile("v_sub_f32_dpp %0, %1, %0 row_ror:3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(a[(i + 15) & 15]));
+      }
       if (MODE == 8) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(iters));  // sgpr operand
     }
   }
@@ -69,5 +74,6 @@ int run(const char* name, int lanes_per_instr_flop) {
 int main() {
   run<0>("v_fma_f32", 1); run<1>("v_pk_fma_f32", 2); run<2>("v_rsq_f32", 1); run<3>("v_mul_f32", 1);
   run<4>("v_pk_mul_f32", 2); run<5>("v_sub_f32", 1); run<6>("v_pk_add_f32", 2); run<7>("3fma:1rsq", 1); run<8>("fma_sgpr", 1);
+  run<9>("sub_dpp_ror", 1); run<10>("mov_dpp_ror", 1); run<11>("sub_dpp_dep", 1);
   return 0;
 }
