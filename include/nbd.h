@@ -155,6 +155,15 @@ int nbd_radius_transpose_fill_f32(const float* pos, int n, float radius_sq, int 
                                   const int* seg_hi, const int* last, const int* rowptr, int* centres,
                                   nbd_stream_t stream);
 
+/* Edge list -> CSR grouped by `key` (a row of an int64 edge_index with values in [0, n)): rowptr[n+1],
+ * out[e] = the `val` entries of each key in ascending order (duplicates kept). With key = edge_index[0]
+ * (sources) and val = edge_index[1] (targets) this is the transposed adjacency that the backward pass of
+ * a gather needs so that it is itself a gather with a fixed summation order (the reference's autograd
+ * scatters with atomics: gnn.py:170,183 `loss.backward()`). cursor[n], scratch[n_edges]: caller-owned
+ * temporaries; *bad_flag (device int) is set to 1 if any key is outside [0, n). */
+int nbd_csr_by_key_i64(const int64_t* key, const int64_t* val, int64_t n_edges, int n, int* rowptr, int* cursor,
+                       int* scratch, int* out, int* bad_flag, nbd_stream_t stream);
+
 /* ptr[0] = 0, ptr[i+1] = ptr[i] + counts[i]  (int32, n counts -> n+1 entries). */
 int nbd_exclusive_scan_i32(const int* counts, int n, int* ptr, nbd_stream_t stream);
 
@@ -242,6 +251,46 @@ typedef struct nbd_gnn_layer_args {
   int ldout;
 } nbd_gnn_layer_args;
 int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Backward kernels: what `loss.backward()` executes in the reference's training step
+ * (gnn.py:163-191 train_batch / train_graph_batch, contconv.py:242-247, driven by trainer.py:60-72)
+ * for the layers above. All sums run in a fixed order (row slabs reduced by a second kernel, gathers
+ * over sorted adjacency lists): gradients are bit-identical run to run, unlike autograd's atomics.
+ * The data gradient of a Linear (dX = g W) is nbd_linear_f32 with the transposed weight.
+ * ------------------------------------------------------------------------------------------------- */
+
+/* g = dy * act'(y): act 0 = identity (copy), 1 = tanh (1 - y^2). y is the forward OUTPUT. */
+int nbd_act_bwd_f32(const float* dy, int lddy, const float* y, int ldy, int act, float* g, int ldg, int n, int c,
+                    nbd_stream_t stream);
+
+/* out[c] = sum_n rowweight[n] * x[n][c] (rowweight NULL = 1): bias gradients. */
+size_t nbd_colsum_workspace_bytes(int n, int c);
+int nbd_colsum_f32(const float* x, int ldx, const float* rowweight, int n, int c, float* out, void* workspace,
+                   size_t workspace_bytes, nbd_stream_t stream);
+
+/* dW[m][k] = sum_n g[n][m] * x[n][k]: the weight gradient of Y = X W^T (W is m x k), fp32 MFMA. */
+size_t nbd_linear_wgrad_workspace_bytes(int n, int m, int k);
+int nbd_linear_wgrad_f32(const float* g, int ldg, const float* x, int ldx, int n, int m, int k, float* dw, int lddw,
+                         void* workspace, size_t workspace_bytes, nbd_stream_t stream);
+
+/* Backward of nbd_edgeconv_aggregate_f32 for aggr 0 (sum) / 1 (mean): dpq[n][2h] = [dP | dQ] from ds[n][h].
+ * (rowptr | fixed_k, src): the forward's by-target lists; (rowptr_t, tgt_t): the same edges grouped by
+ * source (nbd_csr_by_key_i64). */
+int nbd_edgeconv_aggregate_bwd_f32(const float* pq, int ldpq, int h, const float* ds, int ldds, const int* rowptr,
+                                   const int64_t* src, int fixed_k, const int* rowptr_t, const int* tgt_t, int n,
+                                   int aggr, float* dpq, int lddpq, nbd_stream_t stream);
+
+/* Backward of nbd_segment_reduce_f32 mode 2 (max): dm[e][c] = dx[i][c] at the first row e of target i with
+ * m[e][c] == x[i][c] (x = the forward output), 0 elsewhere. m may have zero rows for a target. */
+int nbd_segment_max_bwd_f32(const float* m, int ldm, int h, const float* x, int ldx, const int* rowptr, int n,
+                            const float* dx, int lddx, float* dm, int lddm, nbd_stream_t stream);
+
+/* Backward of nbd_layernorm_f32: dx[n][c], dgamma[c], dbeta[c] from x, gamma (NULL = 1) and dy. */
+size_t nbd_layernorm_bwd_workspace_bytes(int n, int c);
+int nbd_layernorm_bwd_f32(const float* x, int ldx, int c, const float* gamma, float eps, const float* dy, int lddy,
+                          float* dx, int lddx, float* dgamma, float* dbeta, int n, void* workspace,
+                          size_t workspace_bytes, nbd_stream_t stream);
 
 /* scale[i] from the CSR degree d_i: mode 0 = 1/max(d,1), 1 = d, 2 = (d > 0). */
 int nbd_degree_scale_f32(const int* rowptr, int n, int mode, float* scale, nbd_stream_t stream);

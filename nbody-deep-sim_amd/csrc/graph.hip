@@ -382,6 +382,49 @@ __global__ __launch_bounds__(256) void zero_i32_kernel(int* __restrict__ p, int 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int status() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : (int)e; }
 
+// ---- edge list -> CSR grouped by an int64 key row (the transposed adjacency the backward pass needs)
+__global__ __launch_bounds__(256) void key_count_kernel(const int64_t* __restrict__ key, int64_t e, int n,
+                                                        int* __restrict__ counts, int* __restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= e) return;
+  const int64_t k = key[i];
+  if (k < 0 || k >= n) { *bad = 1; return; }
+  atomicAdd(&counts[k], 1);
+}
+// slot order inside a key's list is arbitrary here (atomic cursor); key_sort_kernel fixes it
+__global__ __launch_bounds__(256) void key_scatter_kernel(const int64_t* __restrict__ key, const int64_t* __restrict__ val,
+                                                          int64_t e, int n, const int* __restrict__ rowptr,
+                                                          int* __restrict__ cursor, int* __restrict__ scratch) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= e) return;
+  const int64_t k = key[i];
+  if (k < 0 || k >= n) return;
+  scratch[rowptr[k] + atomicAdd(&cursor[k], 1)] = (int)val[i];
+}
+// one wave per key: stable rank sort of its values (duplicates allowed: ties broken by slot), so the
+// result does not depend on the order the atomics of key_scatter_kernel happened to run in
+__global__ __launch_bounds__(64 * kWavesPerBlock) void key_sort_kernel(const int* __restrict__ rowptr, int n,
+                                                                       const int* __restrict__ unsorted,
+                                                                       int* __restrict__ sorted) {
+  const int j = blockIdx.x * kWavesPerBlock + wave_id();
+  if (j >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int b = rowptr[j], d = rowptr[j + 1] - b;
+  for (int k0 = 0; k0 < d; k0 += 64) {
+    const int k = k0 + lane;
+    const int x = k < d ? unsorted[b + k] : 0x7fffffff;
+    int rank = 0;
+    for (int k2 = 0; k2 < d; ++k2) {
+      const int y = unsorted[b + k2];
+      rank += (y < x) ? 1 : 0;
+    }
+    // equal values are interchangeable (same int), so place duplicates at consecutive ranks
+    int dup = 0;
+    for (int k2 = 0; k2 < k && k2 < d; ++k2) dup += (unsorted[b + k2] == x) ? 1 : 0;
+    if (k < d) sorted[b + rank + dup] = x;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -461,6 +504,28 @@ int nbd_radius_transpose_fill_f32(const float* pos, int n, float radius_sq, int 
   if (!pos || !last || !rowptr || !centres) return NBD_E_BADARG;
   radius_transpose_kernel<true><<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, (hipStream_t)stream>>>(
       pos, n, radius_sq, loop, seg_lo, seg_hi, last, rowptr, nullptr, centres);
+  return status();
+}
+
+int nbd_csr_by_key_i64(const int64_t* key, const int64_t* val, int64_t n_edges, int n, int* rowptr, int* cursor,
+                       int* scratch, int* out, int* bad_flag, nbd_stream_t stream) {
+  if (n < 0 || n_edges < 0) return NBD_E_BADARG;
+  if (!rowptr || !bad_flag) return NBD_E_BADARG;
+  if (n_edges > 0x7fffffffLL) return NBD_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_edges > 0 && (!key || !val || !cursor || !scratch || !out)) return NBD_E_BADARG;
+  zero_i32_kernel<<<1, 256, 0, st>>>(bad_flag, 1);
+  if (n > 0) {
+    if (!cursor) return NBD_E_BADARG;
+    zero_i32_kernel<<<ceil_div(n, 256), 256, 0, st>>>(cursor, n);
+  }
+  const unsigned eb = (unsigned)((n_edges + 255) / 256);
+  if (n_edges > 0) key_count_kernel<<<eb, 256, 0, st>>>(key, n_edges, n, cursor, bad_flag);
+  exclusive_scan_kernel<<<1, 1024, 0, st>>>(cursor, n, rowptr);
+  if (n_edges == 0 || n == 0) return status();
+  zero_i32_kernel<<<ceil_div(n, 256), 256, 0, st>>>(cursor, n);
+  key_scatter_kernel<<<eb, 256, 0, st>>>(key, val, n_edges, n, rowptr, cursor, scratch);
+  key_sort_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(rowptr, n, scratch, out);
   return status();
 }
 

@@ -11,7 +11,10 @@ EdgeConv is evaluated in an algebraically factored form (exact in real arithmeti
 per-edge order by fp32 rounding only):
   nn([x_i || x_j - x_i]) = W2 tanh((W1a - W1b) x_i + b1 + W1b x_j) + b2 = W2 tanh(P_i + Q_j) + b2
   sum/mean over j commute with the affine W2, so W2 is applied once per node, not once per edge.
-Training methods are not part of this build (forward-only kernels): they raise NotImplementedError.
+Training (gnn.py:150-191): when gradients are enabled, forward() runs the same kernels through
+torch.autograd Functions (nbd/autograd.py) whose backward passes are HIP kernels too (csrc/train.hip);
+`compute_loss`, `train_batch` and `train_graph_batch` then behave as in the reference, and any
+torch.optim optimiser steps on the `.grad` fields.
 """
 from __future__ import annotations
 
@@ -20,6 +23,7 @@ import time
 import torch
 from torch.nn import LayerNorm, Linear, ModuleList, Sequential, Tanh
 
+from nbd import autograd as ag
 from nbd import graphops, nnops
 from nbd._lib import NbdError
 from nbd.data import Data
@@ -173,8 +177,10 @@ class GraphModel(torch.nn.Module):
 
     # ------------------------------------------------------------------ forward (gnn.py:130-148)
     def forward(self, data):
-        if self.training and self.encoder_dropout > 0:
-            raise NotImplementedError("training-mode dropout is outside this build (inference kernels only)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_autograd(data)
+        if self.training and self.encoder_dropout > 0 and isinstance(self.node_encoder, MLP):
+            return self._forward_autograd(data)          # dropout active: not the folded inference path
         w = self._cache.get(self._build_weights)
         x7 = data.x
         if not x7.is_cuda:
@@ -322,7 +328,94 @@ class GraphModel(torch.nn.Module):
             loss = torch.sqrt(mse_loss)
         return loss.item(), mse_loss.item(), end - start
 
-    def compute_loss(self, data):
-        raise NotImplementedError("training (gnn.py:150-191) is outside this build: forward-only HIP kernels")
+    # ------------------------------------------------------------------ training (gnn.py:150-191)
+    def _graph_lists(self, data, n):
+        ei = data.edge_index
+        reg = getattr(data, "_regular_k", None)
+        if reg is not None and n * reg == ei.shape[1]:
+            return ag.EdgeLists(n, None, ei[0].contiguous(), reg)
+        cached = getattr(data, "_edge_lists", None)
+        if cached is None or cached.n != n:
+            rowptr, src = graphops.csr_by_target(ei, n)
+            cached = ag.EdgeLists(n, rowptr, src, -1)
+            try:
+                data._edge_lists = cached      # the graph of a batch does not change between epochs
+            except AttributeError:
+                pass
+        return cached
 
-    train_batch = train_graph_batch = compute_loss
+    def _forward_autograd(self, data):
+        """gnn.py:130-148 with every layer a torch.autograd.Function over the HIP kernels."""
+        x7 = data.x
+        if not x7.is_cuda:
+            raise NbdError("GraphModel.forward: data must live on the GPU (no CPU path)")
+        n, h = x7.shape[0], self.gnn_dim
+        x_in = torch.cat((x7[:, :3], x7[:, 6:]), dim=-1) if self.input_dim == 4 else x7
+        x_in = x_in.to(torch.float32).contiguous()
+        if isinstance(self.node_encoder, MLP):
+            enc, last = x_in, len(self.node_encoder.lins) - 1
+            for i, lin in enumerate(self.node_encoder.lins):
+                enc = ag.linear(enc, lin.weight, lin.bias, act="tanh" if i < last else None)
+                if i < last and self.training and self.node_encoder.dropout > 0:
+                    enc = torch.nn.functional.dropout(enc, p=self.node_encoder.dropout, training=True)
+        else:
+            enc = x_in
+        lists = self._graph_lists(data, n)
+        if lists.rowptr is None:
+            val = float(lists.fixed_k) if self.aggr != "mean" else (1.0 if lists.fixed_k > 0 else 0.0)
+            brs = torch.full((n,), val, dtype=torch.float32, device=x7.device)
+        else:
+            brs = nnops.degree_scale(lists.rowptr, n, 2 if self.aggr == "mean" else 1, x7.device)
+        x = enc
+        for g in self.gnns:
+            w1, b1 = g.nn[0].weight, g.nn[0].bias
+            f = w1.shape[1] // 2
+            wpq = torch.cat([w1[:, :f] - w1[:, f:], w1[:, f:]], dim=0)            # rows P then Q
+            bpq = torch.cat([b1, torch.zeros_like(b1)])
+            pq = ag.linear(x, wpq, bpq)
+            if self.aggr == "max":
+                msg = ag.linear(ag.EdgeMessagesFn.apply(pq, lists, h), g.nn[2].weight, g.nn[2].bias)
+                x = ag.SegmentMaxFn.apply(msg, lists.csr_rowptr(), n)
+            else:
+                s = ag.EdgeAggregateFn.apply(pq, lists, h, "mean" if self.aggr == "mean" else "sum")
+                x = ag.linear(s, g.nn[2].weight, g.nn[2].bias, bias_rowscale=brs)
+        z = torch.cat((enc, x), dim=-1)
+        z = ag.LayerNormFn.apply(z, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        if isinstance(self.output, Linear):
+            return ag.linear(z, self.output.weight, self.output.bias)
+        lins = [m for m in self.output if isinstance(m, Linear)]
+        for i, lin in enumerate(lins):
+            z = ag.linear(z, lin.weight, lin.bias, act="tanh" if i < len(lins) - 1 else None)
+        return z
+
+    def compute_loss(self, data):
+        """gnn.py:150-161: (RMSE of the scaled accelerations, plain MSE)."""
+        acc_pred = self.forward(data)
+        loss = torch.sqrt(torch.nn.functional.mse_loss(acc_pred * self.scale_factor, data.y * self.scale_factor,
+                                                       reduction="mean"))
+        mse_losses = torch.nn.functional.mse_loss(acc_pred, data.y, reduction="mean")
+        return loss, mse_losses
+
+    def train_batch(self, optimizer, pos, feat, acc):
+        """gnn.py:163-185: a batch of equally sized particle sets -> one k = 50 graph batch -> one step."""
+        self.train()
+        optimizer.zero_grad()
+        batch = torch.cat([torch.full((pos[i].size(0),), i, dtype=torch.long, device=pos.device)
+                           for i in range(len(pos))])
+        pos = pos.reshape(-1, 3)
+        feat = feat.reshape(-1, feat.size(-1))
+        acc = acc.reshape(-1, 3)
+        data = transform_to_graph(pos, feat, acc, batch=batch, device=self.device)
+        loss, mse_loss = self.compute_loss(data)
+        loss.backward()
+        optimizer.step()
+        return loss.item(), mse_loss.item()
+
+    def train_graph_batch(self, optimizer, data):
+        """gnn.py:187-191."""
+        self.train()
+        optimizer.zero_grad()
+        loss, mse_loss = self.compute_loss(data)
+        loss.backward()
+        optimizer.step()
+        return loss.item(), mse_loss.item()

@@ -102,6 +102,22 @@ SIGNATURES = {
                                      c_float, c_void_p, c_void_p]),
     "nbd_degree_scale_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nbd_gnn_layer_f32": (c_int, [POINTER(GnnLayerArgs), c_void_p]),
+    # --- backward kernels (csrc/train.hip) and the transposed adjacency they gather over
+    "nbd_csr_by_key_i64": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p]),
+    "nbd_act_bwd_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "nbd_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "nbd_colsum_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nbd_linear_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "nbd_linear_wgrad_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                     c_void_p, c_size_t, c_void_p]),
+    "nbd_edgeconv_aggregate_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                               c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "nbd_segment_max_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                        c_void_p, c_int, c_void_p]),
+    "nbd_layernorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "nbd_layernorm_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

@@ -144,3 +144,26 @@ def csr_by_target(edge_index: torch.Tensor, n: int):
     rowptr = torch.zeros(n + 1, dtype=torch.int32, device=edge_index.device)
     rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
     return rowptr, src.contiguous()
+
+
+def csr_by_key(key: torch.Tensor, val: torch.Tensor, n: int):
+    """(rowptr int32 [n+1], vals int32 [E]): the edge list grouped by `key`, each group's `val`s ascending.
+    csr_by_key(edge_index[0], edge_index[1], n) is the adjacency transposed (targets of each source)."""
+    if key.dtype != torch.int64 or val.dtype != torch.int64 or key.shape != val.shape or key.dim() != 1:
+        raise _lib.NbdError("csr_by_key: key/val must be int64 vectors of equal length")
+    if not key.is_cuda:
+        raise _lib.NbdError("csr_by_key: tensors must live on the GPU (no CPU path)")
+    key, val = key.contiguous(), val.contiguous()
+    e, dev = key.numel(), key.device
+    rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    cursor = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    scratch = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    out = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    bad = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().nbd_csr_by_key_i64(key.data_ptr(), val.data_ptr(), e, n, rowptr.data_ptr(),
+                                                 cursor.data_ptr(), scratch.data_ptr(), out.data_ptr(), bad.data_ptr(),
+                                                 _lib.current_stream(dev)), "nbd_csr_by_key_i64")
+    if int(bad.item()):
+        raise _lib.NbdError(f"csr_by_key: an index lies outside [0, {n})")
+    return rowptr, out[:e]

@@ -174,3 +174,87 @@ def gnn_layer(*, n, h, aggr, rowptr, src, fixed_k, w2t, b2, epilogue, out, pq=No
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().nbd_gnn_layer_f32(ctypes.byref(a), _lib.current_stream(dev)), "nbd_gnn_layer_f32")
     return True
+
+
+# ---------------------------------------------------------------------------- backward (csrc/train.hip)
+def _ws(nbytes, device):
+    return torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
+
+
+def act_bwd(dy, y, act):
+    """dy * act'(y) with y the forward output (tanh: 1 - y^2)."""
+    n, c = dy.shape
+    g = torch.empty((n, c), dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(_lib.lib().nbd_act_bwd_f32(dy.data_ptr(), _mat(dy, "dy"), y.data_ptr() if y is not None else None,
+                                              _mat(y, "y") if y is not None else 0, ACT[act], g.data_ptr(), c, n, c,
+                                              _lib.current_stream(dy.device)), "nbd_act_bwd_f32")
+    return g
+
+
+def colsum(x, rowweight=None):
+    n, c = x.shape
+    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    need = _lib.lib().nbd_colsum_workspace_bytes(n, c)
+    ws = _ws(need, x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().nbd_colsum_f32(x.data_ptr(), _mat(x, "x") if n else c, _vec(rowweight, n, "rowweight"),
+                                             n, c, out.data_ptr(), _lib.ptr(ws), need,
+                                             _lib.current_stream(x.device)), "nbd_colsum_f32")
+    return out
+
+
+def linear_wgrad(g, x):
+    """(m, k) = g^T x for g (n, m), x (n, k): torch.nn.Linear's weight gradient."""
+    n, m = g.shape
+    k = x.shape[1]
+    if x.shape[0] != n:
+        raise _lib.NbdError(f"linear_wgrad: g is {tuple(g.shape)}, x is {tuple(x.shape)}")
+    dw = torch.empty((m, k), dtype=torch.float32, device=g.device)
+    need = _lib.lib().nbd_linear_wgrad_workspace_bytes(n, m, k)
+    ws = _ws(need, g.device)
+    with torch.cuda.device(g.device):
+        _lib.check(_lib.lib().nbd_linear_wgrad_f32(g.data_ptr(), _mat(g, "g") if n else m, x.data_ptr(),
+                                                   _mat(x, "x") if n else k, n, m, k, dw.data_ptr(), k, _lib.ptr(ws),
+                                                   need, _lib.current_stream(g.device)), "nbd_linear_wgrad_f32")
+    return dw
+
+
+def edgeconv_aggregate_bwd(pq, h, ds, rowptr, src, fixed_k, rowptr_t, tgt_t, aggr):
+    n = pq.shape[0]
+    dpq = torch.empty((n, 2 * h), dtype=torch.float32, device=pq.device)
+    if rowptr_t.dtype != torch.int32 or rowptr_t.numel() != n + 1 or tgt_t.dtype != torch.int32:
+        raise _lib.NbdError("rowptr_t int32 [n+1] / tgt_t int32 required")
+    with torch.cuda.device(pq.device):
+        _lib.check(_lib.lib().nbd_edgeconv_aggregate_bwd_f32(
+            pq.data_ptr(), _mat(pq, "pq"), h, ds.data_ptr(), _mat(ds, "ds"), _lib.ptr(rowptr), _lib.ptr(src), fixed_k,
+            rowptr_t.data_ptr(), _lib.ptr(tgt_t), n, AGGR[aggr], dpq.data_ptr(), 2 * h,
+            _lib.current_stream(pq.device)), "nbd_edgeconv_aggregate_bwd_f32")
+    return dpq
+
+
+def layernorm_bwd(x, gamma, eps, dy):
+    n, c = x.shape
+    dx = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    dg = torch.empty(c, dtype=torch.float32, device=x.device)
+    db = torch.empty(c, dtype=torch.float32, device=x.device)
+    need = _lib.lib().nbd_layernorm_bwd_workspace_bytes(n, c)
+    ws = _ws(need, x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().nbd_layernorm_bwd_f32(x.data_ptr(), _mat(x, "x") if n else c, c, _vec(gamma, c, "gamma"),
+                                                    float(eps), dy.data_ptr(), _mat(dy, "dy") if n else c,
+                                                    dx.data_ptr(), c, dg.data_ptr(), db.data_ptr(), n, _lib.ptr(ws),
+                                                    need, _lib.current_stream(x.device)), "nbd_layernorm_bwd_f32")
+    return dx, dg, db
+
+
+def segment_max_bwd(m, x, rowptr, dx):
+    e, h = m.shape
+    n = x.shape[0]
+    dm = torch.empty((e, h), dtype=torch.float32, device=m.device)
+    with torch.cuda.device(m.device):
+        _lib.check(_lib.lib().nbd_segment_max_bwd_f32(m.data_ptr(), _mat(m, "m") if e else h, h, x.data_ptr(),
+                                                      _mat(x, "x"), rowptr.data_ptr(), n, dx.data_ptr(), _mat(dx, "dx"),
+                                                      dm.data_ptr(), h, _lib.current_stream(m.device)),
+                   "nbd_segment_max_bwd_f32")
+    return dm

@@ -1,7 +1,8 @@
-"""MI355X drop-in for the rollout / evaluation half of the reference's trainer.py: `Trainer` with
+"""MI355X drop-in for the reference's trainer.py: `Trainer` with `train_from_dir` (trainer.py:20-92),
 `step`, `evaluate_rollout`, `evaluate_stepwise`, `test_from_dir` (trainer.py:94-344) -- same
-signatures, same DataFrame columns and statistics. `train_from_dir` (the optimiser loop,
-trainer.py:20-92) is outside this build and raises.
+signatures, same DataFrame columns and statistics. The training loop is the reference's (csv files ->
+graph batches -> model.train_graph_batch -> scheduler / checkpoints); forward and backward of each
+batch run in the HIP kernels (nbd/autograd.py), the optimiser is whatever torch.optim object was passed in.
 
 Differences that do not change outputs: the leapfrog updates run in the HIP kick/drift kernels;
 the 18 N `.item()` host syncs per rollout step (trainer.py:286-312) are replaced by one bulk
@@ -36,9 +37,55 @@ class Trainer:
         # rollouts replay ONE captured hipGraph per step (the step is ~17 short launches: launch-bound)
         self.use_hip_graph = True
 
-    def train_from_dir(self, *args, **kwargs):
-        raise NotImplementedError("train_from_dir (trainer.py:20-92) is the training loop; this build provides "
-                                  "the inference / rollout path only")
+    def train_from_dir(self, data_path, epochs, batch_size, save_every, save_path=None, create_save_path=False):
+        """trainer.py:20-92. Returns (epoch_losses, epoch_mse_losses). Checkpoints are `model_{epoch}.pt`
+        state_dicts; an existing `save_path` is resumed from its highest-numbered file. (The reference
+        leaves `path` unbound when save_every > 0 with neither save_path nor create_save_path; here nothing
+        is saved in that case.)"""
+        path = None
+        if save_every > 0:
+            if save_path:
+                path = save_path
+            elif create_save_path:
+                from datetime import datetime
+                path = "./models" + datetime.now().strftime("%Y%m%d%H%M%S")
+                os.mkdir(path)
+        last_model = 0
+        if save_path:
+            try:
+                models = sorted(os.listdir(save_path), key=lambda x: int(x.split("_")[1].split(".")[0]))
+                with torch.no_grad():
+                    self.model.load_state_dict(torch.load(f"{save_path}/{models[-1]}", map_location=self.device))
+                print(f"Loaded model {models[-1]}")
+            except (IndexError, ValueError, OSError):
+                print("No model found")
+        csv_files = [f.replace("\\", "/") for f in glob(data_path + "/*.csv")]
+        # the graphs of a csv file do not change between epochs: build each file's dataset once
+        datasets = {f: get_dataloader(csv_path=f, batch_size=batch_size, k=self.model.neighbors, device=self.device)
+                    for f in csv_files}
+        try:
+            import tqdm
+            epochs_range = tqdm.trange(epochs)
+        except ImportError:
+            epochs_range = range(epochs)
+        epoch_losses, epoch_mse_losses = [], []
+        for epoch in epochs_range:
+            epoch_loss, epoch_mse_loss = [], []
+            for f in csv_files:
+                for data in datasets[f]:
+                    loss, mse_loss = self.model.train_graph_batch(self.optimizer, data)
+                    epoch_loss.append(loss)
+                    epoch_mse_loss.append(mse_loss)
+            epoch_losses.append(sum(epoch_loss) / len(epoch_loss))
+            epoch_mse_losses.append(sum(epoch_mse_loss) / len(epoch_mse_loss))
+            if hasattr(epochs_range, "set_postfix_str"):
+                epochs_range.set_postfix_str(f"Epoch {epoch+1}: Loss: {epoch_losses[-1]}, MSE: {epoch_mse_losses[-1]}")
+            if self.scheduler:
+                self.scheduler.step(epoch_losses[-1])
+            if path and save_every > 0 and (epoch + 1) % save_every == 0:
+                torch.save(self.model.state_dict(), f"{path}/model_{epoch+1+last_model}.pt")
+                print(f"Saved model {epoch+1+last_model}")
+        return epoch_losses, epoch_mse_losses
 
     # ------------------------------------------------------------------ trainer.py:217-226
     def step(self, pos, vel, m, acc, dt):

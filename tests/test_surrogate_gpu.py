@@ -326,8 +326,6 @@ def test_test_from_dir_on_a_generated_csv(tmp_path, gpu_device):
     assert list(df_step.columns) == ["loss", "step_time"] and len(df_step) == 2
     assert list(df_roll.columns) == ["pos_rmse", "vel_rmse", "acc_rmse"] and len(df_roll) == 2 * steps
     assert np.isfinite(df_roll.values).all() and (df_roll.loc[("output_file_1.csv", 0, 0)][["pos_rmse", "vel_rmse"]] == 0).all()
-    with pytest.raises(NotImplementedError):
-        tr.train_from_dir(str(path), 1, 1, 0)
 
 
 @pytest.mark.parametrize("kind", ["gnn", "contconv"])
