@@ -260,9 +260,10 @@ int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream);
  * The data gradient of a Linear (dX = g W) is nbd_linear_f32 with the transposed weight.
  * ------------------------------------------------------------------------------------------------- */
 
-/* g = dy * act'(y): act 0 = identity (copy), 1 = tanh (1 - y^2). y is the forward OUTPUT. */
-int nbd_act_bwd_f32(const float* dy, int lddy, const float* y, int ldy, int act, float* g, int ldg, int n, int c,
-                    nbd_stream_t stream);
+/* g = rowscale[n] * dy * act'(y): act 0 = identity, 1 = tanh (1 - y^2); y is the forward OUTPUT;
+ * rowscale NULL = 1 (the 1/deg of a mean aggregation, contconv.py:95-97). */
+int nbd_act_bwd_f32(const float* dy, int lddy, const float* y, int ldy, int act, const float* rowscale, float* g,
+                    int ldg, int n, int c, nbd_stream_t stream);
 
 /* out[c] = sum_n rowweight[n] * x[n][c] (rowweight NULL = 1): bias gradients. */
 size_t nbd_colsum_workspace_bytes(int n, int c);
@@ -280,6 +281,27 @@ int nbd_linear_wgrad_f32(const float* g, int ldg, const float* x, int ldx, int n
 int nbd_edgeconv_aggregate_bwd_f32(const float* pq, int ldpq, int h, const float* ds, int ldds, const int* rowptr,
                                    const int64_t* src, int fixed_k, const int* rowptr_t, const int* tgt_t, int n,
                                    int aggr, float* dpq, int lddpq, nbd_stream_t stream);
+
+/* torch.nn.BatchNorm1d in TRAINING mode fused with the activation that follows it in the PyG MLP
+ * (contconv.py:136-141): y = act(gamma (x - mean) rstd + beta) with the batch mean / biased variance per
+ * column, which are also returned (the caller updates running_mean / running_var). n >= 2 as in torch.
+ * bwd: dx, dgamma, dbeta from dy (and y when act = tanh). */
+size_t nbd_batchnorm_train_workspace_bytes(int n, int c);
+int nbd_batchnorm_train_fwd_f32(const float* x, int ldx, int n, int c, const float* gamma, const float* beta, float eps,
+                                int act, float* y, int ldy, float* mean, float* var, float* rstd, void* workspace,
+                                size_t workspace_bytes, nbd_stream_t stream);
+int nbd_batchnorm_train_bwd_f32(const float* x, int ldx, int n, int c, const float* gamma, const float* mean,
+                                const float* rstd, int act, const float* y, int ldy, const float* dy, int lddy,
+                                float* dx, int lddx, float* dgamma, float* dbeta, void* workspace,
+                                size_t workspace_bytes, nbd_stream_t stream);
+
+/* Adjoint of nbd_contconv_bin_f32 with respect to the features: dfeat[c][i] = sum over edges (n <- c) of
+ * window * sum_corners t_corner * da[n][cell][i], gathered per SOURCE c over its list of targets n:
+ * CSR (rowptr_s, tgt_s) or, with rowptr_s NULL, padded lists tgt_s[c * cap + 0..deg[c]) -- the layout
+ * nbd_radius_search_f32 produces. da is (n, D^3 * in_channels) contiguous. */
+int nbd_contconv_bin_bwd_f32(const float* pos, const float* da, int in_channels, const int* rowptr_s, const int* tgt_s,
+                             const int* deg, int cap, int n, int filter_resolution, float radius_sq, float* dfeat,
+                             int lddf, nbd_stream_t stream);
 
 /* Backward of nbd_segment_reduce_f32 mode 2 (max): dm[e][c] = dx[i][c] at the first row e of target i with
  * m[e][c] == x[i][c] (x = the forward output), 0 elsewhere. m may have zero rows for a target. */

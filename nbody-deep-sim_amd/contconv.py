@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from gnn import MLP, _WeightCache, head_chain, run_chain, transform_to_graph  # noqa: F401  (same import as contconv.py:6)
+from nbd import autograd as ag
 from nbd import graphops, nnops
 from nbd._lib import NbdError
 
@@ -64,6 +65,17 @@ class ContinuousConv(nn.Module):
                 centres = torch.zeros(1, dtype=torch.int32, device=positions.device)
         r2 = float(np.float32(self.radius ** 2))                       # contconv.py:86: python double -> fp32
         scale = nnops.degree_scale(rowptr, n, 0, positions.device) if self.agg == "mean" else None
+        if torch.is_grad_enabled() and (self.filters.requires_grad or features.requires_grad):
+            if lists is not None:            # the radius search's per-centre lists ARE the by-source grouping
+                bwd = dict(tgt_s=lists.nbr, deg=lists.deg, cap=lists.nbr.shape[1])
+            else:
+                rp, tg = graphops.csr_by_key(edge_index[1], edge_index[0], n)
+                bwd = dict(rowptr_s=rp, tgt_s=tg if tg.numel() else torch.zeros(1, dtype=torch.int32, device=tg.device))
+            res = ag.ContConvFn.apply(features, self.filters, positions.contiguous(), (rowptr, centres), bwd,
+                                      self.filter_resolution, r2, scale, act)
+            if out is not None:
+                raise NbdError("ContinuousConv.forward: out= is an inference-only option")
+            return res
         wt = self.weight_t() if wt is None else wt
         if out is None:
             out = torch.empty((n, self.out_channels), dtype=torch.float32, device=positions.device)
@@ -134,10 +146,10 @@ class ContinuousConvModel(nn.Module):
         return {"enc": enc, "wt": [layer.weight_t() for layer in self.contconv], "head": head_chain(self.output)}
 
     def forward(self, data):                                                         # contconv.py:218-234
-        if self.training and (isinstance(self.node_encoder, MLP) and self.node_encoder.has_norm
-                              or self.continuous_conv_dropout > 0 or self.encoder_dropout > 0):
-            raise NotImplementedError("training-mode BatchNorm/dropout is outside this build: call eval() "
-                                      "(predict/eval_graph_batch do)")
+        needs_train_path = self.training and (isinstance(self.node_encoder, MLP) and self.node_encoder.has_norm
+                                              or self.continuous_conv_dropout > 0 or self.encoder_dropout > 0)
+        if needs_train_path or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            return self._forward_autograd(data)
         x7 = data.x
         if not x7.is_cuda:
             raise NbdError("ContinuousConvModel.forward: data must live on the GPU (no CPU path)")
@@ -184,7 +196,63 @@ class ContinuousConvModel(nn.Module):
             loss = torch.sqrt(mse_loss)
         return loss.item(), mse_loss.item(), end - start
 
-    def compute_loss(self, data):
-        raise NotImplementedError("training (contconv.py:236-247) is outside this build: forward-only HIP kernels")
+    # ------------------------------------------------------------------ training (contconv.py:236-247)
+    def _encoder_autograd(self, x):
+        """PyG MLP forward (Linear -> BatchNorm -> tanh -> dropout per hidden layer, plain last Linear) in the
+        module's CURRENT mode: batch statistics when self.training, running statistics otherwise -- the
+        reference's train_graph_batch never calls train(), so a model that went through eval() keeps
+        training with frozen BatchNorm; the same happens here."""
+        enc, last = self.node_encoder, len(self.node_encoder.lins) - 1
+        for i, lin in enumerate(enc.lins):
+            if i == last:
+                return ag.linear(x, lin.weight, lin.bias)
+            if enc.has_norm:
+                bn = enc.norms[i].module
+                if self.training:
+                    x = ag.batchnorm_act(ag.linear(x, lin.weight, lin.bias), bn, "tanh")
+                else:           # eval-mode BatchNorm is affine: fold it into the Linear (tiny torch ops, differentiable)
+                    s_ = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                    x = ag.linear(x, lin.weight * s_.unsqueeze(1), (lin.bias - bn.running_mean) * s_ + bn.bias, act="tanh")
+            else:
+                x = ag.linear(x, lin.weight, lin.bias, act="tanh")
+            if self.training and enc.dropout > 0:
+                x = torch.nn.functional.dropout(x, p=enc.dropout, training=True)
+        return x
 
-    train_graph_batch = compute_loss
+    def _forward_autograd(self, data):
+        x7 = data.x
+        if not x7.is_cuda:
+            raise NbdError("ContinuousConvModel.forward: data must live on the GPU (no CPU path)")
+        x = torch.cat((x7[:, :3], x7[:, 6:]), dim=-1) if self.in_channels == 4 else x7
+        x = x.to(torch.float32).contiguous()
+        pos = x[:, :3].contiguous()
+        lists = graphops.radius_lists(pos, self.radius, getattr(data, "batch", None), loop=self.self_loops,
+                                      max_num_neighbors=self.max_num_neighbors)
+        enc = self._encoder_autograd(x) if isinstance(self.node_encoder, MLP) else x
+        h = enc
+        for layer in self.contconv:
+            h = layer(pos, h, lists=lists, act="tanh")
+            if self.training and self.continuous_conv_dropout > 0:
+                h = torch.nn.functional.dropout(h, p=self.continuous_conv_dropout, training=True)
+        z = ag.LayerNormFn.apply(torch.cat((enc, h), dim=-1), self.layer_norm.weight, self.layer_norm.bias,
+                                 self.layer_norm.eps)
+        if isinstance(self.output, nn.Linear):
+            return ag.linear(z, self.output.weight, self.output.bias)
+        lins = [m for m in self.output if isinstance(m, nn.Linear)]
+        for i, lin in enumerate(lins):
+            z = ag.linear(z, lin.weight, lin.bias, act="tanh" if i < len(lins) - 1 else None)
+        return z
+
+    def compute_loss(self, data):
+        """contconv.py:236-240."""
+        acc_pred = self.forward(data)
+        return (torch.sqrt(torch.nn.functional.mse_loss(acc_pred * self.scale_factor, data.y * self.scale_factor)),
+                torch.nn.functional.mse_loss(acc_pred, data.y))
+
+    def train_graph_batch(self, optimizer, data):
+        """contconv.py:242-247 (no self.train() here, as upstream)."""
+        optimizer.zero_grad()
+        loss, mse_loss = self.compute_loss(data)
+        loss.backward()
+        optimizer.step()
+        return loss.item(), mse_loss.item()

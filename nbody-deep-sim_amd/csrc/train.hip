@@ -34,13 +34,15 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 // ------------------------------------------------------------------ activation backward
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y,
-                                                      int ldy, int act, float* __restrict__ g, int ldg, int n, int c) {
+                                                      int ldy, int act, const float* __restrict__ rowscale,
+                                                      float* __restrict__ g, int ldg, int n, int c) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)n * c) return;
   const int r = (int)(idx / c), col = (int)(idx - (size_t)r * c);
   const float d = dy[(size_t)r * lddy + col];
   float v = d;
   if (act == 1) { const float t = y[(size_t)r * ldy + col]; v = d * (1.0f - t * t); }
+  if (rowscale) v *= rowscale[r];
   g[(size_t)r * ldg + col] = v;
 }
 
@@ -259,17 +261,154 @@ __global__ __launch_bounds__(256) void segment_max_bwd_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------ BatchNorm1d, training mode
+// (the PyG MLP of contconv.py:136-141 carries BatchNorm; a module that was never put in eval() normalises
+// with the batch statistics.) Column statistics in two fixed-order stages like nbd_colsum_f32.
+// stage 1, MODE 0: part[b][c] = sum_r x            MODE 1: part[b][c] = sum_r (x - mean_c)^2
+//          MODE 2: part[b][0:c] = sum_r g xhat, part[b][c:2c] = sum_r g   with g = dy * act'(y)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int ldx, int n, int c,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ dy, int lddy,
+                                                         const float* __restrict__ y, int ldy, int act,
+                                                         float* __restrict__ part) {
+  const int r0 = blockIdx.x * kColRows, r1 = min(r0 + kColRows, n);
+  for (int col = threadIdx.x; col < c; col += 256) {
+    float s = 0.f, s2 = 0.f;
+    const float mu = MODE ? mean[col] : 0.f, rs = MODE == 2 ? rstd[col] : 0.f;
+    for (int r = r0; r < r1; ++r) {
+      const float v = x[(size_t)r * ldx + col];
+      if (MODE == 0) s += v;
+      if (MODE == 1) { const float d = v - mu; s = __builtin_fmaf(d, d, s); }
+      if (MODE == 2) {
+        float g = dy[(size_t)r * lddy + col];
+        if (act == 1) { const float t = y[(size_t)r * ldy + col]; g *= 1.0f - t * t; }
+        s = __builtin_fmaf(g, (v - mu) * rs, s);
+        s2 += g;
+      }
+    }
+    if (MODE == 2) { part[(size_t)blockIdx.x * 2 * c + col] = s; part[(size_t)blockIdx.x * 2 * c + c + col] = s2; }
+    else part[(size_t)blockIdx.x * c + col] = s;
+  }
+}
+// out[col] = (sum_b part[b][col]) * scale; optionally also rstd = 1/sqrt(out + eps)
+__global__ __launch_bounds__(256) void bn_final_kernel(const float* __restrict__ part, int ldpart, int blocks, int c,
+                                                       float scale, float* __restrict__ out, float eps,
+                                                       float* __restrict__ rstd) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= c) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += part[(size_t)b * ldpart + col];
+  s *= scale;
+  out[col] = s;
+  if (rstd) rstd[col] = 1.0f / sqrtf(s + eps);
+}
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, int n, int c,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int act, float* __restrict__ y, int ldy) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)n * c) return;
+  const int r = (int)(idx / c), col = (int)(idx - (size_t)r * c);
+  float v = (x[(size_t)r * ldx + col] - mean[col]) * rstd[col];
+  if (gamma) v *= gamma[col];
+  if (beta) v += beta[col];
+  y[(size_t)r * ldy + col] = act == 1 ? tanhf(v) : v;
+}
+// dx = gamma rstd (g - dbeta/n - xhat dgamma/n)
+__global__ __launch_bounds__(256) void bn_dx_kernel(const float* __restrict__ x, int ldx, int n, int c,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const float* __restrict__ gamma, const float* __restrict__ dy, int lddy,
+                                                    const float* __restrict__ y, int ldy, int act,
+                                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                    float* __restrict__ dx, int lddx) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)n * c) return;
+  const int r = (int)(idx / c), col = (int)(idx - (size_t)r * c);
+  float g = dy[(size_t)r * lddy + col];
+  if (act == 1) { const float t = y[(size_t)r * ldy + col]; g *= 1.0f - t * t; }
+  const float xh = (x[(size_t)r * ldx + col] - mean[col]) * rstd[col];
+  const float inv_n = 1.0f / (float)n;
+  dx[(size_t)r * lddx + col] = (gamma ? gamma[col] : 1.0f) * rstd[col] * (g - dbeta[col] * inv_n - xh * dgamma[col] * inv_n);
+}
+
+// ------------------------------------------------------------------ ContinuousConv binning, backward
+// dfeat[c][i] = sum over the edges (n <- c) of window_e * sum_{8 corners} t_corner(e) * dA[n][cell][i]:
+// the adjoint of contconv_bin_kernel, as a gather per SOURCE c (one wave per source and 64-channel
+// group, lane = channel) over the source's list of aggregation targets n -- the radius search's own
+// per-centre lists (ELL: nbr[c][0..deg[c]), or CSR rowptr_s/tgt_s for a caller-supplied edge list).
+struct Geo { int ix, iy, iz; float tx, ty, tz, window; };
+__device__ __forceinline__ Geo edge_geo(const float* __restrict__ pos, float xc, float yc, float zc, int n_node,
+                                        float r2max, float half) {
+  Geo g;
+  // r = positions[col] - positions[row] (contconv.py:84): source c minus target n -- same ops as the forward
+  const float rx = xc - pos[3 * n_node], ry = yc - pos[3 * n_node + 1], rz = zc - pos[3 * n_node + 2];
+  const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz));
+  const float qq = 1.0f - d2 / r2max;
+  g.window = (d2 < r2max) ? qq * qq * qq : 0.f;
+  const float nrm = sqrtf(d2);
+  const float sc = tanhf(nrm) / (nrm + 1e-8f);
+  const float gx = (rx * sc + 1.0f) * half, gy = (ry * sc + 1.0f) * half, gz = (rz * sc + 1.0f) * half;
+  const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+  g.ix = (int)fx; g.iy = (int)fy; g.iz = (int)fz;
+  g.tx = gx - fx; g.ty = gy - fy; g.tz = gz - fz;
+  return g;
+}
+__global__ __launch_bounds__(64) void contconv_bin_bwd_kernel(
+    const float* __restrict__ pos, const float* __restrict__ dA, int I, const int* __restrict__ rowptr_s,
+    const int* __restrict__ tgt_s, const int* __restrict__ deg, int cap, int D, float r2max,
+    float* __restrict__ dfeat, int lddf) {
+  __shared__ Geo geo[64];
+  __shared__ int tgt[64];
+  const int c = blockIdx.x, lane = threadIdx.x, ch = blockIdx.y * 64 + lane;
+  const int e0 = rowptr_s ? rowptr_s[c] : c * cap, e1 = rowptr_s ? rowptr_s[c + 1] : e0 + deg[c];
+  const float xc = pos[3 * c], yc = pos[3 * c + 1], zc = pos[3 * c + 2];
+  const float half = (float)(D - 1) / 2.0f;
+  const size_t row_len = (size_t)D * D * D * I;
+  float acc = 0.f;
+  for (int eb = e0; eb < e1; eb += 64) {
+    const int cnt = min(64, e1 - eb);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < cnt) {
+      const int n_node = tgt_s[eb + lane];
+      tgt[lane] = n_node;
+      geo[lane] = edge_geo(pos, xc, yc, zc, n_node, r2max, half);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (ch < I) {
+      for (int e = 0; e < cnt; ++e) {
+        const Geo g = geo[e];
+        if (g.window == 0.f) continue;
+        const float* row = dA + (size_t)tgt[e] * row_len + ch;
+        float sum = 0.f;
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+          const int ax = corner & 1, ay = (corner >> 1) & 1, az = corner >> 2;
+          const int cx = g.ix + ax, cy = g.iy + ay, cz = g.iz + az;
+          if (cx < 0 || cx >= D || cy < 0 || cy >= D || cz < 0 || cz >= D) continue;
+          const float t = ((ax ? g.tx : 1.0f - g.tx) * (ay ? g.ty : 1.0f - g.ty)) * (az ? g.tz : 1.0f - g.tz);
+          sum = __builtin_fmaf(t, row[(size_t)((cz * D + cy) * D + cx) * I], sum);
+        }
+        acc = __builtin_fmaf(g.window, sum, acc);
+      }
+    }
+  }
+  if (ch < I) dfeat[(size_t)c * lddf + ch] = acc;
+}
+
 }  // namespace
 
 extern "C" {
 
-int nbd_act_bwd_f32(const float* dy, int lddy, const float* y, int ldy, int act, float* g, int ldg, int n, int c,
-                    nbd_stream_t stream) {
+int nbd_act_bwd_f32(const float* dy, int lddy, const float* y, int ldy, int act, const float* rowscale, float* g,
+                    int ldg, int n, int c, nbd_stream_t stream) {
   if (n < 0 || c < 0 || act < 0 || act > 1) return NBD_E_BADARG;
   if (n == 0 || c == 0) return 0;
   if (!dy || !g || (act == 1 && !y) || lddy < c || ldg < c || (act == 1 && ldy < c)) return NBD_E_BADARG;
   const size_t total = (size_t)n * c;
-  act_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(dy, lddy, y, ldy, act, g, ldg, n, c);
+  act_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(dy, lddy, y, ldy, act, rowscale, g, ldg, n, c);
   return status();
 }
 
@@ -335,6 +474,62 @@ int nbd_edgeconv_aggregate_bwd_f32(const float* pq, int ldpq, int h, const float
                                                              tgt_t, n, aggr, dpq, lddpq);
   edgeconv_bwd_kernel<true><<<ceil_div(n, 4), 256, 0, st>>>(pq, ldpq, h, ds, ldds, rowptr, src, fixed_k, rowptr_t,
                                                             tgt_t, n, aggr, dpq, lddpq);
+  return status();
+}
+
+size_t nbd_batchnorm_train_workspace_bytes(int n, int c) {
+  if (n <= 0 || c <= 0) return 0;
+  return (size_t)ceil_div(n, kColRows) * 2 * c * sizeof(float);
+}
+
+int nbd_batchnorm_train_fwd_f32(const float* x, int ldx, int n, int c, const float* gamma, const float* beta, float eps,
+                                int act, float* y, int ldy, float* mean, float* var, float* rstd, void* workspace,
+                                size_t workspace_bytes, nbd_stream_t stream) {
+  if (n < 2 || c <= 0 || act < 0 || act > 1) return NBD_E_BADARG;      // torch: more than one value per channel
+  if (!x || !y || !mean || !var || !rstd || ldx < c || ldy < c) return NBD_E_BADARG;
+  if (!workspace || workspace_bytes < nbd_batchnorm_train_workspace_bytes(n, c)) return NBD_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  float* part = static_cast<float*>(workspace);
+  const int blocks = ceil_div(n, kColRows), cb = ceil_div(c, 256);
+  bn_partial_kernel<0><<<blocks, 256, 0, st>>>(x, ldx, n, c, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, part);
+  bn_final_kernel<<<cb, 256, 0, st>>>(part, c, blocks, c, 1.0f / (float)n, mean, 0.f, nullptr);
+  bn_partial_kernel<1><<<blocks, 256, 0, st>>>(x, ldx, n, c, mean, nullptr, nullptr, 0, nullptr, 0, 0, part);
+  bn_final_kernel<<<cb, 256, 0, st>>>(part, c, blocks, c, 1.0f / (float)n, var, eps, rstd);
+  const size_t total = (size_t)n * c;
+  bn_apply_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(x, ldx, n, c, mean, rstd, gamma, beta, act, y, ldy);
+  return status();
+}
+
+int nbd_batchnorm_train_bwd_f32(const float* x, int ldx, int n, int c, const float* gamma, const float* mean,
+                                const float* rstd, int act, const float* y, int ldy, const float* dy, int lddy,
+                                float* dx, int lddx, float* dgamma, float* dbeta, void* workspace,
+                                size_t workspace_bytes, nbd_stream_t stream) {
+  if (n < 2 || c <= 0 || act < 0 || act > 1) return NBD_E_BADARG;
+  if (!x || !mean || !rstd || !dy || !dx || !dgamma || !dbeta || (act == 1 && !y)) return NBD_E_BADARG;
+  if (ldx < c || lddy < c || lddx < c || (act == 1 && ldy < c)) return NBD_E_BADARG;
+  if (!workspace || workspace_bytes < nbd_batchnorm_train_workspace_bytes(n, c)) return NBD_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  float* part = static_cast<float*>(workspace);
+  const int blocks = ceil_div(n, kColRows), cb = ceil_div(c, 256);
+  bn_partial_kernel<2><<<blocks, 256, 0, st>>>(x, ldx, n, c, mean, rstd, dy, lddy, y, ldy, act, part);
+  bn_final_kernel<<<cb, 256, 0, st>>>(part, 2 * c, blocks, c, 1.0f, dgamma, 0.f, nullptr);
+  bn_final_kernel<<<cb, 256, 0, st>>>(part + c, 2 * c, blocks, c, 1.0f, dbeta, 0.f, nullptr);
+  const size_t total = (size_t)n * c;
+  bn_dx_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(x, ldx, n, c, mean, rstd, gamma, dy, lddy, y, ldy, act,
+                                                                 dgamma, dbeta, dx, lddx);
+  return status();
+}
+
+int nbd_contconv_bin_bwd_f32(const float* pos, const float* da, int in_channels, const int* rowptr_s, const int* tgt_s,
+                             const int* deg, int cap, int n, int filter_resolution, float radius_sq, float* dfeat,
+                             int lddf, nbd_stream_t stream) {
+  if (n < 0 || in_channels <= 0 || filter_resolution < 1 || !(radius_sq > 0.f)) return NBD_E_BADARG;
+  if (n == 0) return 0;
+  if (!pos || !da || !tgt_s || !dfeat || lddf < in_channels) return NBD_E_BADARG;
+  if (!rowptr_s && (!deg || cap < 0)) return NBD_E_BADARG;
+  dim3 grid(n, ceil_div(in_channels, 64));
+  contconv_bin_bwd_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(pos, da, in_channels, rowptr_s, tgt_s, deg, cap,
+                                                               filter_resolution, radius_sq, dfeat, lddf);
   return status();
 }
 

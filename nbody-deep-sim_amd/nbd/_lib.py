@@ -105,7 +105,16 @@ SIGNATURES = {
     # --- backward kernels (csrc/train.hip) and the transposed adjacency they gather over
     "nbd_csr_by_key_i64": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
-    "nbd_act_bwd_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "nbd_act_bwd_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_void_p]),
+    "nbd_batchnorm_train_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "nbd_batchnorm_train_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int,
+                                            c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nbd_batchnorm_train_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                            c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                            c_void_p, c_size_t, c_void_p]),
+    "nbd_contconv_bin_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                         c_float, c_void_p, c_int, c_void_p]),
     "nbd_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
     "nbd_colsum_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nbd_linear_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

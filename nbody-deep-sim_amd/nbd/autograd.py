@@ -154,3 +154,72 @@ class LayerNormFn(Function):
         x, gamma = ctx.saved_tensors
         dx, dg, db = nnops.layernorm_bwd(x, gamma, ctx.eps, dy if dy.stride(1) == 1 else dy.contiguous())
         return dx, dg, db, None
+
+
+class BatchNormActFn(Function):
+    """act(BatchNorm1d(x)) with BATCH statistics (training mode); returns (y, batch mean, biased batch var)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, act):
+        y, mean, var, rstd = nnops.batchnorm_train_fwd(x, gamma, beta, eps, act)
+        ctx.save_for_backward(x, gamma, mean, rstd, y)
+        ctx.act = act
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, _dmean, _dvar):
+        x, gamma, mean, rstd, y = ctx.saved_tensors
+        dx, dg, db = nnops.batchnorm_train_bwd(x, gamma, mean, rstd, ctx.act, y, dy if dy.stride(1) == 1 else dy.contiguous())
+        return dx, dg, db, None, None
+
+
+def batchnorm_act(x, bn: torch.nn.BatchNorm1d, act):
+    """Training-mode BatchNorm1d + activation, updating bn's running statistics as torch does
+    (momentum blend, unbiased variance, num_batches_tracked)."""
+    y, mean, var = BatchNormActFn.apply(x, bn.weight, bn.bias, bn.eps, act)
+    if bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            n = x.shape[0]
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var, alpha=mom * n / (n - 1))
+    return y
+
+
+class ContConvFn(Function):
+    """ContinuousConv layer (contconv.py:80-98): out = act(scale_n * bin(pos, feat)[n] . filters).
+    Backward: dfilters = bin^T (scale g) on the fp32-MFMA wgrad kernel (the binned matrix is recomputed,
+    not kept), dfeat = adjoint binning of (scale g) filters^T gathered per source."""
+
+    @staticmethod
+    def forward(ctx, feat, filters, pos, fwd_lists, bwd_lists, d, r2, scale, act):
+        i_ch, o_ch = filters.shape[3], filters.shape[4]
+        rowptr, centres = fwd_lists
+        feat = feat if feat.stride(1) == 1 else feat.contiguous()
+        a = nnops.contconv_bin(pos, feat, rowptr, centres, d, r2)
+        w = filters.reshape(d * d * d * i_ch, o_ch)
+        out = nnops.linear(a, w.t().contiguous(), None, act=act, rowscale=scale)
+        ctx.save_for_backward(feat, filters, pos, out, scale)
+        ctx.fwd_lists, ctx.bwd_lists, ctx.d, ctx.r2, ctx.act = fwd_lists, bwd_lists, d, r2, act
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        feat, filters, pos, out, scale = ctx.saved_tensors
+        d, r2 = ctx.d, ctx.r2
+        i_ch, o_ch = filters.shape[3], filters.shape[4]
+        dout = dout if dout.stride(1) == 1 else dout.contiguous()
+        gs = nnops.act_bwd(dout, out if ctx.act == "tanh" else None, ctx.act, rowscale=scale)
+        dfilters = dfeat = None
+        if ctx.needs_input_grad[1]:
+            a = nnops.contconv_bin(pos, feat, ctx.fwd_lists[0], ctx.fwd_lists[1], d, r2)
+            dfilters = nnops.linear_wgrad(a, gs).reshape(filters.shape)
+            del a
+        if ctx.needs_input_grad[0]:
+            da = nnops.linear(gs, filters.reshape(d * d * d * i_ch, o_ch).contiguous())
+            dfeat = nnops.contconv_bin_bwd(pos, da, i_ch, d, r2, **ctx.bwd_lists)
+        return dfeat, dfilters, None, None, None, None, None, None, None

@@ -181,13 +181,14 @@ def _ws(nbytes, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
 
 
-def act_bwd(dy, y, act):
-    """dy * act'(y) with y the forward output (tanh: 1 - y^2)."""
+def act_bwd(dy, y, act, rowscale=None):
+    """rowscale * dy * act'(y) with y the forward output (tanh: 1 - y^2)."""
     n, c = dy.shape
     g = torch.empty((n, c), dtype=torch.float32, device=dy.device)
     with torch.cuda.device(dy.device):
         _lib.check(_lib.lib().nbd_act_bwd_f32(dy.data_ptr(), _mat(dy, "dy"), y.data_ptr() if y is not None else None,
-                                              _mat(y, "y") if y is not None else 0, ACT[act], g.data_ptr(), c, n, c,
+                                              _mat(y, "y") if y is not None else 0, ACT[act],
+                                              _vec(rowscale, n, "rowscale"), g.data_ptr(), c, n, c,
                                               _lib.current_stream(dy.device)), "nbd_act_bwd_f32")
     return g
 
@@ -258,3 +259,55 @@ def segment_max_bwd(m, x, rowptr, dx):
                                                       dm.data_ptr(), h, _lib.current_stream(m.device)),
                    "nbd_segment_max_bwd_f32")
     return dm
+
+
+def batchnorm_train_fwd(x, gamma, beta, eps, act):
+    """y = act(BatchNorm1d_train(x)); returns (y, mean, biased var, rstd)."""
+    n, c = x.shape
+    if n < 2:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
+    dev = x.device
+    y = torch.empty((n, c), dtype=torch.float32, device=dev)
+    mean, var, rstd = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(3))
+    need = _lib.lib().nbd_batchnorm_train_workspace_bytes(n, c)
+    ws = _ws(need, dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().nbd_batchnorm_train_fwd_f32(x.data_ptr(), _mat(x, "x"), n, c, _vec(gamma, c, "gamma"),
+                                                          _vec(beta, c, "beta"), float(eps), ACT[act], y.data_ptr(), c,
+                                                          mean.data_ptr(), var.data_ptr(), rstd.data_ptr(),
+                                                          _lib.ptr(ws), need, _lib.current_stream(dev)),
+                   "nbd_batchnorm_train_fwd_f32")
+    return y, mean, var, rstd
+
+
+def batchnorm_train_bwd(x, gamma, mean, rstd, act, y, dy):
+    n, c = x.shape
+    dev = x.device
+    dx = torch.empty((n, c), dtype=torch.float32, device=dev)
+    dg, db = torch.empty(c, dtype=torch.float32, device=dev), torch.empty(c, dtype=torch.float32, device=dev)
+    need = _lib.lib().nbd_batchnorm_train_workspace_bytes(n, c)
+    ws = _ws(need, dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().nbd_batchnorm_train_bwd_f32(x.data_ptr(), _mat(x, "x"), n, c, _vec(gamma, c, "gamma"),
+                                                          mean.data_ptr(), rstd.data_ptr(), ACT[act], y.data_ptr(),
+                                                          _mat(y, "y"), dy.data_ptr(), _mat(dy, "dy"), dx.data_ptr(), c,
+                                                          dg.data_ptr(), db.data_ptr(), _lib.ptr(ws), need,
+                                                          _lib.current_stream(dev)), "nbd_batchnorm_train_bwd_f32")
+    return dx, dg, db
+
+
+def contconv_bin_bwd(pos, da, i_ch, d, radius_sq, rowptr_s=None, tgt_s=None, deg=None, cap=0):
+    """dfeat (n, i_ch): adjoint of contconv_bin w.r.t. the features; lists are per SOURCE (see nbd.h)."""
+    n = pos.shape[0]
+    if da.shape != (n, d * d * d * i_ch) or not da.is_contiguous():
+        raise _lib.NbdError(f"dA must be contiguous ({n}, {d * d * d * i_ch})")
+    for t in (rowptr_s, tgt_s, deg):
+        if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
+            raise _lib.NbdError("contconv_bin_bwd: index lists must be contiguous int32")
+    dfeat = torch.empty((n, i_ch), dtype=torch.float32, device=pos.device)
+    with torch.cuda.device(pos.device):
+        _lib.check(_lib.lib().nbd_contconv_bin_bwd_f32(pos.data_ptr(), da.data_ptr(), i_ch, _lib.ptr(rowptr_s),
+                                                       tgt_s.data_ptr(), _lib.ptr(deg), cap, n, d, float(radius_sq),
+                                                       dfeat.data_ptr(), i_ch, _lib.current_stream(pos.device)),
+                   "nbd_contconv_bin_bwd_f32")
+    return dfeat

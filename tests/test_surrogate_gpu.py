@@ -252,7 +252,9 @@ def test_contconv_model_matches_oracle(gpu_device):
     x7 = torch.cat([pos, feat], 1)
     with torch.no_grad():
         ref_b = ora.forward_x(x7, batch=b)
-    got_b = model.forward(Data(x=x7.cuda(), batch=b.cuda())).cpu()
+    got_b = model.forward(Data(x=x7.cuda(), batch=b.cuda()))     # outside no_grad: the autograd path
+    assert got_b.requires_grad
+    got_b = got_b.detach().cpu()
     assert global_rel(got_b, ref_b) < TOL
     y = torch.randn(600, 3)
     rmse, mse, secs = model.eval_graph_batch(Data(x=x7.cuda(), batch=b.cuda(), y=y.cuda()))

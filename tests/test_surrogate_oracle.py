@@ -174,8 +174,11 @@ def test_state_dicts_are_interchangeable_with_reference_layout():
     assert c.layer_norm.normalized_shape == (256,) and c.neighbors == 0
     with pytest.raises(NotImplementedError):
         gnn.GraphModel(aggr="min")
-    with pytest.raises(NotImplementedError):
-        g.compute_loss(None)
+    # training runs on the HIP kernels too: CPU tensors are refused, never silently computed on the host
+    from nbd._lib import NbdError
+    from nbd.data import Data
+    with pytest.raises(NbdError):
+        g.compute_loss(Data(x=torch.zeros(5, 7), edge_index=torch.zeros((2, 0), dtype=torch.int64), y=torch.zeros(5, 3)))
 
 
 def test_forward_on_cpu_tensors_fails_loudly():

@@ -270,3 +270,144 @@ def test_train_from_dir_learns_and_checkpoints(tmp_path, gpu_device):
     tr2.train_from_dir(str(path), epochs=1, batch_size=4, save_every=0, save_path=str(save))
     for k, v in model2.state_dict().items():
         assert torch.equal(v.cpu(), state[k]), k
+
+
+# ------------------------------------------------------------------ ContinuousConv / BatchNorm training
+@pytest.mark.parametrize("n,c,act", [(2, 5, None), (300, 64, "tanh"), (4099, 32, "tanh"), (1000, 130, None)])
+def test_batchnorm_train_matches_torch(n, c, act, gpu_device):
+    from nbd import autograd as ag
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, generator=g) * 2 + 0.5
+    dy = torch.randn(n, c, generator=g)
+    bn_r = torch.nn.BatchNorm1d(c).double()
+    bn_g = torch.nn.BatchNorm1d(c).cuda()
+    with torch.no_grad():
+        bn_r.weight.uniform_(0.5, 1.5); bn_r.bias.uniform_(-0.3, 0.3)
+        bn_g.weight.copy_(bn_r.weight.float()); bn_g.bias.copy_(bn_r.bias.float())
+    xr = x.double().requires_grad_()
+    yr = bn_r(xr)
+    yr = torch.tanh(yr) if act else yr
+    yr.backward(dy.double())
+    xg = x.cuda().requires_grad_()
+    yg = ag.batchnorm_act(xg, bn_g, act)
+    yg.backward(dy.cuda())
+    assert global_rel(yg.detach().cpu(), yr.detach().float()) < TOL
+    # n = 2 makes xhat = +-1 whatever x is: the true dx is ~0 and only an absolute bound is meaningful
+    err = float((xg.grad.cpu() - xr.grad.float()).norm())
+    assert err <= 3 * TOL * max(float(xr.grad.norm()), 1e-2 * float(dy.norm()))
+    assert global_rel(bn_g.weight.grad.cpu(), bn_r.weight.grad.float()) < TOL
+    assert global_rel(bn_g.bias.grad.cpu(), bn_r.bias.grad.float()) < TOL
+    assert global_rel(bn_g.running_mean.cpu(), bn_r.running_mean.float()) < TOL
+    assert global_rel(bn_g.running_var.cpu(), bn_r.running_var.float()) < TOL
+    assert int(bn_g.num_batches_tracked) == 1
+    with pytest.raises(ValueError):
+        ag.batchnorm_act(x[:1].cuda(), bn_g, act)
+
+
+@pytest.mark.parametrize("agg,D,I,O", [("mean", 4, 8, 16), ("sum", 3, 70, 40), ("mean", 6, 32, 128), ("mean", 2, 130, 5)])
+def test_contconv_layer_gradients_match_oracle(agg, D, I, O, gpu_device):
+    import contconv
+    from nbd import graphops
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(D)
+    n = 300
+    pos, _, _ = _plummer(n, 8)
+    feat = torch.randn(n, I)
+    dout = torch.randn(n, O)
+    ora = so.ContinuousConvOracle(I, O, D, radius=1.0, agg=agg)
+    layer = contconv.ContinuousConv(I, O, D, radius=1.0, agg=agg).cuda()
+    layer.load_state_dict(ora.state_dict())
+    ei = so.radius_graph(pos, 1.0, loop=True, max_num_neighbors=32)
+    fr = feat.clone().requires_grad_()
+    torch.tanh(ora(pos, fr, ei)).backward(dout)
+    # caller-supplied edge list (by-source CSR built by nbd_csr_by_key_i64)
+    fg = feat.clone().cuda().requires_grad_()
+    out = layer(pos.cuda(), fg, edge_index=ei.cuda(), act="tanh")
+    out.backward(dout.cuda())
+    assert global_rel(fg.grad.cpu(), fr.grad) < TOL
+    assert global_rel(layer.filters.grad.cpu(), ora.filters.grad) < TOL
+    # the radius search's own lists (what the model uses)
+    g1 = layer.filters.grad.clone()
+    layer.filters.grad = None
+    fg2 = feat.clone().cuda().requires_grad_()
+    lists = graphops.radius_lists(pos.cuda(), 1.0, None, loop=True, max_num_neighbors=32)
+    layer(pos.cuda(), fg2, lists=lists, act="tanh").backward(dout.cuda())
+    assert global_rel(fg2.grad.cpu(), fr.grad) < TOL and global_rel(layer.filters.grad.cpu(), ora.filters.grad) < TOL
+    assert torch.equal(g1, layer.filters.grad) or global_rel(g1.cpu(), layer.filters.grad.cpu()) < 1e-6
+
+
+CC_CFGS = [
+    dict(in_channels=4, out_channels=3, filter_resolution=[4, 3], radius=1.0, agg="mean", self_loops=True,
+         continuous_conv_layers=2, continuous_conv_dim=16, encoder_hiddens=[8, 12], decoder_hiddens=[10, 6]),
+    dict(in_channels=4, out_channels=3, filter_resolution=[5], radius=0.7, agg="sum", self_loops=False,
+         continuous_conv_layers=1, continuous_conv_dim=24),
+]
+
+
+@pytest.mark.parametrize("cfg", CC_CFGS)
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_contconv_model_gradients_match_oracle(cfg, mode, gpu_device):
+    """train: BatchNorm on batch statistics (+ running-stat update); eval: the reference's sticky eval mode
+    (train_graph_batch never calls train()), gradients through the frozen BatchNorm."""
+    import contconv
+    from nbd.data import Data
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(3)
+    ora = so.ContinuousConvModelOracle(**cfg)
+    if cfg.get("encoder_hiddens"):
+        with torch.no_grad():
+            for nrm in ora.node_encoder.norms:
+                nrm.module.running_mean.uniform_(-0.5, 0.5); nrm.module.running_var.uniform_(0.5, 2.0)
+                nrm.module.weight.uniform_(0.5, 1.5); nrm.module.bias.uniform_(-0.3, 0.3)
+    model = contconv.ContinuousConvModel(device="cuda", **cfg)
+    model.load_state_dict(ora.state_dict(), strict=True)
+    ora.train(mode == "train"); model.train(mode == "train")
+    n = 500
+    pos, vel, m = _plummer(n, 12)
+    x7 = torch.cat([pos, vel, m[:, None] * n], 1)
+    y = torch.randn(n, 3, generator=torch.Generator().manual_seed(1)) * 0.2
+    b = torch.cat([torch.full((s,), i, dtype=torch.int64) for i, s in enumerate([200, 300])])
+    pred = ora.forward_x(x7, batch=b)
+    lo = torch.sqrt(torch.nn.functional.mse_loss(pred, y))
+    lo.backward()
+    lg, mg = model.compute_loss(Data(x=x7.cuda(), batch=b.cuda(), y=y.cuda()))
+    lg.backward()
+    assert abs(lg.item() - lo.item()) < 1e-5 * lo.item()
+    ref = dict(ora.named_parameters())
+    for name, p in model.named_parameters():
+        r = ref[name].grad
+        assert p.grad is not None, name
+        # (the bias of a Linear feeding a training-mode BatchNorm has an exactly zero gradient: both sides
+        # hold rounding noise there, hence the absolute floor)
+        assert float((p.grad.cpu() - r).norm()) <= 2 * TOL * max(float(r.norm()), 1e-2 * lo.item()), (name, mode)
+    for (k, v), (k2, v2) in zip(model.state_dict().items(), ora.state_dict().items()):
+        if "running" in k or "num_batches" in k:
+            assert k == k2 and global_rel(v.cpu().float(), v2.float()) < TOL, k
+
+
+def test_contconv_training_follows_the_oracle(gpu_device):
+    import contconv
+    from nbd.data import Data
+    from oracle import galaxify_oracle as go
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(5)
+    cfg = CC_CFGS[0]
+    ora = so.ContinuousConvModelOracle(**cfg)
+    model = contconv.ContinuousConvModel(device="cuda", **cfg)
+    model.load_state_dict(ora.state_dict(), strict=True)
+    n = 300
+    pos, vel, m = _plummer(n, 2)
+    x7 = torch.cat([pos, vel, m[:, None] * n], 1)
+    y = go.accelerations(pos, m, 1.0, 0.1)
+    d = Data(x=x7.cuda(), batch=None, y=y.cuda())
+    opt_g = torch.optim.Adam(model.parameters(), lr=2e-3)
+    opt_o = torch.optim.Adam(ora.parameters(), lr=2e-3)
+    lg, lo = [], []
+    for _ in range(15):
+        lg.append(model.train_graph_batch(opt_g, d)[0])
+        opt_o.zero_grad()
+        l = torch.sqrt(torch.nn.functional.mse_loss(ora.forward_x(x7), y))
+        l.backward(); opt_o.step()
+        lo.append(l.item())
+    assert lg[-1] < 0.8 * lg[0]
+    assert max(abs(a - b) / b for a, b in zip(lg, lo)) < 5e-3
