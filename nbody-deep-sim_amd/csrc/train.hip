@@ -47,25 +47,41 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------ column sums (two stages)
-constexpr int kColRows = 128;     // rows per stage-1 block
+constexpr int kColRows = 512;     // rows per stage-1 block
+// stage 1: grid = (row blocks, 64-column groups); the block's 256 threads are 4 row phases x 64 columns
+// (coalesced 256-B reads); the 4 phase sums meet in LDS in fixed order.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ldx,
                                                              const float* __restrict__ w, int n, int c,
                                                              float* __restrict__ part) {
+  __shared__ float red[256];
   const int r0 = blockIdx.x * kColRows, r1 = min(r0 + kColRows, n);
-  for (int col = threadIdx.x; col < c; col += 256) {
-    float s = 0.f;
-    if (w) for (int r = r0; r < r1; ++r) s = __builtin_fmaf(w[r], x[(size_t)r * ldx + col], s);
-    else   for (int r = r0; r < r1; ++r) s += x[(size_t)r * ldx + col];
-    part[(size_t)blockIdx.x * c + col] = s;
+  const int col = blockIdx.y * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < c) {
+    if (w) for (int r = r0 + ph; r < r1; r += 4) s = __builtin_fmaf(w[r], x[(size_t)r * ldx + col], s);
+    else   for (int r = r0 + ph; r < r1; r += 4) s += x[(size_t)r * ldx + col];
   }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (ph == 0 && col < c)
+    part[(size_t)blockIdx.x * c + col] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
+// stage 2: thread = column (coalesced reads of each partial row); the loop over blocks is unrolled by
+// four independent accumulators so that the loads overlap -- still one fixed summation order
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int ldpart, int blocks,
                                                            int c, float* __restrict__ out) {
   const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= c) return;
-  float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += part[(size_t)b * ldpart + col];
-  out[col] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 4 <= blocks; b += 4) {
+    s0 += part[(size_t)b * ldpart + col];
+    s1 += part[(size_t)(b + 1) * ldpart + col];
+    s2 += part[(size_t)(b + 2) * ldpart + col];
+    s3 += part[(size_t)(b + 3) * ldpart + col];
+  }
+  for (; b < blocks; ++b) s0 += part[(size_t)b * ldpart + col];
+  out[col] = (s0 + s1) + (s2 + s3);
 }
 
 // ------------------------------------------------------------------ weight gradient: dW = G^T X
@@ -121,7 +137,8 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
 struct WgradPlan { int slabs, rows_per_slab; size_t ws; };
 WgradPlan plan_wgrad(int n, int m, int k) {
   const int tiles = ceil_div(m, WG_T) * ceil_div(k, WG_T);
-  int s = ceil_div(1024, tiles);
+  int s = ceil_div(512, tiles);
+  if (s > 32) s = 32;                                 // the fixed-order finish walks the slabs serially
   const int max_s = ceil_div(n, 2 * WG_R);            // >= 64 rows per slab
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -272,11 +289,13 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
                                                          const float* __restrict__ dy, int lddy,
                                                          const float* __restrict__ y, int ldy, int act,
                                                          float* __restrict__ part) {
+  __shared__ float red[2][256];
   const int r0 = blockIdx.x * kColRows, r1 = min(r0 + kColRows, n);
-  for (int col = threadIdx.x; col < c; col += 256) {
-    float s = 0.f, s2 = 0.f;
+  const int col = blockIdx.y * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  float s = 0.f, s2 = 0.f;
+  if (col < c) {
     const float mu = MODE ? mean[col] : 0.f, rs = MODE == 2 ? rstd[col] : 0.f;
-    for (int r = r0; r < r1; ++r) {
+    for (int r = r0 + ph; r < r1; r += 4) {
       const float v = x[(size_t)r * ldx + col];
       if (MODE == 0) s += v;
       if (MODE == 1) { const float d = v - mu; s = __builtin_fmaf(d, d, s); }
@@ -287,8 +306,16 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
         s2 += g;
       }
     }
-    if (MODE == 2) { part[(size_t)blockIdx.x * 2 * c + col] = s; part[(size_t)blockIdx.x * 2 * c + c + col] = s2; }
-    else part[(size_t)blockIdx.x * c + col] = s;
+  }
+  red[0][threadIdx.x] = s; red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (ph == 0 && col < c) {
+    const int t = threadIdx.x;
+    const float a = (red[0][t] + red[0][t + 64]) + (red[0][t + 128] + red[0][t + 192]);
+    if (MODE == 2) {
+      part[(size_t)blockIdx.x * 2 * c + col] = a;
+      part[(size_t)blockIdx.x * 2 * c + c + col] = (red[1][t] + red[1][t + 64]) + (red[1][t + 128] + red[1][t + 192]);
+    } else part[(size_t)blockIdx.x * c + col] = a;
   }
 }
 // out[col] = (sum_b part[b][col]) * scale; optionally also rstd = 1/sqrt(out + eps)
@@ -426,7 +453,7 @@ int nbd_colsum_f32(const float* x, int ldx, const float* rowweight, int n, int c
   const int blocks = ceil_div(n, kColRows);
   if (n > 0 && (!workspace || workspace_bytes < nbd_colsum_workspace_bytes(n, c))) return NBD_E_BADARG;
   float* part = static_cast<float*>(workspace);
-  if (n > 0) colsum_partial_kernel<<<blocks, 256, 0, st>>>(x, ldx, rowweight, n, c, part);
+  if (n > 0) colsum_partial_kernel<<<dim3(blocks, ceil_div(c, 64)), 256, 0, st>>>(x, ldx, rowweight, n, c, part);
   colsum_final_kernel<<<ceil_div(c, 256), 256, 0, st>>>(part, c, blocks, c, out);
   return status();
 }
@@ -491,9 +518,9 @@ int nbd_batchnorm_train_fwd_f32(const float* x, int ldx, int n, int c, const flo
   hipStream_t st = (hipStream_t)stream;
   float* part = static_cast<float*>(workspace);
   const int blocks = ceil_div(n, kColRows), cb = ceil_div(c, 256);
-  bn_partial_kernel<0><<<blocks, 256, 0, st>>>(x, ldx, n, c, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, part);
+  bn_partial_kernel<0><<<dim3(blocks, ceil_div(c, 64)), 256, 0, st>>>(x, ldx, n, c, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, part);
   bn_final_kernel<<<cb, 256, 0, st>>>(part, c, blocks, c, 1.0f / (float)n, mean, 0.f, nullptr);
-  bn_partial_kernel<1><<<blocks, 256, 0, st>>>(x, ldx, n, c, mean, nullptr, nullptr, 0, nullptr, 0, 0, part);
+  bn_partial_kernel<1><<<dim3(blocks, ceil_div(c, 64)), 256, 0, st>>>(x, ldx, n, c, mean, nullptr, nullptr, 0, nullptr, 0, 0, part);
   bn_final_kernel<<<cb, 256, 0, st>>>(part, c, blocks, c, 1.0f / (float)n, var, eps, rstd);
   const size_t total = (size_t)n * c;
   bn_apply_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(x, ldx, n, c, mean, rstd, gamma, beta, act, y, ldy);
@@ -511,7 +538,7 @@ int nbd_batchnorm_train_bwd_f32(const float* x, int ldx, int n, int c, const flo
   hipStream_t st = (hipStream_t)stream;
   float* part = static_cast<float*>(workspace);
   const int blocks = ceil_div(n, kColRows), cb = ceil_div(c, 256);
-  bn_partial_kernel<2><<<blocks, 256, 0, st>>>(x, ldx, n, c, mean, rstd, dy, lddy, y, ldy, act, part);
+  bn_partial_kernel<2><<<dim3(blocks, ceil_div(c, 64)), 256, 0, st>>>(x, ldx, n, c, mean, rstd, dy, lddy, y, ldy, act, part);
   bn_final_kernel<<<cb, 256, 0, st>>>(part, 2 * c, blocks, c, 1.0f, dgamma, 0.f, nullptr);
   bn_final_kernel<<<cb, 256, 0, st>>>(part + c, 2 * c, blocks, c, 1.0f, dbeta, 0.f, nullptr);
   const size_t total = (size_t)n * c;
