@@ -333,11 +333,11 @@ class GraphModel(torch.nn.Module):
         ei = data.edge_index
         reg = getattr(data, "_regular_k", None)
         if reg is not None and n * reg == ei.shape[1]:
-            return ag.EdgeLists(n, None, ei[0].contiguous(), reg)
+            return ag.EdgeLists(n, None, ei[0].contiguous(), reg, tgt=ei[1].contiguous())
         cached = getattr(data, "_edge_lists", None)
         if cached is None or cached.n != n:
-            rowptr, src = graphops.csr_by_target(ei, n)
-            cached = ag.EdgeLists(n, rowptr, src, -1)
+            rowptr, src, tgt = graphops.csr_by_target(ei, n, return_tgt=True)
+            cached = ag.EdgeLists(n, rowptr, src, -1, tgt=tgt)
             try:
                 data._edge_lists = cached      # the graph of a batch does not change between epochs
             except AttributeError:

@@ -19,11 +19,10 @@ class EdgeLists:
     """The edges of one batch in the two groupings the kernels gather over: by target (forward and dP)
     and by source (dQ). The by-source lists are built on first use and cached."""
 
-    def __init__(self, n, rowptr, src, fixed_k, edge_index=None):
+    def __init__(self, n, rowptr, src, fixed_k, tgt=None):
         self.n, self.rowptr, self.src, self.fixed_k = n, rowptr, src, fixed_k
-        self._edge_index = edge_index
         self._by_source = None
-        self._tgt = None
+        self._tgt = tgt             # int64 [E] targets in by-target order, when the caller has them (no sync)
 
     def targets(self):
         """int64 [E] target index of every edge, in by-target order."""
@@ -38,7 +37,7 @@ class EdgeLists:
 
     def by_source(self):
         if self._by_source is None:
-            self._by_source = graphops.csr_by_key(self.src, self.targets(), self.n)
+            self._by_source = graphops.csr_by_key(self.src, self.targets(), self.n, validate=False)
         return self._by_source
 
     def csr_rowptr(self):
@@ -119,7 +118,8 @@ class EdgeMessagesFn(Function):
         dpq = torch.empty((n, 2 * h), dtype=torch.float32, device=m.device)
         nnops.segment_reduce(dpre, lists.csr_rowptr(), n, "sum", out=dpq[:, :h])
         e = lists.src.numel()
-        rowptr_e, edge_ids = graphops.csr_by_key(lists.src, torch.arange(e, device=m.device, dtype=torch.int64), n)
+        rowptr_e, edge_ids = graphops.csr_by_key(lists.src, torch.arange(e, device=m.device, dtype=torch.int64), n,
+                                                validate=False)
         nnops.segment_reduce(dpre.index_select(0, edge_ids.to(torch.int64)), rowptr_e, n, "sum", out=dpq[:, h:])
         return dpq, None, None
 

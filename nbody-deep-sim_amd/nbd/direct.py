@@ -46,7 +46,7 @@ def pack_posm(pos: torch.Tensor, mass: torch.Tensor, out: torch.Tensor | None = 
     if out is None:
         out = alloc_posm(n, pos.device)
     _chk(out, (padded_len(n), 4), "posm")
-    with torch.cuda.device(pos.device):
+    with _lib.on_device(pos.device):
         _lib.check(_lib.lib().nbd_pack_posm_f32(pos.data_ptr(), mass.data_ptr(), n, out.data_ptr(),
                                                 _lib.current_stream(pos.device)), "nbd_pack_posm_f32")
     return out
@@ -71,7 +71,7 @@ def accel(posm_src: torch.Tensor, n_src: int, posm_tgt: torch.Tensor, n_tgt: int
     need = _lib.lib().nbd_accel_workspace_bytes(n_src, n_tgt)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = alloc_bytes(need, dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.lib().nbd_accel_f32(
             posm_src.data_ptr() if n_src > 0 else None, n_src, posm_tgt.data_ptr(), n_tgt, tgt_offset,
             float(softening_sq), float(g_const), out.data_ptr(), workspace.data_ptr(),
@@ -102,7 +102,7 @@ def kick_drift(pos, vel, acc, mass, c_kick: float, c_drift: float, posm=None) ->
         _chk(mass, (n,), "mass")
         if posm.dtype != torch.float32 or not posm.is_contiguous() or posm.shape[0] < padded_len(n):
             raise _lib.NbdError("posm: need contiguous fp32 (>= padded_len(n), 4)")
-    with torch.cuda.device(pos.device):
+    with _lib.on_device(pos.device):
         _lib.check(_lib.lib().nbd_kick_drift_f32(pos.data_ptr(), vel.data_ptr(), _lib.ptr(acc),
                                                  _lib.ptr(mass), n, c_kick, c_drift, _lib.ptr(posm),
                                                  _lib.current_stream(pos.device)), "nbd_kick_drift_f32")
@@ -111,7 +111,7 @@ def kick_drift(pos, vel, acc, mass, c_kick: float, c_drift: float, posm=None) ->
 def kick(vel, acc, c: float) -> None:
     n = vel.shape[0]
     _chk(vel, (n, 3), "vel"); _chk(acc, (n, 3), "acc")
-    with torch.cuda.device(vel.device):
+    with _lib.on_device(vel.device):
         _lib.check(_lib.lib().nbd_kick_f32(vel.data_ptr(), acc.data_ptr(), n, c,
                                            _lib.current_stream(vel.device)), "nbd_kick_f32")
 
@@ -119,7 +119,7 @@ def kick(vel, acc, c: float) -> None:
 def drift(pos, vel, c: float) -> None:
     n = pos.shape[0]
     _chk(pos, (n, 3), "pos"); _chk(vel, (n, 3), "vel")
-    with torch.cuda.device(pos.device):
+    with _lib.on_device(pos.device):
         _lib.check(_lib.lib().nbd_drift_f32(pos.data_ptr(), vel.data_ptr(), n, c,
                                             _lib.current_stream(pos.device)), "nbd_drift_f32")
 
@@ -132,7 +132,7 @@ def leapfrog_step(pos, vel, acc_in, acc_out, mass, dt_half: float, dt: float, so
     for t, nm in ((pos, "pos"), (vel, "vel"), (acc_in, "acc_in"), (acc_out, "acc_out")):
         _chk(t, (n, 3), nm)
     _chk(mass, (n,), "mass"); _chk(posm, (padded_len(n), 4), "posm")
-    with torch.cuda.device(pos.device):
+    with _lib.on_device(pos.device):
         _lib.check(_lib.lib().nbd_leapfrog_step_ev_f32(
             pos.data_ptr(), vel.data_ptr(), acc_in.data_ptr(), acc_out.data_ptr(), mass.data_ptr(), n,
             dt_half, dt, softening_sq, g_const, posm.data_ptr(), workspace.data_ptr(), _nbytes(workspace),
@@ -147,7 +147,7 @@ def euler_step(pos, vel, acc_out, mass, dt: float, softening_sq: float, g_const:
     for t, nm in ((pos, "pos"), (vel, "vel"), (acc_out, "acc_out")):
         _chk(t, (n, 3), nm)
     _chk(mass, (n,), "mass"); _chk(posm, (padded_len(n), 4), "posm")
-    with torch.cuda.device(pos.device):
+    with _lib.on_device(pos.device):
         _lib.check(_lib.lib().nbd_euler_step_f32(
             pos.data_ptr(), vel.data_ptr(), acc_out.data_ptr(), mass.data_ptr(), n, dt, softening_sq,
             g_const, posm.data_ptr(), workspace.data_ptr(), _nbytes(workspace),
@@ -164,7 +164,7 @@ def energy(posm, vel, n: int, softening: float, g_const: float, out_uk=None, wor
     need = _lib.lib().nbd_energy_workspace_bytes(n)
     if workspace is None or _nbytes(workspace) < need:
         workspace = alloc_bytes(need, dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.lib().nbd_energy_f32(posm.data_ptr(), vel.data_ptr(), n, softening, g_const,
                                              out_uk.data_ptr(), workspace.data_ptr(), _nbytes(workspace),
                                              _lib.current_stream(dev)), "nbd_energy_f32")

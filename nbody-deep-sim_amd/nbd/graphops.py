@@ -19,19 +19,25 @@ def _stream(dev):
 
 
 def _segments(batch: torch.Tensor | None, n: int, device):
-    """Per-node [lo, hi) of its batch segment (batch must be sorted, as PyG requires)."""
+    """Per-node [lo, hi) of its batch segment (batch must be sorted, as PyG requires). No host sync when
+    the vector is known to be sorted (built by nbd.data.collate, or seen before): the bounds are two
+    binary searches of the vector in itself, remembered on the tensor object."""
     if batch is None:
         return None, None
     if batch.numel() != n:
         raise _lib.NbdError(f"batch has {batch.numel()} entries for {n} nodes")
+    memo = getattr(batch, "_nbd_segments", None)
+    if memo is not None and memo[0] == batch._version and memo[1].device == torch.device(device):
+        return memo[1], memo[2]
     b = batch.to(device=device, dtype=torch.int64).contiguous()
-    if n > 1 and bool((b[1:] < b[:-1]).any()):
+    if not getattr(batch, "_nbd_sorted", False) and n > 1 and bool((b[1:] < b[:-1]).any()):   # one sync, first sight only
         raise _lib.NbdError("batch vector must be sorted (PyG convention)")
-    uniq, counts = torch.unique_consecutive(b, return_counts=True)
-    ends = torch.cumsum(counts, 0)
-    starts = ends - counts
-    lo = torch.repeat_interleave(starts, counts).to(torch.int32).contiguous()
-    hi = torch.repeat_interleave(ends, counts).to(torch.int32).contiguous()
+    lo = torch.searchsorted(b, b, right=False).to(torch.int32).contiguous()
+    hi = torch.searchsorted(b, b, right=True).to(torch.int32).contiguous()
+    try:
+        batch._nbd_segments = (batch._version, lo, hi)
+    except (AttributeError, RuntimeError):
+        pass
     return lo, hi
 
 
@@ -54,9 +60,10 @@ def knn_graph(x: torch.Tensor, k: int, batch: torch.Tensor | None = None, loop: 
         e = int(per.sum().item())
     ei = torch.empty((2, e), dtype=torch.int64, device=dev)
     if e:
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(_lib.lib().nbd_knn_graph_f32(pos.data_ptr(), n, k, int(loop), _lib.ptr(lo), _lib.ptr(hi),
                                                     _lib.ptr(off), e, ei.data_ptr(), _stream(dev)), "nbd_knn_graph_f32")
+    ei._nbd_grouped = True        # edges come out grouped by centre (row 1 ascending): csr_by_target need not check
     return ei
 
 
@@ -91,7 +98,7 @@ def radius_lists(pos: torch.Tensor, r: float, batch=None, loop: bool = False, ma
     r2 = radius_r2(r)
     L, st = _lib.lib(), _stream(dev)
     rowptr = centres = None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         if not transpose:
             _lib.check(L.nbd_radius_search_f32(pos.data_ptr(), n, r2, int(loop), cap, _lib.ptr(lo), _lib.ptr(hi),
                                                nbr.data_ptr(), deg.data_ptr(), last.data_ptr(), None, st),
@@ -122,7 +129,7 @@ def radius_graph(x: torch.Tensor, r: float, batch=None, loop: bool = False, max_
     n, dev = lists.n, x.device
     ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
     L, st = _lib.lib(), _stream(dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(L.nbd_exclusive_scan_i32(lists.deg.data_ptr(), n, ptr.data_ptr(), st), "exclusive_scan")
         e = int(ptr[n].item()) if n else 0
         ei = torch.empty((2, e), dtype=torch.int64, device=dev)
@@ -132,21 +139,24 @@ def radius_graph(x: torch.Tensor, r: float, batch=None, loop: bool = False, max_
     return ei
 
 
-def csr_by_target(edge_index: torch.Tensor, n: int):
+def csr_by_target(edge_index: torch.Tensor, n: int, return_tgt: bool = False):
     """(rowptr int32 [n+1], src int64 [E]) for edges grouped by edge_index[1]; already-grouped input
-    (what knn_graph / PyG produce) is used as is, anything else is stably sorted first."""
+    (what knn_graph / PyG produce) is used as is, anything else is stably sorted first. With
+    return_tgt also the target of every edge in that order."""
     tgt = edge_index[1]
     src = edge_index[0]
-    if tgt.numel() > 1 and bool((tgt[1:] < tgt[:-1]).any()):
+    if not getattr(edge_index, "_nbd_grouped", False) and tgt.numel() > 1 and bool((tgt[1:] < tgt[:-1]).any()):
         order = torch.sort(tgt, stable=True).indices
         tgt, src = tgt[order], src[order]
     counts = torch.bincount(tgt, minlength=n)
     rowptr = torch.zeros(n + 1, dtype=torch.int32, device=edge_index.device)
     rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    if return_tgt:
+        return rowptr, src.contiguous(), tgt.contiguous()
     return rowptr, src.contiguous()
 
 
-def csr_by_key(key: torch.Tensor, val: torch.Tensor, n: int):
+def csr_by_key(key: torch.Tensor, val: torch.Tensor, n: int, validate: bool = True):
     """(rowptr int32 [n+1], vals int32 [E]): the edge list grouped by `key`, each group's `val`s ascending.
     csr_by_key(edge_index[0], edge_index[1], n) is the adjacency transposed (targets of each source)."""
     if key.dtype != torch.int64 or val.dtype != torch.int64 or key.shape != val.shape or key.dim() != 1:
@@ -160,10 +170,10 @@ def csr_by_key(key: torch.Tensor, val: torch.Tensor, n: int):
     scratch = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
     out = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
     bad = torch.empty(1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.lib().nbd_csr_by_key_i64(key.data_ptr(), val.data_ptr(), e, n, rowptr.data_ptr(),
                                                  cursor.data_ptr(), scratch.data_ptr(), out.data_ptr(), bad.data_ptr(),
                                                  _lib.current_stream(dev)), "nbd_csr_by_key_i64")
-    if int(bad.item()):
+    if validate and int(bad.item()):      # one host sync; out-of-range keys are skipped by the kernels either way
         raise _lib.NbdError(f"csr_by_key: an index lies outside [0, {n})")
     return rowptr, out[:e]

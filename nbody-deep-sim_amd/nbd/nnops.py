@@ -41,7 +41,7 @@ def linear(x, w, bias=None, act=None, out=None, rowscale=None, bias_rowscale=Non
     ldy = _mat(out, "out")
     need = _lib.lib().nbd_linear_workspace_bytes(n, m, k)
     ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(_lib.lib().nbd_linear_f32(x.data_ptr(), ldx, w.data_ptr(), ldw, _vec(bias, m, "bias"),
                                              _vec(rowscale, n, "rowscale"), _vec(bias_rowscale, n, "bias_rowscale"),
                                              ACT[act], out.data_ptr(), ldy, n, m, k, _lib.ptr(ws), need,
@@ -64,7 +64,7 @@ def edgeconv_aggregate(pq, h, rowptr, src, fixed_k, aggr, out=None):
     n_edges = 0 if src is None else src.numel()
     if rowptr is None and n * fixed_k != n_edges:
         raise _lib.NbdError(f"fixed_k={fixed_k} x n={n} != {n_edges} edges")
-    with torch.cuda.device(pq.device):
+    with _lib.on_device(pq.device):
         _lib.check(_lib.lib().nbd_edgeconv_aggregate_f32(pq.data_ptr(), ld, h, _lib.ptr(rowptr), _lib.ptr(src),
                                                          fixed_k, n, AGGR[aggr], out.data_ptr(), ldo,
                                                          _lib.current_stream(pq.device)), "nbd_edgeconv_aggregate_f32")
@@ -79,7 +79,7 @@ def edge_messages(pq, h, src, tgt):
     for t in (src, tgt):
         if t.dtype != torch.int64 or not t.is_contiguous() or t.numel() != e:
             raise _lib.NbdError("src/tgt must be contiguous int64 of equal length")
-    with torch.cuda.device(pq.device):
+    with _lib.on_device(pq.device):
         _lib.check(_lib.lib().nbd_edge_messages_f32(pq.data_ptr(), ld, h, src.data_ptr(), tgt.data_ptr(), e,
                                                     m.data_ptr(), h, _lib.current_stream(pq.device)),
                    "nbd_edge_messages_f32")
@@ -90,7 +90,7 @@ def segment_reduce(m, rowptr, n, mode, out=None):
     h = m.shape[1]
     if out is None:
         out = torch.empty((n, h), dtype=torch.float32, device=m.device)
-    with torch.cuda.device(m.device):
+    with _lib.on_device(m.device):
         _lib.check(_lib.lib().nbd_segment_reduce_f32(m.data_ptr(), _mat(m, "m") if m.shape[0] else h, h,
                                                      rowptr.data_ptr(), n, AGGR[mode], out.data_ptr(), _mat(out, "out"),
                                                      _lib.current_stream(m.device)), "nbd_segment_reduce_f32")
@@ -103,7 +103,7 @@ def layernorm(x, gamma, beta, eps, out=None):
     if out is None:
         out = torch.empty((n, c), dtype=torch.float32, device=x.device)
     ldy = _mat(out, "out")
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(_lib.lib().nbd_layernorm_f32(x.data_ptr(), ldx, c, _vec(gamma, c, "gamma"), _vec(beta, c, "beta"),
                                                 float(eps), out.data_ptr(), ldy, n,
                                                 _lib.current_stream(x.device)), "nbd_layernorm_f32")
@@ -127,7 +127,7 @@ def contconv_bin(pos, feat, rowptr, centres, d, radius_sq, out=None, node_begin=
         out = torch.empty((count, kc), dtype=torch.float32, device=feat.device)
     if out.dim() != 2 or out.shape[0] < count or out.shape[1] != kc or not out.is_contiguous():
         raise _lib.NbdError(f"A must be contiguous (>= {count}, {kc})")
-    with torch.cuda.device(feat.device):
+    with _lib.on_device(feat.device):
         _lib.check(_lib.lib().nbd_contconv_bin_f32(pos.data_ptr(), feat.data_ptr(), ldf, i_ch, rowptr.data_ptr(),
                                                    centres.data_ptr(), node_begin, count, d, float(radius_sq),
                                                    out.data_ptr(), _lib.current_stream(feat.device)),
@@ -137,7 +137,7 @@ def contconv_bin(pos, feat, rowptr, centres, d, radius_sq, out=None, node_begin=
 
 def degree_scale(rowptr, n, mode, device):
     out = torch.empty(n, dtype=torch.float32, device=device)
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         _lib.check(_lib.lib().nbd_degree_scale_f32(rowptr.data_ptr(), n, mode, out.data_ptr(),
                                                    _lib.current_stream(device)), "nbd_degree_scale_f32")
     return out
@@ -171,7 +171,7 @@ def gnn_layer(*, n, h, aggr, rowptr, src, fixed_k, w2t, b2, epilogue, out, pq=No
     a.enc, a.ldenc, a.e = _lib.ptr(enc), (_mat(enc, "enc") if enc is not None else 0), e
     a.ln_g, a.ln_b, a.ln_eps = _lib.ptr(ln_g), _lib.ptr(ln_b), float(ln_eps)
     a.out, a.ldout = out.data_ptr(), _mat(out, "out")
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.lib().nbd_gnn_layer_f32(ctypes.byref(a), _lib.current_stream(dev)), "nbd_gnn_layer_f32")
     return True
 
@@ -185,7 +185,7 @@ def act_bwd(dy, y, act, rowscale=None):
     """rowscale * dy * act'(y) with y the forward output (tanh: 1 - y^2)."""
     n, c = dy.shape
     g = torch.empty((n, c), dtype=torch.float32, device=dy.device)
-    with torch.cuda.device(dy.device):
+    with _lib.on_device(dy.device):
         _lib.check(_lib.lib().nbd_act_bwd_f32(dy.data_ptr(), _mat(dy, "dy"), y.data_ptr() if y is not None else None,
                                               _mat(y, "y") if y is not None else 0, ACT[act],
                                               _vec(rowscale, n, "rowscale"), g.data_ptr(), c, n, c,
@@ -198,7 +198,7 @@ def colsum(x, rowweight=None):
     out = torch.empty(c, dtype=torch.float32, device=x.device)
     need = _lib.lib().nbd_colsum_workspace_bytes(n, c)
     ws = _ws(need, x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(_lib.lib().nbd_colsum_f32(x.data_ptr(), _mat(x, "x") if n else c, _vec(rowweight, n, "rowweight"),
                                              n, c, out.data_ptr(), _lib.ptr(ws), need,
                                              _lib.current_stream(x.device)), "nbd_colsum_f32")
@@ -214,7 +214,7 @@ def linear_wgrad(g, x):
     dw = torch.empty((m, k), dtype=torch.float32, device=g.device)
     need = _lib.lib().nbd_linear_wgrad_workspace_bytes(n, m, k)
     ws = _ws(need, g.device)
-    with torch.cuda.device(g.device):
+    with _lib.on_device(g.device):
         _lib.check(_lib.lib().nbd_linear_wgrad_f32(g.data_ptr(), _mat(g, "g") if n else m, x.data_ptr(),
                                                    _mat(x, "x") if n else k, n, m, k, dw.data_ptr(), k, _lib.ptr(ws),
                                                    need, _lib.current_stream(g.device)), "nbd_linear_wgrad_f32")
@@ -226,7 +226,7 @@ def edgeconv_aggregate_bwd(pq, h, ds, rowptr, src, fixed_k, rowptr_t, tgt_t, agg
     dpq = torch.empty((n, 2 * h), dtype=torch.float32, device=pq.device)
     if rowptr_t.dtype != torch.int32 or rowptr_t.numel() != n + 1 or tgt_t.dtype != torch.int32:
         raise _lib.NbdError("rowptr_t int32 [n+1] / tgt_t int32 required")
-    with torch.cuda.device(pq.device):
+    with _lib.on_device(pq.device):
         _lib.check(_lib.lib().nbd_edgeconv_aggregate_bwd_f32(
             pq.data_ptr(), _mat(pq, "pq"), h, ds.data_ptr(), _mat(ds, "ds"), _lib.ptr(rowptr), _lib.ptr(src), fixed_k,
             rowptr_t.data_ptr(), _lib.ptr(tgt_t), n, AGGR[aggr], dpq.data_ptr(), 2 * h,
@@ -241,7 +241,7 @@ def layernorm_bwd(x, gamma, eps, dy):
     db = torch.empty(c, dtype=torch.float32, device=x.device)
     need = _lib.lib().nbd_layernorm_bwd_workspace_bytes(n, c)
     ws = _ws(need, x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         _lib.check(_lib.lib().nbd_layernorm_bwd_f32(x.data_ptr(), _mat(x, "x") if n else c, c, _vec(gamma, c, "gamma"),
                                                     float(eps), dy.data_ptr(), _mat(dy, "dy") if n else c,
                                                     dx.data_ptr(), c, dg.data_ptr(), db.data_ptr(), n, _lib.ptr(ws),
@@ -253,7 +253,7 @@ def segment_max_bwd(m, x, rowptr, dx):
     e, h = m.shape
     n = x.shape[0]
     dm = torch.empty((e, h), dtype=torch.float32, device=m.device)
-    with torch.cuda.device(m.device):
+    with _lib.on_device(m.device):
         _lib.check(_lib.lib().nbd_segment_max_bwd_f32(m.data_ptr(), _mat(m, "m") if e else h, h, x.data_ptr(),
                                                       _mat(x, "x"), rowptr.data_ptr(), n, dx.data_ptr(), _mat(dx, "dx"),
                                                       dm.data_ptr(), h, _lib.current_stream(m.device)),
@@ -271,7 +271,7 @@ def batchnorm_train_fwd(x, gamma, beta, eps, act):
     mean, var, rstd = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(3))
     need = _lib.lib().nbd_batchnorm_train_workspace_bytes(n, c)
     ws = _ws(need, dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.lib().nbd_batchnorm_train_fwd_f32(x.data_ptr(), _mat(x, "x"), n, c, _vec(gamma, c, "gamma"),
                                                           _vec(beta, c, "beta"), float(eps), ACT[act], y.data_ptr(), c,
                                                           mean.data_ptr(), var.data_ptr(), rstd.data_ptr(),
@@ -287,7 +287,7 @@ def batchnorm_train_bwd(x, gamma, mean, rstd, act, y, dy):
     dg, db = torch.empty(c, dtype=torch.float32, device=dev), torch.empty(c, dtype=torch.float32, device=dev)
     need = _lib.lib().nbd_batchnorm_train_workspace_bytes(n, c)
     ws = _ws(need, dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(_lib.lib().nbd_batchnorm_train_bwd_f32(x.data_ptr(), _mat(x, "x"), n, c, _vec(gamma, c, "gamma"),
                                                           mean.data_ptr(), rstd.data_ptr(), ACT[act], y.data_ptr(),
                                                           _mat(y, "y"), dy.data_ptr(), _mat(dy, "dy"), dx.data_ptr(), c,
@@ -305,7 +305,7 @@ def contconv_bin_bwd(pos, da, i_ch, d, radius_sq, rowptr_s=None, tgt_s=None, deg
         if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
             raise _lib.NbdError("contconv_bin_bwd: index lists must be contiguous int32")
     dfeat = torch.empty((n, i_ch), dtype=torch.float32, device=pos.device)
-    with torch.cuda.device(pos.device):
+    with _lib.on_device(pos.device):
         _lib.check(_lib.lib().nbd_contconv_bin_bwd_f32(pos.data_ptr(), da.data_ptr(), i_ch, _lib.ptr(rowptr_s),
                                                        tgt_s.data_ptr(), _lib.ptr(deg), cap, n, d, float(radius_sq),
                                                        dfeat.data_ptr(), i_ch, _lib.current_stream(pos.device)),

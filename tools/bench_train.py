@@ -30,7 +30,20 @@ def make_batch(n_graphs, k, seed=0):
         ei = graphops.knn_graph(x[:, :3].contiguous(), k=k, loop=False) if k > 0 else \
             torch.zeros((2, 0), dtype=torch.int64, device="cuda")
         graphs.append(Data(x=x, edge_index=ei, y=sim.accelerations.clone()))
-    return collate(graphs)
+    return graphs
+
+
+class Batches:
+    """What the reference's DataLoader does per step: a fresh collate of the (rotated) graph list, so
+    nothing derived from a batch (CSR, transposed adjacency) survives from one step to the next."""
+
+    def __init__(self, graphs):
+        self.graphs, self.i = graphs, 0
+
+    def next(self):
+        self.i += 1
+        r = self.i % len(self.graphs)
+        return collate(self.graphs[r:] + self.graphs[:r])
 
 
 def time_steps(step, iters, warm=3):
@@ -53,8 +66,9 @@ def main():
     model = gnn.GraphModel(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", neighbors=10, device="cuda",
                            scale_factor=1e6)
     opt = torch.optim.Adam(model.parameters(), lr=0.01)
-    data = make_batch(64, 10)
-    ms = time_steps(lambda: model.train_graph_batch(opt, data), iters)
+    loader = Batches(make_batch(64, 10))
+    ms = time_steps(lambda: model.train_graph_batch(opt, loader.next()), iters)
+    data = loader.next()
     model.eval()
     with torch.no_grad():
         fwd = time_steps(lambda: model.forward(data), iters)
@@ -83,8 +97,9 @@ def main():
                                           encoder_hiddens=[32, 64], decoder_hiddens=[64, 32], device="cuda",
                                           scale_factor=1e6)
     copt = torch.optim.Adam(cmodel.parameters(), lr=0.01)
-    cdata = make_batch(16, 0, seed=100)
-    cms = time_steps(lambda: cmodel.train_graph_batch(copt, cdata), iters)
+    cloader = Batches(make_batch(16, 0, seed=100))
+    cms = time_steps(lambda: cmodel.train_graph_batch(copt, cloader.next()), iters)
+    cdata = cloader.next()
     out["contconv"] = {"nodes": int(cdata.x.shape[0]), "train_step_ms": cms, "batch_graphs": 16}
     if cpu:
         from oracle import surrogate_oracle as so
