@@ -195,6 +195,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_surrogates
         out["secondary"] = bench_surrogates.run(10)
+        import bench_train          # ms per training step at the reference's batch sizes
+        out["secondary"]["training"] = bench_train.run(10)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

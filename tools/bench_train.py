@@ -57,9 +57,7 @@ def time_steps(step, iters, warm=3):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
-def main():
-    iters = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
-    cpu = "--cpu" in sys.argv
+def run(iters=20, cpu=False):
     out = {}
     torch.manual_seed(0)
     # ---- GNN
@@ -118,8 +116,8 @@ def main():
         for _ in range(2):
             ccpu_step()
         out["contconv"]["cpu_oracle_train_step_ms"] = (time.perf_counter() - t0) / 2 * 1e3
-    print(json.dumps(out))
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20, "--cpu" in sys.argv)))
