@@ -142,6 +142,29 @@ def main():
     k_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
     assert torch.isfinite(sim.positions).all()
 
+    # BASELINE.json's metric string reads "N = 65 536 ... 1/2/4/8 MI355X": next to the weak series above
+    # (fixed bodies per GPU, configs[4] at 8 GPUs), time the SAME 65 536-body problem split over all ranks.
+    strong_leg = None
+    if world > 1 and not strong:
+        n_s = args.particles_per_gpu
+        p2, v2, m2 = generate_plummer(n_s, seed=args.seed)
+        sim2 = simulation.LeapFrogSimulator(positions=p2, velocities=v2, masses=m2, g_const=1.0, softening=0.1,
+                                            dt=0.01, calc_energy=False, device="cuda", process_group=group)
+        for _ in range(args.warmup):
+            sim2.step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            sim2.step()
+        barrier()
+        el2 = time.perf_counter() - t1
+        t = torch.tensor([el2], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el2 = t.item()
+        strong_leg = {"n_particles": n_s, "value": float(n_s) * float(n_s) * args.steps / el2,
+                      "unit": "pair-interactions/s", "ms_per_step": el2 / args.steps * 1e3, "scaling": "strong",
+                      "note": "same run, the single-GPU problem size split over all ranks (one all-gather per step)"}
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -185,6 +208,8 @@ def main():
                     "is 2 pairs/clk/SIMD = 62% of this peak at 2.4 GHz",
         },
     }
+    if strong_leg is not None:
+        out["strong_scaling_n65536"] = strong_leg
     if args.cpu_seconds > 0 and world == 1:
         threads = min(len(os.sched_getaffinity(0)), 16)
         out["cpu_baseline"] = cpu_baseline(min(n_total, 65536), args.seed, args.cpu_seconds, threads)
