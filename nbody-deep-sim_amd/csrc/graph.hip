@@ -268,6 +268,139 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_kernel(
   if (lane == 0) { deg[i] = count; last[i] = last_j; }
 }
 
+// ---- radius search, streaming form: lane = centre, sources broadcast from LDS (the structure of the
+// all-pairs force kernel). A wave owns 64 centres and ONE slice of the source range, walks it in
+// ascending index and appends each hit to its centre's slice-local list (at most `cap` kept: the final
+// list is the first `cap` hits overall, so no slice ever contributes more). radius_merge_kernel then
+// concatenates the slices in order. The distance test is the same rounded expression as dist2().
+// bits (31 - u) for the sources j = base + u, u in [0, 32), that satisfy lo <= j < hi and j != self
+__device__ __forceinline__ unsigned valid_bits(int base, int lo, int hi, int self) {
+  const int a = max(lo - base, 0), b = min(hi - base, 32);           // u in [a, b)
+  if (a >= b) return 0u;
+  unsigned m = (0xffffffffu >> a) & (b >= 32 ? 0xffffffffu : ~(0xffffffffu >> b));
+  const int su = self - base;
+  if (su >= 0 && su < 32) m &= ~(0x80000000u >> su);
+  return m;
+}
+
+template <bool BATCH>
+__global__ __launch_bounds__(256) void radius_stream_kernel(
+    const float* __restrict__ pos, int n, float r2, int loop, int cap, const int* __restrict__ seg_lo,
+    const int* __restrict__ seg_hi, int n_slices, int slice_len, int* __restrict__ tmp_list,
+    int* __restrict__ tmp_cnt) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  __shared__ f4 stage[kWavesPerBlock][64];
+  const int w = wave_id(), lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * kWavesPerBlock + w;
+  const int group = gw / n_slices, slice = gw - group * n_slices;
+  if (group * 128 >= n) return;
+  // two centres per lane (ia, ib = ia + 64): one LDS broadcast of a source feeds both
+  const int ia = group * 128 + lane, ib = ia + 64;
+  const bool va = ia < n, vb = ib < n;
+  float xa = 0.f, ya = 0.f, za = 0.f, xb = 0.f, yb = 0.f, zb = 0.f;
+  int loa = 0, hia = 0, lob = 0, hib = 0;
+  if (va) { xa = pos[3 * ia]; ya = pos[3 * ia + 1]; za = pos[3 * ia + 2]; loa = BATCH ? seg_lo[ia] : 0; hia = BATCH ? seg_hi[ia] : n; }
+  if (vb) { xb = pos[3 * ib]; yb = pos[3 * ib + 1]; zb = pos[3 * ib + 2]; lob = BATCH ? seg_lo[ib] : 0; hib = BATCH ? seg_hi[ib] : n; }
+  int s0 = slice * slice_len, s1 = min(s0 + slice_len, n);
+  if (BATCH) {   // the wave scans the part of its slice that some lane's batch segment reaches
+    int wlo = min(va ? loa : 0x7fffffff, vb ? lob : 0x7fffffff), whi = max(va ? hia : 0, vb ? hib : 0);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { wlo = min(wlo, __shfl_xor(wlo, off)); whi = max(whi, __shfl_xor(whi, off)); }
+    s0 = max(s0, __builtin_amdgcn_readfirstlane(wlo) & ~63);
+    s1 = min(s1, __builtin_amdgcn_readfirstlane(whi));
+  }
+  f4* st = stage[w];
+  int ca = 0, cb = 0;
+  int* la = tmp_list + ((size_t)slice * n + (va ? ia : 0)) * cap;
+  int* lb = tmp_list + ((size_t)slice * n + (vb ? ib : 0)) * cap;
+  const int self_a = loop ? -1 : ia, self_b = loop ? -1 : ib;
+  const f2 xab = {xa, xb}, yab = {ya, yb}, zab = {za, zb};
+  // the chunk after the one being scanned is already on its way from HBM/L2 into registers
+  auto fetch = [&](int c0) {
+    const int j = c0 + lane;
+    f4 v = {__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f};
+    if (j < n) { v.x = pos[3 * j]; v.y = pos[3 * j + 1]; v.z = pos[3 * j + 2]; }
+    return v;
+  };
+  f4 next = {};
+  if (s0 < s1) next = fetch(s0);
+  for (int c0 = s0; c0 < s1; c0 += 64) {
+    __builtin_amdgcn_wave_barrier();
+    st[lane] = next;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (c0 + 64 < s1) next = fetch(c0 + 64);
+    // 32 sources at a time, branch-free: bit (31 - u) of a per-lane mask records "source u is inside the
+    // radius" (mask = 2 mask + hit, one shift-or per test); validity (batch segment, slice end, self) is
+    // applied to the whole mask afterwards, and only then do the lanes that hit anything append -- one
+    // wave-level branch per 32 sources instead of two per source.
+#pragma unroll 1
+    for (int jb = 0; jb < 64 && c0 + jb < s1; jb += 32) {
+      unsigned ma = 0u, mb = 0u;
+#pragma unroll 8
+      for (int u = 0; u < 32; ++u) {
+        const f4 sp = st[jb + u];                                // wave-uniform address: LDS broadcast
+        const f2 dx = f2{sp.x, sp.x} - xab, dy = f2{sp.y, sp.y} - yab, dz = f2{sp.z, sp.z} - zab;
+        const f2 d2 = (dx * dx + dy * dy) + dz * dz;             // -ffp-contract=off: rounded as dist2()
+        ma = (ma << 1) | (d2.x < r2 ? 1u : 0u);
+        mb = (mb << 1) | (d2.y < r2 ? 1u : 0u);
+      }
+      const int base = c0 + jb;
+      ma &= valid_bits(base, max(loa, 0), min(hia, s1), self_a);
+      mb &= valid_bits(base, max(lob, 0), min(hib, s1), self_b);
+      if (__builtin_amdgcn_ballot_w64((ma | mb) != 0u)) {
+        while (ma) {
+          const int u = __builtin_clz(ma);
+          ma &= ~(0x80000000u >> u);
+          if (ca < cap) la[ca] = base + u;
+          ++ca;
+        }
+        while (mb) {
+          const int u = __builtin_clz(mb);
+          mb &= ~(0x80000000u >> u);
+          if (cb < cap) lb[cb] = base + u;
+          ++cb;
+        }
+      }
+    }
+  }
+  if (va) tmp_cnt[(size_t)slice * n + ia] = min(ca, cap);
+  if (vb) tmp_cnt[(size_t)slice * n + ib] = min(cb, cap);
+}
+
+// one wave per centre: exclusive scan of its slice counts (lane = slice), then slot t of the final list
+// comes from the slice whose range holds t.
+__global__ __launch_bounds__(64 * kWavesPerBlock) void radius_merge_kernel(
+    const int* __restrict__ tmp_list, const int* __restrict__ tmp_cnt, int n, int n_slices, int cap,
+    int* __restrict__ nbr, int* __restrict__ deg, int* __restrict__ last, int* __restrict__ indeg) {
+  const int i = blockIdx.x * kWavesPerBlock + wave_id();
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int c = lane < n_slices ? tmp_cnt[(size_t)lane * n + i] : 0;
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  const int excl = incl - c;
+  const int total = __shfl(incl, 63);
+  const int d = min(total, cap);
+  // lane = slice: each lane moves its own (few) entries to their final slots excl .. excl + c
+  const int* mine = tmp_list + ((size_t)min(lane, n_slices - 1) * n + i) * cap;
+  for (int e = 0; e < c; ++e) {
+    const int t = excl + e;
+    if (t >= d) break;
+    const int j = mine[e];
+    nbr[(size_t)i * cap + t] = j;
+    if (indeg) atomicAdd(&indeg[j], 1);
+    if (t == d - 1) last[i] = j;
+  }
+  if (lane == 0) { deg[i] = d; if (d == 0) last[i] = -1; }
+}
+
 // ---- transpose of the capped lists: for node j, the centres c (ascending) whose list contains j.
 // "c lists j"  <=>  d2(c,j) < r2, (loop or c != j), same segment, and j <= last[c]  (lists are the
 // first `cap` hits in ascending index, so membership is a comparison, not a search).
@@ -467,6 +600,55 @@ int nbd_radius_search_f32(const float* pos, int n, float radius_sq, int loop, in
   if (indeg) zero_i32_kernel<<<ceil_div(n, 256), 256, 0, st>>>(indeg, n);
   radius_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
       pos, n, radius_sq, loop, max_num_neighbors, seg_lo, seg_hi, nbr, deg, last, indeg);
+  return status();
+}
+
+struct RadiusPlan { int slices, slice_len; size_t ws; };
+static RadiusPlan plan_radius(int n, int cap) {
+  const int groups = ceil_div(n, 128);
+  int s = ceil_div(8192, groups);                  // ~8 waves per SIMD chip-wide
+  s = s > 64 ? 64 : s;
+  const int max_s = ceil_div(n, 256);              // >= 256 sources per slice
+  s = s > max_s ? max_s : s;
+  s = s < 1 ? 1 : s;
+  RadiusPlan p;
+  p.slice_len = ceil_div(ceil_div(n, s), 64) * 64;
+  p.slices = ceil_div(n, p.slice_len);
+  p.ws = ((size_t)p.slices * n * cap + (size_t)p.slices * n) * sizeof(int);
+  return p;
+}
+
+size_t nbd_radius_search_workspace_bytes(int n, int max_num_neighbors) {
+  if (n <= 0 || max_num_neighbors <= 0) return 0;
+  return plan_radius(n, max_num_neighbors).ws;
+}
+
+int nbd_radius_search_ws_f32(const float* pos, int n, float radius_sq, int loop, int max_num_neighbors,
+                             const int* seg_lo, const int* seg_hi, int* nbr, int* deg, int* last, int* indeg,
+                             void* workspace, size_t workspace_bytes, nbd_stream_t stream) {
+  if (n < 0 || max_num_neighbors < 0 || (seg_lo == nullptr) != (seg_hi == nullptr)) return NBD_E_BADARG;
+  if (n == 0) return 0;
+  if (!pos || !deg || !last || (max_num_neighbors > 0 && !nbr)) return NBD_E_BADARG;
+  if (max_num_neighbors == 0)
+    return nbd_radius_search_f32(pos, n, radius_sq, loop, 0, seg_lo, seg_hi, nbr, deg, last, indeg, stream);
+  const RadiusPlan p = plan_radius(n, max_num_neighbors);
+  if (!workspace || workspace_bytes < p.ws) return NBD_E_BADARG;
+  if ((long long)p.slices * n * max_num_neighbors > 0x7fffffffLL * 2) return NBD_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  int* tmp_list = static_cast<int*>(workspace);
+  int* tmp_cnt = tmp_list + (size_t)p.slices * n * max_num_neighbors;
+  if (indeg) zero_i32_kernel<<<ceil_div(n, 256), 256, 0, st>>>(indeg, n);
+  const int waves = ceil_div(n, 128) * p.slices;
+  if (seg_lo)
+    radius_stream_kernel<true><<<ceil_div(waves, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
+        pos, n, radius_sq, loop, max_num_neighbors, seg_lo, seg_hi, p.slices, p.slice_len, tmp_list, tmp_cnt);
+  else
+    radius_stream_kernel<false><<<ceil_div(waves, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
+        pos, n, radius_sq, loop, max_num_neighbors, seg_lo, seg_hi, p.slices, p.slice_len, tmp_list, tmp_cnt);
+  int rc = status();
+  if (rc) return rc;
+  radius_merge_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
+      tmp_list, tmp_cnt, n, p.slices, max_num_neighbors, nbr, deg, last, indeg);
   return status();
 }
 

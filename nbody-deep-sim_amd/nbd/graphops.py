@@ -98,18 +98,29 @@ def radius_lists(pos: torch.Tensor, r: float, batch=None, loop: bool = False, ma
     r2 = radius_r2(r)
     L, st = _lib.lib(), _stream(dev)
     rowptr = centres = None
+    # streaming search (lane = centre) when its slice lists are small; the one-wave-per-centre search for
+    # very large caps (its early exit at `cap` hits does not need them)
+    need = L.nbd_radius_search_workspace_bytes(n, cap)
+    stream_ok = 0 < need <= (1 << 29)
+    ws = torch.empty(need if stream_ok else 1, dtype=torch.uint8, device=dev)
+
+    def search(indeg_ptr):
+        if stream_ok:
+            _lib.check(L.nbd_radius_search_ws_f32(pos.data_ptr(), n, r2, int(loop), cap, _lib.ptr(lo), _lib.ptr(hi),
+                                                  nbr.data_ptr(), deg.data_ptr(), last.data_ptr(), indeg_ptr,
+                                                  ws.data_ptr(), need, st), "nbd_radius_search_ws_f32")
+        else:
+            _lib.check(L.nbd_radius_search_f32(pos.data_ptr(), n, r2, int(loop), cap, _lib.ptr(lo), _lib.ptr(hi),
+                                               nbr.data_ptr(), deg.data_ptr(), last.data_ptr(), indeg_ptr, st),
+                       "nbd_radius_search_f32")
     with _lib.on_device(dev):
         if not transpose:
-            _lib.check(L.nbd_radius_search_f32(pos.data_ptr(), n, r2, int(loop), cap, _lib.ptr(lo), _lib.ptr(hi),
-                                               nbr.data_ptr(), deg.data_ptr(), last.data_ptr(), None, st),
-                       "nbd_radius_search_f32")
+            search(None)
         else:
             indeg = torch.empty(n, dtype=torch.int32, device=dev)
             rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
             centres = torch.empty(max(n * cap, 1), dtype=torch.int32, device=dev)   # E <= n*cap: no sync needed
-            _lib.check(L.nbd_radius_search_f32(pos.data_ptr(), n, r2, int(loop), cap, _lib.ptr(lo), _lib.ptr(hi),
-                                               nbr.data_ptr(), deg.data_ptr(), last.data_ptr(), indeg.data_ptr(), st),
-                       "nbd_radius_search_f32")
+            search(indeg.data_ptr())
             _lib.check(L.nbd_exclusive_scan_i32(indeg.data_ptr(), n, rowptr.data_ptr(), st), "exclusive_scan")
             if scan_transpose:      # O(N^2) scanning transpose (kept as the independent cross-check)
                 _lib.check(L.nbd_radius_transpose_fill_f32(pos.data_ptr(), n, r2, int(loop), _lib.ptr(lo), _lib.ptr(hi),

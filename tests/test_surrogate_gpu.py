@@ -59,7 +59,8 @@ def test_knn_graph_batched(gpu_device):
 
 @pytest.mark.parametrize("n,r,loop,cap", [(1, 1.0, True, 32), (50, 0.5, False, 32), (500, 1.0, True, 32),
                                           (500, 1.0, False, 32), (500, 0.3, True, 4), (2000, 1.0, True, 32),
-                                          (300, 100.0, True, 7)])
+                                          (300, 100.0, True, 7), (5000, 0.8, False, 32), (4097, 1.0, True, 3),
+                                          (3000, 1.0, True, 4096)])       # last: cap too large for the streaming form
 def test_radius_graph_bit_exact(n, r, loop, cap, gpu_device):
     from nbd import graphops
     from oracle import surrogate_oracle as so
@@ -84,6 +85,12 @@ def test_radius_graph_batched(gpu_device):
     b = _batch(400, [150, 1, 249])
     ref = so.radius_graph(pos, 1.0, batch=b, loop=True, max_num_neighbors=16)
     assert torch.equal(graphops.radius_graph(pos.cuda(), 1.0, batch=b.cuda(), loop=True, max_num_neighbors=16).cpu(), ref)
+    # many ragged graphs: segments straddle the 128-centre groups and the source slices of the streaming search
+    pos, _, _ = _plummer_pos(3000, 10)
+    b = _batch(3000, [3, 25, 50, 100, 250, 500, 1, 64, 128, 129, 700, 550, 500])
+    for loop, cap in ((True, 32), (False, 5)):
+        ref = so.radius_graph(pos, 0.9, batch=b, loop=loop, max_num_neighbors=cap)
+        assert torch.equal(graphops.radius_graph(pos.cuda(), 0.9, batch=b.cuda(), loop=loop, max_num_neighbors=cap).cpu(), ref)
 
 
 # ------------------------------------------------------------------ dense blocks
