@@ -16,7 +16,8 @@ def _mat(t: torch.Tensor, name: str):
     if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
         raise _lib.NbdError(f"{name}: need a 2-D fp32 CUDA/HIP tensor with unit inner stride, got "
                             f"{t.dtype} {tuple(t.shape)} strides {t.stride()} on {t.device}")
-    return t.stride(0)
+    # a single row has no meaningful row stride (torch reports whatever the view it came from had)
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1], 1)
 
 
 def _vec(t, n, name):

@@ -2,9 +2,17 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 
-PARITY UNPINNED against the reference: gnn.py / contconv.py import torch_geometric (2.6.1),
-torch_cluster (1.6.3) and torch_scatter (2.1.2) (requirements.txt:3-5), none of which exist in
-this image, and the reference holds no tests or golden vectors for this path. What follows is a
+PARITY PARTLY PINNED, the rest UNPINNED: gnn.py / contconv.py / trainer.py import torch_geometric
+(2.6.1), torch_cluster (1.6.3) and torch_scatter (2.1.2) (requirements.txt:3-5), none of which exist
+in this image, and the reference holds no tests or golden vectors for this path.
+  pinned   -- the arithmetic that lives in the reference's OWN files and needs none of those packages:
+              ContinuousConv.ball_to_cube / trilinear_interpolate (contconv.py:30-33,53-78) and
+              Trainer.step / Trainer.evaluate_rollout (trainer.py:217-344). tests/golden/
+              make_golden_surrogate.py compiled those two classes from the reference's source text and ran
+              them; tests/test_oracle_golden.py holds this oracle (and tests/test_surrogate_gpu.py the HIP
+              path) to the vectors it stored (tests/golden/surrogate_ref_*.npz).
+  unpinned -- everything the absent packages compute: neighbour search, PyG MLP / EdgeConv, scatter.
+What follows is a
 pure-torch restatement of (a) the reference's own lines, cited per function, and (b) the
 published semantics of the third-party calls it makes, written down here as the SPECIFICATION
 the HIP path is tested against:
