@@ -320,3 +320,38 @@ def test_euler_run_reports_post_step_energies(gpu_device):
             u, k = ora.compute_energies()
             assert abs(st.u_energy - u) <= 2e-5 * abs(u) and abs(st.k_energy - k) <= 2e-6 * abs(k), cls
             assert row_rel(st.positions.numpy(), ora.positions.numpy()) < TOL
+
+
+def test_dataset_cli_reproduces_the_reference_csv(tmp_path, gpu_device):
+    """tests/golden/ref_cli_spiral_n5_n8.csv was written by the REFERENCE's CLI on its CPU path
+    (tests/golden/make_golden_cli.py). Same arguments through this build's CLI on the GPU: same header, rows,
+    integer / string columns and float formatting; float values within fp32 tolerance (step_time is a clock)."""
+    import csv
+    import importlib.util
+    import os
+    import sys
+    from conftest import PKG
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden_cli import ARGS
+    spec = importlib.util.spec_from_file_location("s01", f"{PKG}/s01-dataset-generation.py")
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    out = str(tmp_path / "out.csv")
+    cli.main([*ARGS, "--device", "cuda", "--output", out])
+    ref_raw = open(os.path.join(os.path.dirname(__file__), "golden", "ref_cli_spiral_n5_n8.csv"), newline="").read()
+    got_raw = open(out, newline="").read()
+    assert ref_raw.split("\r\n")[0] == got_raw.split("\r\n")[0] and ref_raw.endswith("\r\n") == got_raw.endswith("\r\n")
+    ref = list(csv.DictReader(ref_raw.splitlines()))
+    got = list(csv.DictReader(got_raw.splitlines()))
+    assert len(ref) == len(got) == (5 + 8) * 3
+    f32_cols = ["x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az"]
+    for a, b in zip(ref, got):
+        assert (a["scene"], a["scene_type"], a["step"]) == (b["scene"], b["scene_type"], b["step"])
+        assert a["mass"] == b["mass"]                                   # float64 from the generator: same seed, same string
+        for c in f32_cols:
+            x, y = float(a[c]), float(b[c])
+            assert str(np.float32(y)) == b[c]                           # fp32 values printed the way numpy prints them
+            assert abs(x - y) <= 1e-5 * max(abs(x), 1e-30) + 1e-12, (c, a[c], b[c])
+        for c in ("u", "k"):
+            assert abs(float(a[c]) - float(b[c])) <= 2e-5 * abs(float(a[c])), (c, a[c], b[c])
+        assert float(b["step_time"]) >= 0.0
