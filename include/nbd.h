@@ -219,11 +219,15 @@ int nbd_layernorm_f32(const float* x, int ldx, int c, const float* gamma, const 
  * window/ball_to_cube/grid_sample(align_corners=True) exactly as contconv.py:30-33,53-78,85-90, so
  * that ContinuousConv = scatter_mean(...) = rowscale * (a_out . filters.reshape(D^3*I, O)).
  * rowptr/centres: CSR by aggregation target (nbd_radius_transpose_*). D <= 10.
- * Rows [node_begin, node_begin + n) are produced into a_out[0 .. n): callers bin + contract in node
- * chunks whose A block stays resident in the 256 MiB Infinity Cache instead of round-tripping HBM. */
+ * Rows [node_begin, node_begin + n) are produced into a_out[0 .. n).
+ * cell_map (NULL = identity, cells_out ignored): int[D^3], cell -> column block of a_out or -1. ball_to_cube
+ * keeps every sample inside |mapped| < tanh(R) (contconv.py:30-33 with the window cut at R, :85-87), so grid
+ * points further than that from the cube centre are never touched: their columns are structurally zero and
+ * the caller may drop them from a_out AND from the filter matrix (D = 6, R = 1: 160 of 216 cells remain);
+ * a_out is then (n, cells_out * in_channels). */
 int nbd_contconv_bin_f32(const float* pos, const float* feat, int ldf, int in_channels, const int* rowptr,
                          const int* centres, int node_begin, int n, int filter_resolution, float radius_sq,
-                         float* a_out, nbd_stream_t stream);
+                         const int* cell_map, int cells_out, float* a_out, nbd_stream_t stream);
 
 /* One whole EdgeConv layer of GraphModel.forward (gnn.py:75-93,140-148) in ONE launch, one node per
  * wave: s_i = aggr_j tanh(P_i + Q_j); y_i = W2 s_i + beta_i b2 (beta = [deg>0] for mean, deg for sum);
@@ -306,10 +310,11 @@ int nbd_batchnorm_train_bwd_f32(const float* x, int ldx, int n, int c, const flo
 /* Adjoint of nbd_contconv_bin_f32 with respect to the features: dfeat[c][i] = sum over edges (n <- c) of
  * window * sum_corners t_corner * da[n][cell][i], gathered per SOURCE c over its list of targets n:
  * CSR (rowptr_s, tgt_s) or, with rowptr_s NULL, padded lists tgt_s[c * cap + 0..deg[c]) -- the layout
- * nbd_radius_search_f32 produces. da is (n, D^3 * in_channels) contiguous. */
+ * nbd_radius_search_f32 produces. da is (n, cells_out * in_channels) contiguous; cell_map / cells_out as in
+ * nbd_contconv_bin_f32. */
 int nbd_contconv_bin_bwd_f32(const float* pos, const float* da, int in_channels, const int* rowptr_s, const int* tgt_s,
-                             const int* deg, int cap, int n, int filter_resolution, float radius_sq, float* dfeat,
-                             int lddf, nbd_stream_t stream);
+                             const int* deg, int cap, int n, int filter_resolution, float radius_sq,
+                             const int* cell_map, int cells_out, float* dfeat, int lddf, nbd_stream_t stream);
 
 /* Backward of nbd_segment_reduce_f32 mode 2 (max): dm[e][c] = dx[i][c] at the first row e of target i with
  * m[e][c] == x[i][c] (x = the forward output), 0 elsewhere. m may have zero rows for a target. */

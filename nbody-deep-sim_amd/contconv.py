@@ -44,10 +44,24 @@ class ContinuousConv(nn.Module):
         self.filters = nn.Parameter(torch.randn(filter_resolution, filter_resolution, filter_resolution,
                                                 in_channels, out_channels))            # contconv.py:20-28
 
+    def cells(self):
+        """(reachable cell indices int64 [K], cell -> compact index int32 [D^3], K) on the filters' device:
+        only grid points within tanh(radius) (D-1)/2 (+ their adjacent unit cubes) of the grid centre can be
+        touched by a sample (nnops.reachable_cells); the others are dropped from the binned matrix and from the
+        filter matrix alike -- their products are exact zeros in the reference."""
+        key = (self.filter_resolution, float(self.radius), str(self.filters.device))
+        if getattr(self, "_cells_key", None) != key:
+            idx, cmap = nnops.reachable_cells(self.filter_resolution, self.radius)
+            self._cells_val = (idx.to(self.filters.device), cmap.to(self.filters.device), int(idx.numel()))
+            self._cells_key = key
+        return self._cells_val
+
     def weight_t(self):
-        """filters (D,D,D,I,O) -> (O, D^3*I): the `w` operand of nbd_linear_f32, k = ((z*D+y)*D+x)*I + i."""
+        """filters (D,D,D,I,O) -> (O, K*I) over the K reachable cells: the `w` operand of nbd_linear_f32,
+        k = compact(cell)*I + i with cell = (z*D+y)*D+x."""
         d, i, o = self.filter_resolution, self.in_channels, self.out_channels
-        return self.filters.detach().reshape(d * d * d * i, o).t().contiguous()
+        idx, _, k = self.cells()
+        return self.filters.detach().reshape(d * d * d, i, o).index_select(0, idx).reshape(k * i, o).t().contiguous()
 
     def forward(self, positions, features, edge_index=None, lists=None, act=None, out=None, wt=None):
         """contconv.py:80-98. Give either the sync-free `lists` (graphops.radius_lists) or a PyG-style
@@ -72,7 +86,7 @@ class ContinuousConv(nn.Module):
                 rp, tg = graphops.csr_by_key(edge_index[1], edge_index[0], n)
                 bwd = dict(rowptr_s=rp, tgt_s=tg if tg.numel() else torch.zeros(1, dtype=torch.int32, device=tg.device))
             res = ag.ContConvFn.apply(features, self.filters, positions.contiguous(), (rowptr, centres), bwd,
-                                      self.filter_resolution, r2, scale, act)
+                                      self.filter_resolution, r2, scale, act, self.cells())
             if out is not None:
                 raise NbdError("ContinuousConv.forward: out= is an inference-only option")
             return res
@@ -81,14 +95,15 @@ class ContinuousConv(nn.Module):
             out = torch.empty((n, self.out_channels), dtype=torch.float32, device=positions.device)
         # bin + contract in node chunks: the chunk's A block (<= A_CHUNK_BYTES) is produced and consumed
         # while it sits in the 256 MiB Infinity Cache, and the buffer is reused chunk after chunk
-        kc = self.filter_resolution ** 3 * self.in_channels
+        _, cmap, n_cells = self.cells()
+        kc = n_cells * self.in_channels
         rows = max(128, (A_CHUNK_BYTES // (4 * kc)) // 128 * 128)
         pos_c = positions.contiguous()
         a_buf = torch.empty((min(rows, n), kc), dtype=torch.float32, device=positions.device)
         for lo in range(0, n, rows):
             cnt = min(rows, n - lo)
             nnops.contconv_bin(pos_c, features, rowptr, centres, self.filter_resolution, r2, out=a_buf,
-                               node_begin=lo, count=cnt)
+                               node_begin=lo, count=cnt, cell_map=cmap, cells_out=n_cells)
             nnops.linear(a_buf[:cnt], wt, None, act=act, out=out[lo:lo + cnt],
                          rowscale=None if scale is None else scale[lo:lo + cnt])
         return out

@@ -390,7 +390,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 template <int CPL>
 __global__ __launch_bounds__(64) void contconv_bin_kernel(
     const float* __restrict__ pos, const float* __restrict__ feat, int ldf, int I, const int* __restrict__ rowptr,
-    const int* __restrict__ centres, int node_begin, int D, float r2max, float* __restrict__ A) {
+    const int* __restrict__ centres, int node_begin, int D, float r2max, const int* __restrict__ cell_map,
+    int cells_out, float* __restrict__ A) {
   typedef float vec __attribute__((ext_vector_type(CPL)));
   extern __shared__ float img_raw[];        // [D*D][64] vec slab image, then kGeoCache EdgeGeo records
   vec* img = reinterpret_cast<vec*>(img_raw);
@@ -458,9 +459,12 @@ __global__ __launch_bounds__(64) void contconv_bin_kernel(
       if (!cached) __builtin_amdgcn_wave_barrier();
     }
     if (live) {
-      float* dst = A + ((size_t)blockIdx.x * D * slab_cells + (size_t)z * slab_cells) * I + ch;
+      // cell_map compacts the row to the grid points a sample can reach at all (ball_to_cube keeps every
+      // sample inside |mapped| < tanh(R)): unreachable cells are structurally zero and are not stored
+      float* dst = A + (size_t)blockIdx.x * cells_out * I + ch;
       for (int c = 0; c < slab_cells; ++c) {
-        *reinterpret_cast<vec*>(dst + (size_t)c * I) = img[c * 64 + lane];
+        const int m = cell_map ? cell_map[z * slab_cells + c] : z * slab_cells + c;
+        if (m >= 0) *reinterpret_cast<vec*>(dst + (size_t)m * I) = img[c * 64 + lane];
         img[c * 64 + lane] = zero;
       }
     } else {
@@ -581,8 +585,11 @@ int nbd_layernorm_f32(const float* x, int ldx, int c, const float* gamma, const 
 
 int nbd_contconv_bin_f32(const float* pos, const float* feat, int ldf, int in_channels, const int* rowptr,
                          const int* centres, int node_begin, int n, int filter_resolution, float radius_sq,
-                         float* a_out, nbd_stream_t stream) {
+                         const int* cell_map, int cells_out, float* a_out, nbd_stream_t stream) {
   if (n < 0 || node_begin < 0 || in_channels <= 0 || filter_resolution < 2) return NBD_E_BADARG;
+  const int cells = filter_resolution * filter_resolution * filter_resolution;
+  if (!cell_map) cells_out = cells;
+  if (cells_out <= 0 || cells_out > cells) return NBD_E_BADARG;
   if (n == 0) return 0;
   if (!pos || !feat || !rowptr || !centres || !a_out || ldf < in_channels) return NBD_E_BADARG;
   // two channels per lane (8-byte accesses) when the layout allows it: even I, even ldf, 8-byte aligned bases
@@ -595,10 +602,10 @@ int nbd_contconv_bin_f32(const float* pos, const float* feat, int ldf, int in_ch
   hipStream_t st = (hipStream_t)stream;
   if (cpl2)
     contconv_bin_kernel<2><<<grid, 64, shmem, st>>>(pos, feat, ldf, in_channels, rowptr, centres, node_begin,
-                                                    filter_resolution, radius_sq, a_out);
+                                                    filter_resolution, radius_sq, cell_map, cells_out, a_out);
   else
     contconv_bin_kernel<1><<<grid, 64, shmem, st>>>(pos, feat, ldf, in_channels, rowptr, centres, node_begin,
-                                                    filter_resolution, radius_sq, a_out);
+                                                    filter_resolution, radius_sq, cell_map, cells_out, a_out);
   return status();
 }
 

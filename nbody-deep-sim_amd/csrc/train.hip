@@ -384,14 +384,14 @@ __device__ __forceinline__ Geo edge_geo(const float* __restrict__ pos, float xc,
 __global__ __launch_bounds__(64) void contconv_bin_bwd_kernel(
     const float* __restrict__ pos, const float* __restrict__ dA, int I, const int* __restrict__ rowptr_s,
     const int* __restrict__ tgt_s, const int* __restrict__ deg, int cap, int D, float r2max,
-    float* __restrict__ dfeat, int lddf) {
+    const int* __restrict__ cell_map, int cells_out, float* __restrict__ dfeat, int lddf) {
   __shared__ Geo geo[64];
   __shared__ int tgt[64];
   const int c = blockIdx.x, lane = threadIdx.x, ch = blockIdx.y * 64 + lane;
   const int e0 = rowptr_s ? rowptr_s[c] : c * cap, e1 = rowptr_s ? rowptr_s[c + 1] : e0 + deg[c];
   const float xc = pos[3 * c], yc = pos[3 * c + 1], zc = pos[3 * c + 2];
   const float half = (float)(D - 1) / 2.0f;
-  const size_t row_len = (size_t)D * D * D * I;
+  const size_t row_len = (size_t)cells_out * I;
   float acc = 0.f;
   for (int eb = e0; eb < e1; eb += 64) {
     const int cnt = min(64, e1 - eb);
@@ -416,7 +416,9 @@ __global__ __launch_bounds__(64) void contconv_bin_bwd_kernel(
           const int cx = g.ix + ax, cy = g.iy + ay, cz = g.iz + az;
           if (cx < 0 || cx >= D || cy < 0 || cy >= D || cz < 0 || cz >= D) continue;
           const float t = ((ax ? g.tx : 1.0f - g.tx) * (ay ? g.ty : 1.0f - g.ty)) * (az ? g.tz : 1.0f - g.tz);
-          sum = __builtin_fmaf(t, row[(size_t)((cz * D + cy) * D + cx) * I], sum);
+          const int cell = (cz * D + cy) * D + cx;
+          const int mc = cell_map ? cell_map[cell] : cell;
+          if (mc >= 0) sum = __builtin_fmaf(t, row[(size_t)mc * I], sum);
         }
         acc = __builtin_fmaf(g.window, sum, acc);
       }
@@ -548,15 +550,19 @@ int nbd_batchnorm_train_bwd_f32(const float* x, int ldx, int n, int c, const flo
 }
 
 int nbd_contconv_bin_bwd_f32(const float* pos, const float* da, int in_channels, const int* rowptr_s, const int* tgt_s,
-                             const int* deg, int cap, int n, int filter_resolution, float radius_sq, float* dfeat,
-                             int lddf, nbd_stream_t stream) {
+                             const int* deg, int cap, int n, int filter_resolution, float radius_sq,
+                             const int* cell_map, int cells_out, float* dfeat, int lddf, nbd_stream_t stream) {
   if (n < 0 || in_channels <= 0 || filter_resolution < 1 || !(radius_sq > 0.f)) return NBD_E_BADARG;
+  const int cells = filter_resolution * filter_resolution * filter_resolution;
+  if (!cell_map) cells_out = cells;
+  if (cells_out <= 0 || cells_out > cells) return NBD_E_BADARG;
   if (n == 0) return 0;
   if (!pos || !da || !tgt_s || !dfeat || lddf < in_channels) return NBD_E_BADARG;
   if (!rowptr_s && (!deg || cap < 0)) return NBD_E_BADARG;
   dim3 grid(n, ceil_div(in_channels, 64));
   contconv_bin_bwd_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(pos, da, in_channels, rowptr_s, tgt_s, deg, cap,
-                                                               filter_resolution, radius_sq, dfeat, lddf);
+                                                               filter_resolution, radius_sq, cell_map, cells_out, dfeat,
+                                                               lddf);
   return status();
 }
 

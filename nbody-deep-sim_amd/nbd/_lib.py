@@ -102,7 +102,7 @@ SIGNATURES = {
     "nbd_layernorm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
                                   c_void_p]),
     "nbd_contconv_bin_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
-                                     c_float, c_void_p, c_void_p]),
+                                     c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "nbd_degree_scale_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nbd_gnn_layer_f32": (c_int, [POINTER(GnnLayerArgs), c_void_p]),
     # --- backward kernels (csrc/train.hip) and the transposed adjacency they gather over
@@ -117,7 +117,7 @@ SIGNATURES = {
                                             c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                             c_void_p, c_size_t, c_void_p]),
     "nbd_contconv_bin_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                         c_float, c_void_p, c_int, c_void_p]),
+                                         c_float, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "nbd_colsum_workspace_bytes": (c_size_t, [c_int, c_int]),
     "nbd_colsum_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nbd_linear_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -195,15 +195,16 @@ class ContConvFn(Function):
     not kept), dfeat = adjoint binning of (scale g) filters^T gathered per source."""
 
     @staticmethod
-    def forward(ctx, feat, filters, pos, fwd_lists, bwd_lists, d, r2, scale, act):
+    def forward(ctx, feat, filters, pos, fwd_lists, bwd_lists, d, r2, scale, act, cells):
         i_ch, o_ch = filters.shape[3], filters.shape[4]
         rowptr, centres = fwd_lists
+        idx, cmap, k = cells
         feat = feat if feat.stride(1) == 1 else feat.contiguous()
-        a = nnops.contconv_bin(pos, feat, rowptr, centres, d, r2)
-        w = filters.reshape(d * d * d * i_ch, o_ch)
+        a = nnops.contconv_bin(pos, feat, rowptr, centres, d, r2, cell_map=cmap, cells_out=k)
+        w = filters.reshape(d * d * d, i_ch, o_ch).index_select(0, idx).reshape(k * i_ch, o_ch)
         out = nnops.linear(a, w.t().contiguous(), None, act=act, rowscale=scale)
         ctx.save_for_backward(feat, filters, pos, out, scale)
-        ctx.fwd_lists, ctx.bwd_lists, ctx.d, ctx.r2, ctx.act = fwd_lists, bwd_lists, d, r2, act
+        ctx.fwd_lists, ctx.bwd_lists, ctx.d, ctx.r2, ctx.act, ctx.cells = fwd_lists, bwd_lists, d, r2, act, cells
         return out
 
     @staticmethod
@@ -211,15 +212,21 @@ class ContConvFn(Function):
     def backward(ctx, dout):
         feat, filters, pos, out, scale = ctx.saved_tensors
         d, r2 = ctx.d, ctx.r2
+        idx, cmap, k = ctx.cells
         i_ch, o_ch = filters.shape[3], filters.shape[4]
         dout = dout if dout.stride(1) == 1 else dout.contiguous()
         gs = nnops.act_bwd(dout, out if ctx.act == "tanh" else None, ctx.act, rowscale=scale)
         dfilters = dfeat = None
         if ctx.needs_input_grad[1]:
-            a = nnops.contconv_bin(pos, feat, ctx.fwd_lists[0], ctx.fwd_lists[1], d, r2)
-            dfilters = nnops.linear_wgrad(a, gs).reshape(filters.shape)
+            a = nnops.contconv_bin(pos, feat, ctx.fwd_lists[0], ctx.fwd_lists[1], d, r2, cell_map=cmap, cells_out=k)
+            dw = nnops.linear_wgrad(a, gs).reshape(k, i_ch, o_ch)
             del a
+            # unreachable grid points never enter a product: their gradient is exactly zero
+            dfilters = torch.zeros((d * d * d, i_ch, o_ch), dtype=torch.float32, device=dw.device)
+            dfilters.index_copy_(0, idx, dw)
+            dfilters = dfilters.reshape(filters.shape)
         if ctx.needs_input_grad[0]:
-            da = nnops.linear(gs, filters.reshape(d * d * d * i_ch, o_ch).contiguous())
-            dfeat = nnops.contconv_bin_bwd(pos, da, i_ch, d, r2, **ctx.bwd_lists)
-        return dfeat, dfilters, None, None, None, None, None, None, None
+            w = filters.reshape(d * d * d, i_ch, o_ch).index_select(0, idx).reshape(k * i_ch, o_ch).contiguous()
+            da = nnops.linear(gs, w)
+            dfeat = nnops.contconv_bin_bwd(pos, da, i_ch, d, r2, cell_map=cmap, cells_out=k, **ctx.bwd_lists)
+        return dfeat, dfilters, None, None, None, None, None, None, None, None

@@ -111,9 +111,29 @@ def layernorm(x, gamma, beta, eps, out=None):
     return out
 
 
-def contconv_bin(pos, feat, rowptr, centres, d, radius_sq, out=None, node_begin=0, count=None):
-    """A (count, d^3 * I): feature-side trilinear binning of ContinuousConv (contconv.py:80-93) for the
-    nodes [node_begin, node_begin + count)."""
+def reachable_cells(d: int, radius: float, margin: float = 1e-3):
+    """Filter grid points (cell = (z*D + y)*D + x) a ContinuousConv sample can touch at all: ball_to_cube maps
+    every edge inside |mapped| <= tanh(R) (contconv.py:30-33; the window is zero beyond R, :85-87), i.e. inside
+    a ball of radius tanh(R) (D-1)/2 around the grid centre, and a grid point is touched only by samples in
+    the unit cubes adjacent to it. Returns (cells int64 [K], cell_map int32 [D^3] with -1 for unreachable)."""
+    import math
+    c = (d - 1) / 2.0
+    rad = math.tanh(radius) * c + margin
+    ax = torch.arange(d, dtype=torch.float64)
+    gap = torch.clamp((ax - c).abs() - 1.0, min=0.0)                 # distance from the centre to [p-1, p+1]
+    g2 = gap ** 2
+    dist2 = g2[:, None, None] + g2[None, :, None] + g2[None, None, :]
+    keep = (dist2 <= rad * rad).reshape(-1)
+    cells = torch.nonzero(keep).reshape(-1)
+    cell_map = torch.full((d * d * d,), -1, dtype=torch.int32)
+    cell_map[cells] = torch.arange(cells.numel(), dtype=torch.int32)
+    return cells, cell_map
+
+
+def contconv_bin(pos, feat, rowptr, centres, d, radius_sq, out=None, node_begin=0, count=None, cell_map=None,
+                 cells_out=None):
+    """A (count, cells_out * I): feature-side trilinear binning of ContinuousConv (contconv.py:80-93) for the
+    nodes [node_begin, node_begin + count); cell_map (int32 [d^3] on the device) drops unreachable cells."""
     n, i_ch = feat.shape
     count = n - node_begin if count is None else count
     ldf = _mat(feat, "feat")
@@ -123,7 +143,11 @@ def contconv_bin(pos, feat, rowptr, centres, d, radius_sq, out=None, node_begin=
         raise _lib.NbdError("rowptr int32 [n+1] / centres int32 required")
     if node_begin < 0 or count < 0 or node_begin + count > n:
         raise _lib.NbdError(f"node range [{node_begin}, {node_begin + count}) outside [0, {n})")
-    kc = d * d * d * i_ch
+    if cell_map is None:
+        cells_out = d * d * d
+    elif cell_map.dtype != torch.int32 or cell_map.numel() != d * d * d or not cell_map.is_cuda or cells_out is None:
+        raise _lib.NbdError("cell_map must be an int32 CUDA tensor of d^3 entries, with cells_out")
+    kc = cells_out * i_ch
     if out is None:
         out = torch.empty((count, kc), dtype=torch.float32, device=feat.device)
     if out.dim() != 2 or out.shape[0] < count or out.shape[1] != kc or not out.is_contiguous():
@@ -131,7 +155,8 @@ def contconv_bin(pos, feat, rowptr, centres, d, radius_sq, out=None, node_begin=
     with _lib.on_device(feat.device):
         _lib.check(_lib.lib().nbd_contconv_bin_f32(pos.data_ptr(), feat.data_ptr(), ldf, i_ch, rowptr.data_ptr(),
                                                    centres.data_ptr(), node_begin, count, d, float(radius_sq),
-                                                   out.data_ptr(), _lib.current_stream(feat.device)),
+                                                   _lib.ptr(cell_map), cells_out, out.data_ptr(),
+                                                   _lib.current_stream(feat.device)),
                    "nbd_contconv_bin_f32")
     return out
 
@@ -297,18 +322,21 @@ def batchnorm_train_bwd(x, gamma, mean, rstd, act, y, dy):
     return dx, dg, db
 
 
-def contconv_bin_bwd(pos, da, i_ch, d, radius_sq, rowptr_s=None, tgt_s=None, deg=None, cap=0):
+def contconv_bin_bwd(pos, da, i_ch, d, radius_sq, rowptr_s=None, tgt_s=None, deg=None, cap=0, cell_map=None,
+                     cells_out=None):
     """dfeat (n, i_ch): adjoint of contconv_bin w.r.t. the features; lists are per SOURCE (see nbd.h)."""
     n = pos.shape[0]
-    if da.shape != (n, d * d * d * i_ch) or not da.is_contiguous():
-        raise _lib.NbdError(f"dA must be contiguous ({n}, {d * d * d * i_ch})")
-    for t in (rowptr_s, tgt_s, deg):
+    cells_out = d * d * d if cell_map is None else cells_out
+    if da.shape != (n, cells_out * i_ch) or not da.is_contiguous():
+        raise _lib.NbdError(f"dA must be contiguous ({n}, {cells_out * i_ch})")
+    for t in (rowptr_s, tgt_s, deg, cell_map):
         if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
             raise _lib.NbdError("contconv_bin_bwd: index lists must be contiguous int32")
     dfeat = torch.empty((n, i_ch), dtype=torch.float32, device=pos.device)
     with _lib.on_device(pos.device):
         _lib.check(_lib.lib().nbd_contconv_bin_bwd_f32(pos.data_ptr(), da.data_ptr(), i_ch, _lib.ptr(rowptr_s),
                                                        tgt_s.data_ptr(), _lib.ptr(deg), cap, n, d, float(radius_sq),
-                                                       dfeat.data_ptr(), i_ch, _lib.current_stream(pos.device)),
+                                                       _lib.ptr(cell_map), cells_out, dfeat.data_ptr(), i_ch,
+                                                       _lib.current_stream(pos.device)),
                    "nbd_contconv_bin_bwd_f32")
     return dfeat
