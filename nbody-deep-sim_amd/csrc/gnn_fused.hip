@@ -70,7 +70,7 @@ __device__ __forceinline__ void matvec(const float (&in)[RIN], const float* __re
 
 namespace {
 
-template <int R>
+template <int R, int FM>      // FM: on-the-fly feature count the loops are unrolled for (4 or kFMax)
 __global__ __launch_bounds__(256) void gnn_layer_kernel(const nbd_gnn_layer_args a) {
   extern __shared__ float smem[];
   const int H = a.h;
@@ -85,14 +85,14 @@ __global__ __launch_bounds__(256) void gnn_layer_kernel(const nbd_gnn_layer_args
   __syncthreads();
 
   // on-the-fly P/Q weights of this lane's channels (first layer, F <= 8)
-  float wp[R][kFMax], wq[R][kFMax], bp[R];
+  float wp[R][FM], wq[R][FM], bp[R];
   if (a.pq == nullptr) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int h = r * 64 + lane;
       bp[r] = h < H ? a.bpq[h] : 0.f;
 #pragma unroll
-      for (int f = 0; f < kFMax; ++f) {
+      for (int f = 0; f < FM; ++f) {
         const bool ok = h < H && f < a.f;
         wp[r][f] = ok ? a.wpq[(size_t)h * a.f + f] : 0.f;
         wq[r][f] = ok ? a.wpq[(size_t)(H + h) * a.f + f] : 0.f;
@@ -109,14 +109,14 @@ __global__ __launch_bounds__(256) void gnn_layer_kernel(const nbd_gnn_layer_args
 #pragma unroll
       for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; p[r] = h < H ? a.pq[(size_t)node * a.ldpq + h] : 0.f; }
     } else {
-      float xi[kFMax];
+      float xi[FM];
 #pragma unroll
-      for (int f = 0; f < kFMax; ++f) xi[f] = f < a.f ? a.x[(size_t)node * a.ldx + f] : 0.f;
+      for (int f = 0; f < FM; ++f) xi[f] = f < a.f ? a.x[(size_t)node * a.ldx + f] : 0.f;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         float acc = bp[r];
 #pragma unroll
-        for (int f = 0; f < kFMax; ++f) acc = __builtin_fmaf(wp[r][f], xi[f], acc);
+        for (int f = 0; f < FM; ++f) acc = __builtin_fmaf(wp[r][f], xi[f], acc);
         p[r] = acc;
       }
     }
@@ -127,11 +127,11 @@ __global__ __launch_bounds__(256) void gnn_layer_kernel(const nbd_gnn_layer_args
     for (int eb = e0; eb < e1; eb += 64) {
       const int cnt = min(64, e1 - eb);
       const int jv = lane < cnt ? (int)a.src[eb + lane] : 0;
-      for (int t = 0; t < cnt; t += kEF) {
+      for (int t = 0; a.pq && t < cnt; t += kEF) {
         int j[kEF];
 #pragma unroll
         for (int u = 0; u < kEF; ++u) j[u] = __builtin_amdgcn_readlane(jv, min(t + u, cnt - 1));
-        if (a.pq) {
+        {
           float q[kEF][R];
 #pragma unroll
           for (int u = 0; u < kEF; ++u)
@@ -147,22 +147,26 @@ __global__ __launch_bounds__(256) void gnn_layer_kernel(const nbd_gnn_layer_args
               const float v = fast_tanh(__fadd_rn(p[r], q[u][r]));
               s[r] += (t + u < cnt) ? v : 0.f;
             }
-        } else {
-          float xj[kEF][kFMax];
+        }
+      }
+      if (!a.pq) {
+        // first layer: every lane fetches ONE neighbour's features (a single gather latency for the whole
+        // chunk), then neighbour t's row is broadcast out of lane t; Q is formed on the fly
+        float xv[FM];
 #pragma unroll
-          for (int u = 0; u < kEF; ++u)
+        for (int f = 0; f < FM; ++f) xv[f] = (lane < cnt && f < a.f) ? a.x[(size_t)jv * a.ldx + f] : 0.f;
+        for (int t = 0; t < cnt; ++t) {
+          float xj[FM];
 #pragma unroll
-            for (int f = 0; f < kFMax; ++f) xj[u][f] = f < a.f ? a.x[(size_t)j[u] * a.ldx + f] : 0.f;
+          for (int f = 0; f < FM; ++f)
+            xj[f] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv[f]), t));
 #pragma unroll
-          for (int u = 0; u < kEF; ++u)
+          for (int r = 0; r < R; ++r) {
+            float q = 0.f;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-              float q = 0.f;
-#pragma unroll
-              for (int f = 0; f < kFMax; ++f) q = __builtin_fmaf(wq[r][f], xj[u][f], q);
-              const float v = fast_tanh(__fadd_rn(p[r], q));
-              s[r] += (t + u < cnt) ? v : 0.f;
-            }
+            for (int f = 0; f < FM; ++f) q = __builtin_fmaf(wq[r][f], xj[f], q);
+            s[r] += fast_tanh(__fadd_rn(p[r], q));
+          }
         }
       }
     }
@@ -280,8 +284,14 @@ int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
   int blocks = (a.n + 3) / 4;
   if (blocks > 512) blocks = 512;                    // >= 2 nodes per wave amortise the weight staging
   hipStream_t st = (hipStream_t)stream;
-  if (a.h <= 64) gnn_layer_kernel<1><<<blocks, 256, shmem, st>>>(a);
-  else gnn_layer_kernel<2><<<blocks, 256, shmem, st>>>(a);
+  const bool f4 = a.pq != nullptr || a.f <= 4;
+  if (a.h <= 64) {
+    if (f4) gnn_layer_kernel<1, 4><<<blocks, 256, shmem, st>>>(a);
+    else gnn_layer_kernel<1, kFMax><<<blocks, 256, shmem, st>>>(a);
+  } else {
+    if (f4) gnn_layer_kernel<2, 4><<<blocks, 256, shmem, st>>>(a);
+    else gnn_layer_kernel<2, kFMax><<<blocks, 256, shmem, st>>>(a);
+  }
   return status();
 }
 

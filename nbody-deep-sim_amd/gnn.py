@@ -152,6 +152,7 @@ class GraphModel(torch.nn.Module):
         self._cache = _WeightCache(self)
         self.use_fused = True          # one launch per EdgeConv layer when the shapes allow (csrc/gnn_fused.hip)
         self._fused_out = None
+        self._brs_const = None
         self.to(device)
 
     def get_config(self):
@@ -181,42 +182,53 @@ class GraphModel(torch.nn.Module):
             return self._forward_autograd(data)
         if self.training and self.encoder_dropout > 0 and isinstance(self.node_encoder, MLP):
             return self._forward_autograd(data)          # dropout active: not the folded inference path
-        w = self._cache.get(self._build_weights)
         x7 = data.x
         if not x7.is_cuda:
             raise NbdError("GraphModel.forward: data must live on the GPU (no CPU path)")
-        n = x7.shape[0]
         x_in = torch.cat((x7[:, :3], x7[:, 6:]), dim=-1) if self.input_dim == 4 else x7
-        x_in = x_in.to(torch.float32)
+        return self._forward_inference(x_in.to(torch.float32), data.edge_index, getattr(data, "_regular_k", None))
+
+    def _forward_inference(self, x_in, ei, reg):
+        """Inference forward on the model input x_in (n, input_dim) = [pos | mass] or [pos | vel | mass]."""
+        w = self._cache.get(self._build_weights)
+        n = x_in.shape[0]
         h = self.gnn_dim
+        dev = x_in.device
         enc_dim = self.input_dim if w["enc"] is None else h
-        cat_buf = torch.empty((n, enc_dim + h), dtype=torch.float32, device=x7.device)
+        # edges grouped by target (edge_index[1]); regular kNN output needs no CSR
+        e = ei.shape[1]
+        fixed_k, rowptr, src = -1, None, ei[0].contiguous()
+        if reg is not None and n * reg == e:
+            fixed_k = reg
+        else:
+            rowptr, src = graphops.csr_by_target(ei, n)
+        aggr = "mean" if self.aggr == "mean" else "sum"
+        if self.use_fused and self.aggr != "max" and w["enc"] is None:
+            # the fused layer kernels read the encoder output through (pointer, row stride): the model input
+            # itself when there is no encoder -- no concatenation buffer, no copy
+            x_c = x_in if x_in.stride(1) == 1 else x_in.contiguous()
+            if self._forward_fused(w, x_c, n, h, rowptr, src, fixed_k, aggr, None):
+                return self._fused_out
+        cat_buf = torch.empty((n, enc_dim + h), dtype=torch.float32, device=dev)
         enc_view, gnn_view = cat_buf[:, :enc_dim], cat_buf[:, enc_dim:]
         if w["enc"] is None:
             enc_view.copy_(x_in)
         else:
             run_chain(x_in.contiguous(), w["enc"], out_last=enc_view)
-        # edges grouped by target (edge_index[1]); regular kNN output needs no CSR
-        ei = data.edge_index
-        e = ei.shape[1]
-        fixed_k, rowptr, src = -1, None, ei[0].contiguous()
-        reg = getattr(data, "_regular_k", None)
-        if reg is not None and n * reg == e:
-            fixed_k = reg
-        else:
-            rowptr, src = graphops.csr_by_target(ei, n)
         if self.aggr == "mean":
             brs_mode = 2
         else:
             brs_mode = 1
         if rowptr is None:
             val = float(fixed_k) if brs_mode == 1 else (1.0 if fixed_k > 0 else 0.0)
-            brs = torch.full((n,), val, dtype=torch.float32, device=x7.device)
+            key = (n, val, str(dev))
+            if self._brs_const is None or self._brs_const[0] != key:       # a constant vector: built once
+                self._brs_const = (key, torch.full((n,), val, dtype=torch.float32, device=dev))
+            brs = self._brs_const[1]
         else:
-            brs = nnops.degree_scale(rowptr, n, brs_mode, x7.device)
+            brs = nnops.degree_scale(rowptr, n, brs_mode, dev)
         if self.aggr == "max":
             return self._forward_max(w, enc_view, gnn_view, cat_buf, n, h, rowptr, src, fixed_k, ei)
-        aggr = "mean" if self.aggr == "mean" else "sum"
         if self.use_fused and self._forward_fused(w, enc_view, n, h, rowptr, src, fixed_k, aggr, cat_buf):
             return self._fused_out
         x = enc_view
@@ -305,9 +317,13 @@ class GraphModel(torch.nn.Module):
         self.eval()
         with torch.no_grad():
             k = 50 if neighbors is None else neighbors
-            data = transform_to_graph(pos, feat, None, neighbors=k, device=self.device)
-            data._regular_k = max(min(k, pos.shape[0] - 1), 0)
-            pred = self.forward(data)
+            if not pos.is_cuda:
+                raise NbdError("GraphModel.predict: tensors must live on the GPU (no CPU path)")
+            # transform_to_graph + forward without materialising x = [pos | feat] first: the model input is
+            # [pos | mass] (input_dim == 4, gnn.py:131-132) or [pos | feat]
+            ei = graphops.knn_graph(pos, k=k, batch=None, loop=False)
+            x_in = torch.cat((pos, feat[:, 3:]), dim=-1) if self.input_dim == 4 else torch.cat((pos, feat), dim=-1)
+            pred = self._forward_inference(x_in.to(torch.float32), ei, max(min(k, pos.shape[0] - 1), 0))
         return pred
 
     def predict_graph(self, data):

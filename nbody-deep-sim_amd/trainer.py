@@ -110,9 +110,14 @@ class Trainer:
                     self.step(s_pos, s_vel, m, s_acc, dt)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
+            half, full = direct.f32(0.5 * dt), direct.f32(dt)
             with torch.cuda.graph(graph):
-                o_pos, o_vel, o_acc = self.step(s_pos, s_vel, m, s_acc, dt)
-                s_pos.copy_(o_pos); s_vel.copy_(o_vel); s_acc.copy_(o_acc)
+                # step() on the static state IN PLACE (same kernels and arithmetic; the functional clones and
+                # copy-backs of step() would be five more launches per replay)
+                direct.kick_drift(s_pos, s_vel, s_acc, None, half, full)
+                o_acc = self.model.predict(s_pos, torch.cat([s_vel, m], dim=-1))
+                direct.kick(s_vel, o_acc, half)
+                s_acc.copy_(o_acc)
         except Exception as exc:                          # pragma: no cover - depends on runtime support
             import warnings
             warnings.warn(f"hipGraph capture of the rollout step failed ({exc}); using eager launches")
