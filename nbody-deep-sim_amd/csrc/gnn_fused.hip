@@ -282,7 +282,10 @@ int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
   const size_t shmem = ((size_t)kp * a.h + (size_t)kp * n_ep) * sizeof(float);
   if (shmem > 64 * 1024) return NBD_E_UNSUPPORTED;   // H = 64: 48 KiB; H = 128 fits only without NEXT_PQ
   int blocks = (a.n + 3) / 4;
-  if (blocks > 512) blocks = 512;                    // >= 2 nodes per wave amortise the weight staging
+  // residency: 48 KiB of LDS (W2^T + the next layer's [P|Q] matrix) lets 3 workgroups share a CU, 16 KiB
+  // (W2^T alone) leaves the 4-waves-per-SIMD register limit = 4 workgroups: one resident round either way
+  const int max_blocks = shmem > 40 * 1024 ? 512 : 1024;
+  if (blocks > max_blocks) blocks = max_blocks;
   hipStream_t st = (hipStream_t)stream;
   const bool f4 = a.pq != nullptr || a.f <= 4;
   if (a.h <= 64) {
