@@ -237,6 +237,9 @@ int nbd_contconv_bin_f32(const float* pos, const float* feat, int ldf, int in_ch
 #define NBD_GNN_NEXT_PQ 1    /* out[i][0..ep_out) = w_ep y_i + b_ep       (next layer's [P|Q])        */
 #define NBD_GNN_FINAL_HEAD 2 /* out[i][0..ep_out) = w_ep LayerNorm([enc_i || y_i]) + b_ep, ep_out<=8 */
 #define NBD_GNN_FINAL_LN 3   /* out[i][0..e+h) = LayerNorm([enc_i || y_i])                            */
+#define NBD_GNN_NEXT_PQ_FOLDED 4 /* out[i][0..ep_out) = (w_ep W2) S_i + beta_i (w_ep b2) + b_ep: as NEXT_PQ with
+                                  * the two mat-vecs folded on the host; the caller passes w_ep := (w_ep W2)^T
+                                  * [h][ep_out], b2 := w_ep b2 [ep_out]; w2t is not read                   */
 typedef struct nbd_gnn_layer_args {
   const int* rowptr;      /* [n+1] edges grouped by target, or NULL: exactly fixed_k edges per node */
   const int64_t* src;     /* source node j of every edge (edge_index[0])                            */

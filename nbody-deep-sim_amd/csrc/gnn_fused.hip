@@ -75,12 +75,13 @@ __global__ __launch_bounds__(256) void gnn_layer_kernel(const nbd_gnn_layer_args
   extern __shared__ float smem[];
   const int H = a.h;
   constexpr int KP = 64 * R;               // mat-vec depth, zero padded
-  float* w2t = smem;                       // [KP][H]   (a.w2t is already W2 transposed: [k][out])
-  float* ept = smem + KP * H;              // [KP][n_ep] epilogue matrix (NEXT_PQ only)
+  const bool folded = a.epilogue == NBD_GNN_NEXT_PQ_FOLDED;
+  float* w2t = smem;                       // [KP][H]   (a.w2t is already W2 transposed: [k][out]); absent when folded
+  float* ept = smem + (folded ? 0 : KP * H);   // [KP][n_ep] epilogue matrix (NEXT_PQ / NEXT_PQ_FOLDED)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n_ep = a.epilogue == NBD_GNN_NEXT_PQ ? a.ep_out : 0;
-  for (int idx = threadIdx.x; idx < KP * H; idx += 256) w2t[idx] = idx < H * H ? a.w2t[idx] : 0.f;
+  const int n_ep = (a.epilogue == NBD_GNN_NEXT_PQ || folded) ? a.ep_out : 0;
+  for (int idx = threadIdx.x; !folded && idx < KP * H; idx += 256) w2t[idx] = idx < H * H ? a.w2t[idx] : 0.f;
   for (int idx = threadIdx.x; idx < KP * n_ep; idx += 256) ept[idx] = idx < H * n_ep ? a.w_ep[idx] : 0.f;
   __syncthreads();
 
@@ -177,6 +178,17 @@ __global__ __launch_bounds__(256) void gnn_layer_kernel(const nbd_gnn_layer_args
     }
     // y = W2 S + beta b2
     const float beta = a.aggr == 1 ? (deg > 0 ? 1.f : 0.f) : (float)deg;
+    if (folded) {
+      // next [P|Q] = (Wpq W2) S + beta (Wpq b2) + bpq: the two mat-vecs folded into one on the host
+      // (w_ep = (Wpq W2)^T, b2 = Wpq b2 here), so W2^T is neither staged nor applied
+      float o[2 * R];
+#pragma unroll
+      for (int r = 0; r < 2 * R; ++r) { const int c = r * 64 + lane; o[r] = c < n_ep ? __builtin_fmaf(beta, a.b2[c], a.b_ep[c]) : 0.f; }
+      matvec<R, 2 * R>(s, ept, n_ep, lane, o);
+#pragma unroll
+      for (int r = 0; r < 2 * R; ++r) { const int c = r * 64 + lane; if (c < n_ep) a.out[(size_t)node * a.ldout + c] = o[r]; }
+      continue;
+    }
     float y[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; y[r] = h < H ? beta * a.b2[h] : 0.f; }
@@ -256,7 +268,7 @@ int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
   if (a.n < 0 || a.h <= 0 || a.aggr < 0 || a.aggr > 1) return NBD_E_BADARG;
   if (a.n == 0) return 0;
   if (a.h > 64 * kMaxR) return NBD_E_UNSUPPORTED;
-  if (!a.w2t || !a.b2 || !a.out || (!a.rowptr && a.fixed_k < 0)) return NBD_E_BADARG;
+  if ((!a.w2t && a.epilogue != NBD_GNN_NEXT_PQ_FOLDED) || !a.b2 || !a.out || (!a.rowptr && a.fixed_k < 0)) return NBD_E_BADARG;
   if (!a.src && (a.rowptr || a.fixed_k > 0)) return NBD_E_BADARG;
   if (a.pq) { if (a.ldpq < 2 * a.h) return NBD_E_BADARG; }
   else { if (!a.x || !a.wpq || !a.bpq || a.f <= 0 || a.ldx < a.f) return NBD_E_BADARG; if (a.f > kFMax) return NBD_E_UNSUPPORTED; }
@@ -264,6 +276,7 @@ int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
   switch (a.epilogue) {
     case NBD_GNN_WRITE_X: if (a.ldout < a.h) return NBD_E_BADARG; break;
     case NBD_GNN_NEXT_PQ:
+    case NBD_GNN_NEXT_PQ_FOLDED:
       if (!a.w_ep || !a.b_ep || a.ep_out <= 0 || a.ldout < a.ep_out) return NBD_E_BADARG;
       if (a.ep_out > 2 * 64 * kMaxR || a.ep_out > 2 * 64 * ((a.h + 63) / 64)) return NBD_E_UNSUPPORTED;
       n_ep = a.ep_out; break;
@@ -279,7 +292,7 @@ int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
     default: return NBD_E_BADARG;
   }
   const int kp = 64 * ((a.h + 63) / 64);
-  const size_t shmem = ((size_t)kp * a.h + (size_t)kp * n_ep) * sizeof(float);
+  const size_t shmem = ((a.epilogue == NBD_GNN_NEXT_PQ_FOLDED ? 0 : (size_t)kp * a.h) + (size_t)kp * n_ep) * sizeof(float);
   if (shmem > 64 * 1024) return NBD_E_UNSUPPORTED;   // H = 64: 48 KiB; H = 128 fits only without NEXT_PQ
   int blocks = (a.n + 3) / 4;
   // residency: 48 KiB of LDS (W2^T + the next layer's [P|Q] matrix) lets 3 workgroups share a CU, 16 KiB

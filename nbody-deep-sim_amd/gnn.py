@@ -174,7 +174,15 @@ class GraphModel(torch.nn.Module):
         enc = self.node_encoder.folded() if isinstance(self.node_encoder, MLP) else None
         # transposed copies ([in][out]) for the fused layer kernel's LDS mat-vecs
         fused = [(wpq.t().contiguous(), w2.t().contiguous()) for (wpq, _, w2, _) in layers]
-        return {"enc": enc, "layers": layers, "head": head_chain(self.output), "fused_t": fused}
+        # layer l's second Linear folded into layer l+1's [P|Q] Linear (both act on the node's aggregate, nothing
+        # non-linear in between): next_pq = (Wpq' W2) S + beta (Wpq' b2) + bpq'  -- one mat-vec per node, not two
+        folded = []
+        for li in range(len(layers) - 1):
+            wpq_n, w2, b2 = layers[li + 1][0], layers[li][2], layers[li][3]
+            m = nnops.linear(wpq_n, w2.t().contiguous())                          # (2H, H) = Wpq' W2
+            c = nnops.linear(b2.unsqueeze(0).contiguous(), wpq_n).reshape(-1)     # (2H,)  = Wpq' b2
+            folded.append((m.t().contiguous(), c.contiguous()))
+        return {"enc": enc, "layers": layers, "head": head_chain(self.output), "fused_t": fused, "folded": folded}
 
     # ------------------------------------------------------------------ forward (gnn.py:130-148)
     def forward(self, data):
@@ -275,9 +283,9 @@ class GraphModel(torch.nn.Module):
         if h > 128 or e > 256:
             return False
         for li in range(n_layers):
-            ep_cols = 2 * h if li < n_layers - 1 else 0
             kp = 64 * ((h + 63) // 64)
-            if (kp * h + kp * ep_cols) * 4 > 64 * 1024:
+            lds = kp * 2 * h if li < n_layers - 1 else kp * h        # folded [P|Q] matrix, or W2^T on the last layer
+            if lds * 4 > 64 * 1024:
                 return False
         ln_g, ln_b = self.layer_norm.weight.detach(), self.layer_norm.bias.detach()
         pq = None
@@ -291,8 +299,10 @@ class GraphModel(torch.nn.Module):
                 kw.update(x=enc, f=e, wpq=wpq, bpq=layers[li][1][:h].contiguous())
             if li < n_layers - 1:
                 nxt = torch.empty((n, 2 * h), dtype=torch.float32, device=dev)
-                ok = nnops.gnn_layer(epilogue="next_pq", w_ep=w["fused_t"][li + 1][0], b_ep=layers[li + 1][1],
-                                     ep_out=2 * h, out=nxt, **kw)
+                m_t, c = w["folded"][li]
+                kw_f = dict(kw, w2t=None, b2=c)
+                ok = nnops.gnn_layer(epilogue="next_pq_folded", w_ep=m_t, b_ep=layers[li + 1][1], ep_out=2 * h,
+                                     out=nxt, **kw_f)
                 pq = nxt
             elif single_head:
                 out = torch.empty((n, head[0][0].shape[0]), dtype=torch.float32, device=dev)

@@ -169,7 +169,7 @@ def degree_scale(rowptr, n, mode, device):
     return out
 
 
-EPILOGUE = {"write_x": 0, "next_pq": 1, "final_head": 2, "final_ln": 3}
+EPILOGUE = {"write_x": 0, "next_pq": 1, "final_head": 2, "final_ln": 3, "next_pq_folded": 4}
 
 
 def gnn_layer(*, n, h, aggr, rowptr, src, fixed_k, w2t, b2, epilogue, out, pq=None, x=None, f=0, wpq=None, bpq=None,
@@ -179,7 +179,8 @@ def gnn_layer(*, n, h, aggr, rowptr, src, fixed_k, w2t, b2, epilogue, out, pq=No
     a = _lib.GnnLayerArgs()
     dev = out.device
     kp = 64 * ((h + 63) // 64)
-    if h > 128 or (pq is None and f > 8) or (kp * h + kp * (ep_out if epilogue == "next_pq" else 0)) * 4 > 64 * 1024:
+    lds_floats = kp * ep_out if epilogue == "next_pq_folded" else kp * h + kp * (ep_out if epilogue == "next_pq" else 0)
+    if h > 128 or (pq is None and f > 8) or lds_floats * 4 > 64 * 1024:
         return False
     if epilogue == "final_head" and ep_out > 8:
         return False
@@ -192,7 +193,7 @@ def gnn_layer(*, n, h, aggr, rowptr, src, fixed_k, w2t, b2, epilogue, out, pq=No
     a.pq, a.ldpq = _lib.ptr(pq), (_mat(pq, "pq") if pq is not None else 0)
     a.x, a.ldx, a.f = _lib.ptr(x), (_mat(x, "x") if x is not None else 0), f
     a.wpq, a.bpq = _lib.ptr(wpq), _lib.ptr(bpq)
-    a.h, a.aggr, a.w2t, a.b2 = h, AGGR[aggr], w2t.data_ptr(), b2.data_ptr()
+    a.h, a.aggr, a.w2t, a.b2 = h, AGGR[aggr], _lib.ptr(w2t), b2.data_ptr()
     a.epilogue, a.w_ep, a.b_ep, a.ep_out = EPILOGUE[epilogue], _lib.ptr(w_ep), _lib.ptr(b_ep), ep_out
     a.enc, a.ldenc, a.e = _lib.ptr(enc), (_mat(enc, "enc") if enc is not None else 0), e
     a.ln_g, a.ln_b, a.ln_eps = _lib.ptr(ln_g), _lib.ptr(ln_b), float(ln_eps)
