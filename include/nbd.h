@@ -130,6 +130,16 @@ int nbd_energy_f32(const float* posm, const float* vel, int n, float softening, 
 int nbd_knn_graph_f32(const float* pos, int n, int k, int loop, const int* seg_lo, const int* seg_hi,
                       const int64_t* out_off, int64_t num_edges, int64_t* edge_index, nbd_stream_t stream);
 
+/* The same search with a HINT: hint[i * kk + t], t < kk = min(k, n - 1 (+1 if loop)), are kk distinct
+ * neighbours of centre i from an earlier, similar configuration -- in a rollout, the previous step's own
+ * edge_index row 0. The largest of their CURRENT distances bounds the kk-th neighbour distance, which saves
+ * the first of the two candidate scans; the result is exactly that of nbd_knn_graph_f32 whatever the hint
+ * holds (a hint that is not kk distinct valid neighbours is detected and ignored for that centre). hint may
+ * alias edge_index (each centre reads its hint before writing its own list). No batch segments / out_off. */
+int nbd_knn_graph_hint_f32(const float* pos, int n, int k, int loop, const int* seg_lo, const int* seg_hi,
+                           const int64_t* out_off, int64_t num_edges, int64_t* edge_index, const int64_t* hint,
+                           nbd_stream_t stream);
+
 /* radius_graph(pos, r, batch, loop, max_num_neighbors) -- contconv.py:225 -- in padded (ELL) form:
  * nbr[i][0..deg[i]) = the first max_num_neighbors indices j (ascending) with d2 < radius_sq
  * (strict), j == i iff loop; last[i] = the largest listed j (-1 if none). No host sync needed. */

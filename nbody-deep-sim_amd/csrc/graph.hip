@@ -136,7 +136,7 @@ template <int R, int RI>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_select_kernel(
     const float* __restrict__ pos, int n, int k, int loop, const int* __restrict__ seg_lo,
     const int* __restrict__ seg_hi, const int64_t* __restrict__ out_off, int64_t e_total,
-    int64_t* __restrict__ edge_index) {
+    int64_t* edge_index, const int64_t* hint) {      // hint may alias edge_index: no __restrict__ on either
   __shared__ float ld[kWavesPerBlock][kSelCap];
   __shared__ int lj[kWavesPerBlock][kSelCap];
   const int w = wave_id();
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_select_kernel(
   const float inf = __builtin_inff();
 
   // A: per-lane R smallest (sorted ascending in m[0..R-1])
+  auto phase_a = [&]() -> float {
   float m[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) m[r] = inf;
@@ -191,7 +192,29 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_select_kernel(
     const unsigned long long who = __ballot(cand != -inf);
     bound = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand), __builtin_ctzll(who)));
   }
+  return bound;
+  };
+  // A': with a hint -- kk distinct neighbours of this centre from an earlier, similar configuration (the
+  // previous rollout step's own list) -- the largest of THEIR current distances already bounds the kk-th
+  // neighbour distance from above, and the whole first scan is skipped. Invalid entries (out of range,
+  // the centre itself) void the hint; duplicates can make the bound too small, which phase B detects.
+  float bound = inf;
+  bool hinted = false;
+  if (hint) {
+    float hm = -inf;
+    for (int t = lane; t < kk; t += 64) {
+      const int64_t j = hint[(int64_t)i * kk + t];
+      const bool ok = j >= lo && j < hi && (loop || j != i);
+      hm = fmaxf(hm, ok ? dist2(pos, (int)j, xi, yi, zi) : inf);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) hm = fmaxf(hm, __shfl_xor(hm, off));
+    bound = hm;
+    hinted = bound < inf;
+  }
+  if (!hinted) bound = phase_a();
   // B: compact everything within the bound
+  auto phase_b = [&](float bnd) -> int {
   int count = 0;
   for (int c0 = lo; c0 < hi; c0 += 256) {
     float px[4], py[4], pz[4];
@@ -205,12 +228,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_select_kernel(
       const int j = c0 + 64 * u + lane;
       const float dx = px[u] - xi, dy = py[u] - yi, dz = pz[u] - zi;
       const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      const bool hit = j < hi && (loop || j != i) && d <= bound;
+      const bool hit = j < hi && (loop || j != i) && d <= bnd;
       const unsigned long long mask = __ballot(hit);
       const int slot = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
       if (hit && slot < kSelCap) { ld[w][slot] = d; lj[w][slot] = j; }
       count += __builtin_popcountll(mask);
     }
+  }
+  return count;
+  };
+  int count = phase_b(bound);
+  if (hinted && count < kk) {              // the hint was not kk distinct neighbours: do the full first scan
+    __builtin_amdgcn_wave_barrier();
+    bound = phase_a();
+    count = phase_b(bound);
   }
   const int64_t base = out_off ? out_off[i] : (int64_t)i * kk;
   if (count > kSelCap) {                     // cannot happen with distinct distances; massive ties can
@@ -564,7 +595,15 @@ extern "C" {
 
 int nbd_knn_graph_f32(const float* pos, int n, int k, int loop, const int* seg_lo, const int* seg_hi,
                       const int64_t* out_off, int64_t num_edges, int64_t* edge_index, nbd_stream_t stream) {
+  return nbd_knn_graph_hint_f32(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index, nullptr, stream);
+}
+
+int nbd_knn_graph_hint_f32(const float* pos, int n, int k, int loop, const int* seg_lo, const int* seg_hi,
+                           const int64_t* out_off, int64_t num_edges, int64_t* edge_index, const int64_t* hint,
+                           nbd_stream_t stream) {
   if (n < 0 || k < 0 || num_edges < 0 || (seg_lo == nullptr) != (seg_hi == nullptr)) return NBD_E_BADARG;
+  // a hint is a regular list (min(k, n - 1 + loop) sources per centre, no batch segments)
+  if (hint && (seg_lo || out_off || num_edges != (int64_t)n * (k < n - (loop ? 0 : 1) ? k : n - (loop ? 0 : 1)))) return NBD_E_BADARG;
   if (n == 0 || k == 0 || num_edges == 0) return 0;
   if (!pos || !edge_index) return NBD_E_BADARG;
   if (k > 256) return NBD_E_UNSUPPORTED;
@@ -574,13 +613,13 @@ int nbd_knn_graph_f32(const float* pos, int n, int k, int loop, const int* seg_l
   // NBD_KNN_INSERTION=1 forces the insertion form (cross-check / comparison).
   static const bool force_insert = [] { const char* e = getenv("NBD_KNN_INSERTION"); return e && e[0] == '1'; }();
   if (!force_insert && k <= 40)
-    knn_select_kernel<1, 1><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
+    knn_select_kernel<1, 1><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index, hint);
   else if (!force_insert && k <= 64)
-    knn_select_kernel<2, 1><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
+    knn_select_kernel<2, 1><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index, hint);
   else if (!force_insert && k <= 100)
-    knn_select_kernel<2, 2><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
+    knn_select_kernel<2, 2><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index, hint);
   else if (!force_insert && k <= 200)
-    knn_select_kernel<4, 4><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
+    knn_select_kernel<4, 4><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index, hint);
   else if (k <= 64)
     knn_kernel<1><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
   else if (k <= 128)

@@ -153,6 +153,7 @@ class GraphModel(torch.nn.Module):
         self.use_fused = True          # one launch per EdgeConv layer when the shapes allow (csrc/gnn_fused.hip)
         self._fused_out = None
         self._brs_const = None
+        self._knn_buf = None
         self.to(device)
 
     def get_config(self):
@@ -331,7 +332,14 @@ class GraphModel(torch.nn.Module):
                 raise NbdError("GraphModel.predict: tensors must live on the GPU (no CPU path)")
             # transform_to_graph + forward without materialising x = [pos | feat] first: the model input is
             # [pos | mass] (input_dim == 4, gnn.py:131-132) or [pos | feat]
-            ei = graphops.knn_graph(pos, k=k, batch=None, loop=False)
+            # the previous call's graph (same n, k) is both the hint and the output buffer of this search: in a
+            # rollout consecutive configurations are close, and the search result does not depend on the hint
+            kk = max(min(k, pos.shape[0] - 1), 0)
+            buf = self._knn_buf
+            if buf is not None and (buf.shape != (2, pos.shape[0] * kk) or buf.device != pos.device):
+                buf = None
+            ei = graphops.knn_graph(pos, k=k, batch=None, loop=False, hint=buf, out=buf)
+            self._knn_buf = ei
             x_in = torch.cat((pos, feat[:, 3:]), dim=-1) if self.input_dim == 4 else torch.cat((pos, feat), dim=-1)
             pred = self._forward_inference(x_in.to(torch.float32), ei, max(min(k, pos.shape[0] - 1), 0))
         return pred

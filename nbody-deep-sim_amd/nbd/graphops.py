@@ -41,8 +41,12 @@ def _segments(batch: torch.Tensor | None, n: int, device):
     return lo, hi
 
 
-def knn_graph(x: torch.Tensor, k: int, batch: torch.Tensor | None = None, loop: bool = False) -> torch.Tensor:
-    """int64 edge_index [2, E]: per centre i its k nearest j (ascending (d2, j)); row 0 = j, row 1 = i."""
+def knn_graph(x: torch.Tensor, k: int, batch: torch.Tensor | None = None, loop: bool = False,
+              hint: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """int64 edge_index [2, E]: per centre i its k nearest j (ascending (d2, j)); row 0 = j, row 1 = i.
+    hint: an earlier edge_index of the same shape for a similar configuration (the previous rollout step): its
+    neighbours' current distances bound the search and save one of the two candidate scans; the result does not
+    depend on it. out: write into this (2, E) tensor (may be the hint itself)."""
     n = x.shape[0]
     if x.dim() != 2 or x.shape[1] != 3:
         raise _lib.NbdError(f"knn_graph: this build searches 3-D positions (n,3) as the reference does "
@@ -58,11 +62,24 @@ def knn_graph(x: torch.Tensor, k: int, batch: torch.Tensor | None = None, loop: 
         per = torch.clamp((hi - lo).to(torch.int64) - (0 if loop else 1), min=0, max=k)
         off = (torch.cumsum(per, 0) - per).contiguous()
         e = int(per.sum().item())
-    ei = torch.empty((2, e), dtype=torch.int64, device=dev)
+    if out is not None:
+        if out.shape != (2, e) or out.dtype != torch.int64 or not out.is_contiguous() or out.device != dev:
+            raise _lib.NbdError(f"knn_graph: out must be a contiguous int64 (2, {e}) tensor on {dev}")
+        ei = out
+    else:
+        ei = torch.empty((2, e), dtype=torch.int64, device=dev)
+    use_hint = (hint is not None and lo is None and e > 0 and hint.shape == (2, e) and hint.dtype == torch.int64
+                and hint.is_contiguous() and hint.device == dev)
     if e:
         with _lib.on_device(dev):
-            _lib.check(_lib.lib().nbd_knn_graph_f32(pos.data_ptr(), n, k, int(loop), _lib.ptr(lo), _lib.ptr(hi),
-                                                    _lib.ptr(off), e, ei.data_ptr(), _stream(dev)), "nbd_knn_graph_f32")
+            if use_hint:
+                _lib.check(_lib.lib().nbd_knn_graph_hint_f32(pos.data_ptr(), n, k, int(loop), None, None, None, e,
+                                                             ei.data_ptr(), hint.data_ptr(), _stream(dev)),
+                           "nbd_knn_graph_hint_f32")
+            else:
+                _lib.check(_lib.lib().nbd_knn_graph_f32(pos.data_ptr(), n, k, int(loop), _lib.ptr(lo), _lib.ptr(hi),
+                                                        _lib.ptr(off), e, ei.data_ptr(), _stream(dev)),
+                           "nbd_knn_graph_f32")
     ei._nbd_grouped = True        # edges come out grouped by centre (row 1 ascending): csr_by_target need not check
     return ei
 

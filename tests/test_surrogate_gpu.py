@@ -512,3 +512,45 @@ def test_trainer_rollout_reproduces_reference_frame(gpu_device):
         cols = list(g["rollout_numeric_columns"])
         assert np.array_equal(df[cols].to_numpy(dtype=np.float64), g["rollout_values"]), use_graph
         assert df["filename"].tolist() == list(g["rollout_filename"])
+
+
+@pytest.mark.parametrize("n,k", [(500, 10), (4096, 50), (700, 70), (65, 64)])
+def test_knn_graph_result_does_not_depend_on_the_hint(n, k, gpu_device):
+    """nbd_knn_graph_hint_f32: a previous graph bounds the search; a perfect, stale, duplicated or garbage hint
+    must all give exactly the un-hinted (= oracle) result, also when the hint buffer is the output buffer."""
+    from nbd import graphops
+    from oracle import surrogate_oracle as so
+    pos, vel, _ = _plummer_pos(n, 30 + n)
+    ref = so.knn_graph(pos, k)
+    kk = min(k, n - 1)
+    g = torch.Generator().manual_seed(n)
+    moved = pos + 0.05 * vel                                            # "the next rollout step"
+    ref_moved = so.knn_graph(moved, k)
+    good = ref.clone()
+    dup = ref.clone(); dup[0] = dup[0].reshape(n, kk)[:, :1].expand(n, kk).reshape(-1)      # one neighbour repeated kk times
+    garbage = torch.stack([torch.randint(-5, n + 5, (n * kk,), generator=g), ref[1]])
+    selfs = torch.stack([ref[1].clone(), ref[1]])                       # every hint is the centre itself
+    far = torch.stack([torch.randint(0, n, (n * kk,), generator=g), ref[1]])   # random (mostly distant) nodes
+    for name, hint in (("good", good), ("dup", dup), ("garbage", garbage), ("self", selfs), ("far", far)):
+        got = graphops.knn_graph(moved.cuda(), k, hint=hint.cuda().contiguous())
+        assert torch.equal(got.cpu(), ref_moved), name
+    buf = graphops.knn_graph(pos.cuda(), k)
+    assert torch.equal(buf.cpu(), ref)
+    out = graphops.knn_graph(moved.cuda(), k, hint=buf, out=buf)        # in place: hint and output share the buffer
+    assert out.data_ptr() == buf.data_ptr() and torch.equal(buf.cpu(), ref_moved)
+
+
+def test_gnn_predict_reuses_its_previous_graph_as_hint(gpu_device):
+    import gnn
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(2)
+    ora = so.GraphModelOracle(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", neighbors=10).eval()
+    model = gnn.GraphModel(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", neighbors=10, device="cuda")
+    _copy_state(model, ora)
+    pos, vel, m = _plummer_pos(600, 6)
+    feat = torch.cat([vel, m[:, None] * 600], 1)
+    for step in range(3):                                               # second and third call run hinted, in place
+        p = pos + 0.02 * step * vel
+        assert global_rel(model.predict(p.cuda(), feat.cuda()).cpu(), ora.predict(p, feat, k=50)) < TOL, step
+    other, _, _ = _plummer_pos(600, 99)                                 # an unrelated system of the same size
+    assert global_rel(model.predict(other.cuda(), feat.cuda()).cpu(), ora.predict(other, feat, k=50)) < TOL
