@@ -28,7 +28,7 @@ constexpr int kFMax = 8;        // on-the-fly P/Q: input features, zero padded
 constexpr int kMaxR = 2;        // channels per lane: H <= 128
 constexpr int kMaxZR = 4;       // concat width per lane: E + H <= 256
 constexpr int kMaxOut = 8;
-constexpr int kEF = 8;          // edges (neighbour rows) in flight per wave
+constexpr int kEF = 16;         // edges (neighbour rows) in flight per wave
 
 __device__ __forceinline__ float lane_bcast(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
