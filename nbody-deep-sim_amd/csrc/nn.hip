@@ -14,6 +14,7 @@
 //                           dense MFMA GEMM and the (E, I, O) interpolated-filter tensor never exists.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/nbd.h"
 
@@ -355,7 +356,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // Trilinear weights follow F.grid_sample(align_corners=True) with coordinate component 0 indexing
 // filter axis 2 (x fastest) and component 2 indexing axis 0: cell = (z*D + y)*D + x  (contconv.py:62-75).
 struct EdgeGeo { int c, ix, iy, iz; float tx, ty, tz, window; };
-constexpr int kGeoCache = 256;     // edge geometries kept in LDS per node (in-degree above this: recomputed per slab)
+// edge geometries kept in LDS per node (in-degree above this: recomputed per slab). 64 = one chunk: a cache
+// of 256 entries (8 KiB more LDS per wave, 6 instead of 8 waves per CU) cost 5 % of the rollout step.
+constexpr int kGeoCache = 64;
 
 __device__ __forceinline__ EdgeGeo edge_geometry(const float* __restrict__ pos, int c, float xn, float yn, float zn,
                                                  float r2max, float half) {
