@@ -5,6 +5,8 @@ from __future__ import annotations
 
 import torch
 
+from . import graphops
+
 
 class Data:
     def __init__(self, x=None, edge_index=None, edge_attr=None, y=None, batch=None, **extra):
@@ -57,10 +59,10 @@ def collate(graphs: list[Data]) -> Data:
                                         torch.tensor(counts, dtype=torch.int64).to(dev, non_blocking=True),
                                         output_size=e_total)
         out["edge_index"] = ei + shift
-        if all(getattr(g.edge_index, "_nbd_grouped", False) for g in with_edges):
-            out["edge_index"]._nbd_grouped = True      # grouped member graphs stay grouped after the offsets
+        if all(graphops.marked(g.edge_index, "_nbd_grouped") for g in with_edges):
+            graphops.mark(out["edge_index"], "_nbd_grouped")     # grouped member graphs stay grouped after the offsets
     else:
         out["edge_index"] = None
     out["batch"] = torch.repeat_interleave(gid, sizes_t, output_size=n_total)
-    out["batch"]._nbd_sorted = True            # ascending by construction: graphops need not validate (a host sync)
+    graphops.mark(out["batch"], "_nbd_sorted")  # ascending by construction: graphops need not validate (a host sync)
     return Data(**out)

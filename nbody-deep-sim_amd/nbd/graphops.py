@@ -14,6 +14,16 @@ from . import _lib
 from .direct import _chk
 
 
+def mark(t: torch.Tensor, attr: str) -> None:
+    """Record a structural fact about tensor `t` (sorted / grouped) together with its version counter, so that an
+    in-place edit of the tensor silently retires the fact."""
+    setattr(t, attr, t._version)
+
+
+def marked(t, attr: str) -> bool:
+    return getattr(t, attr, None) == getattr(t, "_version", -1)
+
+
 def _stream(dev):
     return _lib.current_stream(dev)
 
@@ -30,7 +40,7 @@ def _segments(batch: torch.Tensor | None, n: int, device):
     if memo is not None and memo[0] == batch._version and memo[1].device == torch.device(device):
         return memo[1], memo[2]
     b = batch.to(device=device, dtype=torch.int64).contiguous()
-    if not getattr(batch, "_nbd_sorted", False) and n > 1 and bool((b[1:] < b[:-1]).any()):   # one sync, first sight only
+    if not marked(batch, "_nbd_sorted") and n > 1 and bool((b[1:] < b[:-1]).any()):   # one sync, first sight only
         raise _lib.NbdError("batch vector must be sorted (PyG convention)")
     lo = torch.searchsorted(b, b, right=False).to(torch.int32).contiguous()
     hi = torch.searchsorted(b, b, right=True).to(torch.int32).contiguous()
@@ -80,7 +90,7 @@ def knn_graph(x: torch.Tensor, k: int, batch: torch.Tensor | None = None, loop: 
                 _lib.check(_lib.lib().nbd_knn_graph_f32(pos.data_ptr(), n, k, int(loop), _lib.ptr(lo), _lib.ptr(hi),
                                                         _lib.ptr(off), e, ei.data_ptr(), _stream(dev)),
                            "nbd_knn_graph_f32")
-    ei._nbd_grouped = True        # edges come out grouped by centre (row 1 ascending): csr_by_target need not check
+    mark(ei, "_nbd_grouped")      # edges come out grouped by centre (row 1 ascending): csr_by_target need not check
     return ei
 
 
@@ -173,7 +183,7 @@ def csr_by_target(edge_index: torch.Tensor, n: int, return_tgt: bool = False):
     return_tgt also the target of every edge in that order."""
     tgt = edge_index[1]
     src = edge_index[0]
-    if not getattr(edge_index, "_nbd_grouped", False) and tgt.numel() > 1 and bool((tgt[1:] < tgt[:-1]).any()):
+    if not marked(edge_index, "_nbd_grouped") and tgt.numel() > 1 and bool((tgt[1:] < tgt[:-1]).any()):
         order = torch.sort(tgt, stable=True).indices
         tgt, src = tgt[order], src[order]
     counts = torch.bincount(tgt, minlength=n)
