@@ -344,6 +344,21 @@ class GraphModel(torch.nn.Module):
             pred = self._forward_inference(x_in.to(torch.float32), ei, max(min(k, pos.shape[0] - 1), 0))
         return pred
 
+    def _predict_posm(self, posm, pos, k=50):
+        """predict() for callers that already hold the packed rows {x, y, z, mass} the kick-drift kernel writes
+        (Trainer's captured rollout step): with input_dim == 4 that IS the model input [pos | mass]
+        (gnn.py:131-132), so nothing is concatenated. Same graph, same kernels, same values as predict()."""
+        self.eval()
+        with torch.no_grad():
+            n = pos.shape[0]
+            kk = max(min(k, n - 1), 0)
+            buf = self._knn_buf
+            if buf is not None and (buf.shape != (2, n * kk) or buf.device != pos.device):
+                buf = None
+            ei = graphops.knn_graph(pos, k=k, batch=None, loop=False, hint=buf, out=buf)
+            self._knn_buf = ei
+            return self._forward_inference(posm[:n], ei, kk)
+
     def predict_graph(self, data):
         self.eval()
         with torch.no_grad():

@@ -111,11 +111,24 @@ class Trainer:
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             half, full = direct.f32(0.5 * dt), direct.f32(dt)
+            # a model whose input is [pos | mass] (GraphModel, input_dim 4) can read the packed {x,y,z,m} rows the
+            # kick-drift kernel writes anyway: no concatenations in the captured step
+            packed = (hasattr(self.model, "_predict_posm") and getattr(self.model, "input_dim", 0) == 4
+                      and m.dim() == 2 and m.shape[1] == 1 and m.dtype == torch.float32)
+            keep = [m]                 # every buffer the captured kernels touch must outlive the graph
+            if packed:
+                posm = torch.zeros((direct.padded_len(s_pos.shape[0]), 4), dtype=torch.float32, device=s_pos.device)
+                m_flat = m.reshape(-1).contiguous()
+                keep += [posm, m_flat]
             with torch.cuda.graph(graph):
                 # step() on the static state IN PLACE (same kernels and arithmetic; the functional clones and
                 # copy-backs of step() would be five more launches per replay)
-                direct.kick_drift(s_pos, s_vel, s_acc, None, half, full)
-                o_acc = self.model.predict(s_pos, torch.cat([s_vel, m], dim=-1))
+                if packed:
+                    direct.kick_drift(s_pos, s_vel, s_acc, m_flat, half, full, posm=posm)
+                    o_acc = self.model._predict_posm(posm, s_pos)
+                else:
+                    direct.kick_drift(s_pos, s_vel, s_acc, None, half, full)
+                    o_acc = self.model.predict(s_pos, torch.cat([s_vel, m], dim=-1))
                 direct.kick(s_vel, o_acc, half)
                 s_acc.copy_(o_acc)
         except Exception as exc:                          # pragma: no cover - depends on runtime support
@@ -129,6 +142,7 @@ class Trainer:
             the next call (evaluate_rollout copies them into its table right away)."""
             graph.replay()
             return (s_pos.clone(), s_vel.clone(), s_acc.clone()) if clone else (s_pos, s_vel, s_acc)
+        advance.keep_alive = keep      # (s_pos / s_vel / s_acc and the graph itself live in the closure)
         return advance
 
     # ------------------------------------------------------------------ trainer.py:228-344
