@@ -142,6 +142,9 @@ class Trainer:
             the next call (evaluate_rollout copies them into its table right away)."""
             graph.replay()
             return (s_pos.clone(), s_vel.clone(), s_acc.clone()) if clone else (s_pos, s_vel, s_acc)
+        cache = getattr(self.model, "_cache", None)
+        if cache is not None:          # derived (folded / transposed) weights the captured kernels read
+            keep.append(cache.value)
         advance.keep_alive = keep      # (s_pos / s_vel / s_acc and the graph itself live in the closure)
         return advance
 
