@@ -152,6 +152,7 @@ class GraphModel(torch.nn.Module):
         self._cache = _WeightCache(self)
         self.use_fused = True          # one launch per EdgeConv layer when the shapes allow (csrc/gnn_fused.hip)
         self._fused_out = None
+        self._out_hint = None
         self._brs_const = None
         self._knn_buf = None
         self.to(device)
@@ -197,7 +198,7 @@ class GraphModel(torch.nn.Module):
         x_in = torch.cat((x7[:, :3], x7[:, 6:]), dim=-1) if self.input_dim == 4 else x7
         return self._forward_inference(x_in.to(torch.float32), data.edge_index, getattr(data, "_regular_k", None))
 
-    def _forward_inference(self, x_in, ei, reg):
+    def _forward_inference(self, x_in, ei, reg, out=None):
         """Inference forward on the model input x_in (n, input_dim) = [pos | mass] or [pos | vel | mass]."""
         w = self._cache.get(self._build_weights)
         n = x_in.shape[0]
@@ -216,7 +217,10 @@ class GraphModel(torch.nn.Module):
             # the fused layer kernels read the encoder output through (pointer, row stride): the model input
             # itself when there is no encoder -- no concatenation buffer, no copy
             x_c = x_in if x_in.stride(1) == 1 else x_in.contiguous()
-            if self._forward_fused(w, x_c, n, h, rowptr, src, fixed_k, aggr, None):
+            self._out_hint = out           # a caller-owned (n, output_dim) buffer the last fused layer may write into
+            done = self._forward_fused(w, x_c, n, h, rowptr, src, fixed_k, aggr, None)
+            self._out_hint = None
+            if done:
                 return self._fused_out
         cat_buf = torch.empty((n, enc_dim + h), dtype=torch.float32, device=dev)
         enc_view, gnn_view = cat_buf[:, :enc_dim], cat_buf[:, enc_dim:]
@@ -306,7 +310,12 @@ class GraphModel(torch.nn.Module):
                                      out=nxt, **kw_f)
                 pq = nxt
             elif single_head:
-                out = torch.empty((n, head[0][0].shape[0]), dtype=torch.float32, device=dev)
+                hint = getattr(self, "_out_hint", None)
+                if (hint is not None and tuple(hint.shape) == (n, head[0][0].shape[0]) and hint.dtype == torch.float32
+                        and hint.is_contiguous() and hint.device == dev):
+                    out = hint
+                else:
+                    out = torch.empty((n, head[0][0].shape[0]), dtype=torch.float32, device=dev)
                 ok = nnops.gnn_layer(epilogue="final_head", w_ep=head[0][0], b_ep=head[0][1],
                                      ep_out=head[0][0].shape[0], enc=enc, e=e, ln_g=ln_g, ln_b=ln_b,
                                      ln_eps=self.layer_norm.eps, out=out, **kw)
@@ -344,7 +353,7 @@ class GraphModel(torch.nn.Module):
             pred = self._forward_inference(x_in.to(torch.float32), ei, max(min(k, pos.shape[0] - 1), 0))
         return pred
 
-    def _predict_posm(self, posm, pos, k=50):
+    def _predict_posm(self, posm, pos, k=50, out=None):
         """predict() for callers that already hold the packed rows {x, y, z, mass} the kick-drift kernel writes
         (Trainer's captured rollout step): with input_dim == 4 that IS the model input [pos | mass]
         (gnn.py:131-132), so nothing is concatenated. Same graph, same kernels, same values as predict()."""
@@ -357,7 +366,7 @@ class GraphModel(torch.nn.Module):
                 buf = None
             ei = graphops.knn_graph(pos, k=k, batch=None, loop=False, hint=buf, out=buf)
             self._knn_buf = ei
-            return self._forward_inference(posm[:n], ei, kk)
+            return self._forward_inference(posm[:n], ei, kk, out=out)
 
     def predict_graph(self, data):
         self.eval()

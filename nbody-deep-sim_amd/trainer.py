@@ -125,12 +125,13 @@ class Trainer:
                 # copy-backs of step() would be five more launches per replay)
                 if packed:
                     direct.kick_drift(s_pos, s_vel, s_acc, m_flat, half, full, posm=posm)
-                    o_acc = self.model._predict_posm(posm, s_pos)
+                    o_acc = self.model._predict_posm(posm, s_pos, out=s_acc)   # s_acc is consumed by kick_drift above
                 else:
                     direct.kick_drift(s_pos, s_vel, s_acc, None, half, full)
                     o_acc = self.model.predict(s_pos, torch.cat([s_vel, m], dim=-1))
                 direct.kick(s_vel, o_acc, half)
-                s_acc.copy_(o_acc)
+                if o_acc.data_ptr() != s_acc.data_ptr():
+                    s_acc.copy_(o_acc)
         except Exception as exc:                          # pragma: no cover - depends on runtime support
             import warnings
             warnings.warn(f"hipGraph capture of the rollout step failed ({exc}); using eager launches")
