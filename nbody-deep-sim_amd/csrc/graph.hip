@@ -131,6 +131,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_kernel(
 // overflows (only possible with hundreds of exactly tied distances) the wave falls back to the
 // insertion form for that centre.
 constexpr int kSelCap = 512;     // LDS list entries per wave
+constexpr int kBU = 4;           // candidate chunks (of 64) whose position loads are in flight together in scan B
 
 template <int R, int RI>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_select_kernel(
@@ -216,15 +217,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_select_kernel(
   // B: compact everything within the bound
   auto phase_b = [&](float bnd) -> int {
   int count = 0;
-  for (int c0 = lo; c0 < hi; c0 += 256) {
-    float px[4], py[4], pz[4];
+  for (int c0 = lo; c0 < hi; c0 += 64 * kBU) {
+    float px[kBU], py[kBU], pz[kBU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kBU; ++u) {
       const int jc = min(c0 + 64 * u + lane, hi - 1);
       px[u] = pos[3 * jc]; py[u] = pos[3 * jc + 1]; pz[u] = pos[3 * jc + 2];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kBU; ++u) {
       const int j = c0 + 64 * u + lane;
       const float dx = px[u] - xi, dy = py[u] - yi, dz = pz[u] - zi;
       const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
