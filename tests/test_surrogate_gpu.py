@@ -554,3 +554,54 @@ def test_gnn_predict_reuses_its_previous_graph_as_hint(gpu_device):
         assert global_rel(model.predict(p.cuda(), feat.cuda()).cpu(), ora.predict(p, feat, k=50)) < TOL, step
     other, _, _ = _plummer_pos(600, 99)                                 # an unrelated system of the same size
     assert global_rel(model.predict(other.cuda(), feat.cuda()).cpu(), ora.predict(other, feat, k=50)) < TOL
+
+
+# ------------------------------------------------------------------ BASELINE configs[2] / [3] at their full sizes
+def test_gnn_full_size_config_matches_oracle(gpu_device):
+    """configs[2]: published GNN shape, N = 4096, k = 32 -- the whole forward against the oracle at full size."""
+    import gnn
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(7)
+    cfg = dict(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", neighbors=10)
+    ora = so.GraphModelOracle(**cfg).eval()
+    model = gnn.GraphModel(device="cuda", **cfg)
+    _copy_state(model, ora)
+    n = 4096
+    pos, vel, m = _plummer_pos(n, 1234)
+    feat = torch.cat([vel, m[:, None] * n], 1)
+    ref = ora.predict(pos, feat, k=32)
+    got = model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu()
+    assert global_rel(got, ref) < TOL and row_rel(got, ref) < 10 * TOL
+    again = model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu()            # second call: hinted kNN, in place
+    assert torch.equal(again, got)
+
+
+def test_contconv_full_size_config_rows_match_oracle_and_layer_is_linear(gpu_device):
+    """configs[3]: published ContinuousConv layer shape (D = 6, 128 -> 128 channels) at N = 16 384 with a mean
+    radius-1 degree of ~32. The oracle is too slow for all rows, so (a) 48 random rows are checked against the
+    oracle evaluated on exactly the edges that end in them, (b) the layer (no activation) must be linear in the
+    features at full size: conv(a f1 + b f2) = a conv(f1) + b conv(f2)."""
+    import contconv
+    from nbd import graphops
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(11)
+    n, D, C = 16384, 6, 128
+    pos, _, _ = _plummer_pos(n, 1234)
+    pos = pos * 4.6                                                  # mean number of bodies within radius 1 ~ 32
+    ora = so.ContinuousConvOracle(C, C, D, radius=1.0, agg="mean")
+    layer = contconv.ContinuousConv(C, C, D, radius=1.0, agg="mean").cuda()
+    _copy_state(layer, ora)
+    f1, f2 = torch.randn(n, C), torch.randn(n, C)
+    ei = graphops.radius_graph(pos.cuda(), 1.0, loop=True, max_num_neighbors=32)
+    with torch.no_grad():
+        o1 = layer(pos.cuda(), f1.cuda(), edge_index=ei)
+        o2 = layer(pos.cuda(), f2.cuda(), edge_index=ei)
+        o12 = layer(pos.cuda(), (0.5 * f1 - 2.0 * f2).cuda(), edge_index=ei)
+        assert global_rel(o12.cpu(), (0.5 * o1 - 2.0 * o2).cpu()) < TOL
+        rows = torch.randperm(n, generator=torch.Generator().manual_seed(3))[:48]
+        ei_c = ei.cpu()
+        keep = torch.isin(ei_c[0], rows)                                 # aggregation happens at edge_index[0]
+        ref = ora(pos, f1, ei_c[:, keep])[rows]
+        assert float(ref.abs().max()) > 0
+        assert global_rel(o1.cpu()[rows], ref) < TOL
+    assert 10 < ei.shape[1] / n <= 32                                  # capped at 32 per centre (uncapped mean ~32)
