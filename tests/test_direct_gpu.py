@@ -355,3 +355,29 @@ def test_dataset_cli_reproduces_the_reference_csv(tmp_path, gpu_device):
         for c in ("u", "k"):
             assert abs(float(a[c]) - float(b[c])) <= 2e-5 * abs(float(a[c])), (c, a[c], b[c])
         assert float(b["step_time"]) >= 0.0
+
+
+def test_config5_size_range_partition_on_one_gpu(gpu_device):
+    """BASELINE configs[4]: 524 288 bodies range-partitioned over 8 ranks. On one GPU: the eight target shards
+    (65 536 targets x all 524 288 sources, tgt_global_offset = lo -- exactly what each rank launches) against 64
+    sampled rows of an fp64 evaluation and against momentum conservation of the assembled result."""
+    from nbd import direct
+    from nbd.plummer import generate_plummer
+    n, ranks = 524288, 8
+    p, v, m = generate_plummer(n, seed=1234)
+    pos = torch.tensor(p, dtype=torch.float32).cuda(); mass = torch.tensor(m, dtype=torch.float32).cuda()
+    posm = direct.pack_posm(pos, mass)
+    per = n // ranks
+    eps2 = direct.f32(0.1 ** 2)
+    acc = torch.cat([direct.accel(posm, n, posm[r * per:], per, r * per, eps2, 1.0) for r in range(ranks)])
+    a64 = _np(acc).astype(np.float64)
+    pf, mf = p.astype(np.float32).astype(np.float64), m.astype(np.float32).astype(np.float64)
+    net = (mf[:, None] * a64).sum(0)
+    assert np.abs(net).max() < 1e-6 * (mf[:, None] * np.abs(a64)).sum(0).max()
+    rows = np.random.default_rng(5).choice(n, 64, replace=False)
+    d = pf[None, :, :] - pf[rows, None, :]
+    q = (d * d).sum(2) + float(np.float32(0.1 ** 2))
+    inv = q ** -1.5
+    inv[np.arange(64), rows] = 0.0
+    ref = (d * (inv * mf[None, :])[:, :, None]).sum(1)
+    assert row_rel(a64[rows], ref) < 2e-6
