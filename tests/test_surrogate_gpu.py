@@ -605,3 +605,25 @@ def test_contconv_full_size_config_rows_match_oracle_and_layer_is_linear(gpu_dev
         assert float(ref.abs().max()) > 0
         assert global_rel(o1.cpu()[rows], ref) < TOL
     assert 10 < ei.shape[1] / n <= 32                                  # capped at 32 per centre (uncapped mean ~32)
+
+
+def test_random_batched_graph_sweep(gpu_device):
+    """30 random batches (ragged segment sizes incl. 1-node graphs, random k / radius / cap / loop): kNN and radius
+    graphs index-exact against the oracle -- exercises the slice / 128-centre-group boundaries of the streaming search."""
+    from nbd import graphops
+    from oracle import surrogate_oracle as so
+    rng = np.random.default_rng(77)
+    for trial in range(30):
+        n_graphs = int(rng.integers(1, 9))
+        sizes = [int(rng.choice([1, 2, 3, 17, 63, 64, 65, 127, 128, 129, 200, 333])) for _ in range(n_graphs)]
+        n = sum(sizes)
+        pos = torch.tensor(rng.normal(size=(n, 3)) * rng.choice([0.3, 1.0, 3.0]), dtype=torch.float32)
+        b = _batch(n, sizes) if n_graphs > 1 or trial % 3 else None
+        k = int(rng.choice([1, 4, 10, 50, 70]))
+        r = float(rng.choice([0.2, 0.7, 1.5]))
+        cap = int(rng.choice([1, 5, 32, 100]))
+        loop = bool(trial % 2)
+        bc = b.cuda() if b is not None else None
+        assert torch.equal(graphops.knn_graph(pos.cuda(), k, batch=bc).cpu(), so.knn_graph(pos, k, batch=b)), ("knn", trial)
+        assert torch.equal(graphops.radius_graph(pos.cuda(), r, batch=bc, loop=loop, max_num_neighbors=cap).cpu(),
+                           so.radius_graph(pos, r, batch=b, loop=loop, max_num_neighbors=cap)), ("radius", trial, sizes, r, cap)

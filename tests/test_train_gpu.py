@@ -411,3 +411,37 @@ def test_contconv_training_follows_the_oracle(gpu_device):
         lo.append(l.item())
     assert lg[-1] < 0.8 * lg[0]
     assert max(abs(a - b) / b for a, b in zip(lg, lo)) < 5e-3
+
+
+# ------------------------------------------------------------------ randomized shape sweeps (fixed seeds)
+def test_random_shape_sweep_of_backward_kernels(gpu_device):
+    """40 random (n, m, k) shapes incl. degenerate ones through Linear / LayerNorm backward against fp64 torch."""
+    from nbd import autograd as ag
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        n = int(rng.choice([1, 2, 3, 31, 63, 64, 65, 127, 129, 500, 1023, 2049, 6000]))
+        m = int(rng.integers(1, 200))
+        k = int(rng.integers(1, 200))
+        g = torch.Generator().manual_seed(trial)
+        x, w, b = torch.randn(n, k, generator=g), torch.randn(m, k, generator=g) / k ** 0.5, torch.randn(m, generator=g)
+        dy = torch.randn(n, m, generator=g)
+        act = "tanh" if trial % 2 else None
+        xr, wr, br = (t.clone().double().requires_grad_() for t in (x, w, b))
+        pre = xr @ wr.T + br
+        (torch.tanh(pre) if act else pre).backward(dy.double())
+        xg, wg, bg = (t.clone().cuda().requires_grad_() for t in (x, w, b))
+        ag.linear(xg, wg, bg, act=act).backward(dy.cuda())
+        for got, ref, what in ((xg.grad, xr.grad, "dx"), (wg.grad, wr.grad, "dw"), (bg.grad, br.grad, "db")):
+            err = float((got.cpu().double() - ref).norm())
+            assert err <= 2 * TOL * max(float(ref.norm()), 1e-6), (trial, n, m, k, act, what)
+        c = m
+        gam, bet = torch.randn(c, generator=g), torch.randn(c, generator=g)
+        z = torch.randn(n, c, generator=g) * 2 + 0.3
+        zr, gr, btr = (t.clone().double().requires_grad_() for t in (z, gam, bet))
+        torch.nn.functional.layer_norm(zr, (c,), gr, btr, 1e-5).backward(dy.double())
+        zg, gg, bg2 = (t.clone().cuda().requires_grad_() for t in (z, gam, bet))
+        ag.LayerNormFn.apply(zg, gg, bg2, 1e-5).backward(dy.cuda())
+        if c > 1:               # c = 1: LayerNorm output is constant, gradients are exactly 0 +- noise
+            assert float((zg.grad.cpu().double() - zr.grad).norm()) <= 5 * TOL * max(float(zr.grad.norm()), 1e-6), (trial, n, c)
+        assert float((gg.grad.cpu().double() - gr.grad).norm()) <= 2 * TOL * max(float(gr.grad.norm()), 1e-6), (trial, n, c)
+        assert float((bg2.grad.cpu().double() - btr.grad).norm()) <= 2 * TOL * max(float(btr.grad.norm()), 1e-6), (trial, n, c)
