@@ -381,3 +381,29 @@ def test_config5_size_range_partition_on_one_gpu(gpu_device):
     inv[np.arange(64), rows] = 0.0
     ref = (d * (inv * mf[None, :])[:, :, None]).sum(1)
     assert row_rel(a64[rows], ref) < 2e-6
+
+
+def test_random_rectangular_blocks_against_oracle(gpu_device):
+    """25 random (n, target range, softening) blocks -- what a rank of an arbitrary range partition launches --
+    against the oracle's rows: ragged n, ranges that start / end anywhere, tiny softening (index-masked kernel),
+    massless and heavy bodies."""
+    from nbd import direct
+    from oracle import galaxify_oracle as go
+    rng = np.random.default_rng(99)
+    for trial in range(25):
+        n = int(rng.choice([2, 3, 63, 64, 65, 130, 500, 1000, 1537, 4099]))
+        lo = int(rng.integers(0, n))
+        cnt = int(rng.integers(1, n - lo + 1))
+        eps = float(rng.choice([0.0, 1e-13, 1e-3, 0.05, 0.1, 1.0]))
+        pos = torch.tensor(rng.normal(size=(n, 3)) * rng.choice([0.1, 1.0, 30.0]), dtype=torch.float32)
+        mass = torch.tensor(rng.random(n) * rng.choice([1e-6, 1.0, 1e3]), dtype=torch.float32)
+        mass[rng.integers(0, n)] = 0.0
+        g = float(rng.choice([1.0, 4.5e-6]))
+        ref = go.accelerations(pos, mass, g, eps, tgt_slice=slice(lo, lo + cnt))
+        posm = direct.pack_posm(pos.cuda(), mass.cuda())
+        eps2 = float(torch.tensor(eps ** 2, dtype=torch.float32))
+        got = direct.accel(posm, n, posm[lo:], cnt, lo, eps2, direct.f32(g)).cpu()
+        assert got.shape == (cnt, 3) and torch.isfinite(got).all(), (trial, n, lo, cnt, eps)
+        scale = float(ref.norm(dim=1).max())
+        err = float((got - ref).norm(dim=1).max())
+        assert err <= 2e-6 * max(scale, 1e-30), (trial, n, lo, cnt, eps, err, scale)
