@@ -445,3 +445,74 @@ def test_random_shape_sweep_of_backward_kernels(gpu_device):
             assert float((zg.grad.cpu().double() - zr.grad).norm()) <= 5 * TOL * max(float(zr.grad.norm()), 1e-6), (trial, n, c)
         assert float((gg.grad.cpu().double() - gr.grad).norm()) <= 2 * TOL * max(float(gr.grad.norm()), 1e-6), (trial, n, c)
         assert float((bg2.grad.cpu().double() - btr.grad).norm()) <= 2 * TOL * max(float(btr.grad.norm()), 1e-6), (trial, n, c)
+
+
+def test_random_model_config_sweep(gpu_device):
+    """16 random GNN and 10 random ContinuousConv configurations (odd widths, 1..3 layers, all aggregations, with
+    and without encoder / MLP head): forward (inference kernels, fused where the shape allows) and parameter
+    gradients (autograd kernels) against the oracle."""
+    import contconv
+    import gnn
+    from nbd.data import Data
+    from oracle import surrogate_oracle as so
+    rng = np.random.default_rng(4242)
+    n = 260
+    pos, vel, m = _plummer(n, 17)
+    x7 = torch.cat([pos, vel, m[:, None] * n], 1)
+    y = torch.randn(n, 3, generator=torch.Generator().manual_seed(9)) * 0.3
+    for trial in range(16):
+        cfg = dict(input_dim=int(rng.choice([4, 7])), gnn_dim=int(rng.choice([3, 17, 32, 64, 65, 100, 128])),
+                   message_passing_steps=int(rng.integers(1, 4)), aggr=str(rng.choice(["sum", "mean", "max"])),
+                   neighbors=int(rng.choice([1, 3, 9, 33])))
+        if rng.random() < 0.4:
+            cfg["node_encoder_dims"] = [int(rng.integers(2, 20))]
+        if rng.random() < 0.4:
+            cfg["output_hiddens"] = [int(rng.integers(2, 20))]
+        torch.manual_seed(trial)
+        ora = so.GraphModelOracle(**cfg)
+        model = gnn.GraphModel(device="cuda", **cfg)
+        model.load_state_dict(ora.state_dict(), strict=True)
+        ei = so.knn_graph(pos, cfg["neighbors"])
+        ora.eval(); model.eval()
+        with torch.no_grad():
+            ref = ora.forward_graph(x7, ei)
+        d = Data(x=x7.cuda(), edge_index=ei.cuda(), y=y.cuda()); d._regular_k = cfg["neighbors"]
+        got = model.predict_graph(d).cpu()
+        assert global_rel(got, ref) < 2 * TOL, ("gnn fwd", trial, cfg)
+        ora.train(); model.train(); ora.zero_grad(); model.zero_grad()
+        lo, _ = _oracle_loss(ora, x7, ei, y, 1)
+        lo.backward()
+        lg, _ = model.compute_loss(d)
+        lg.backward()
+        refp = dict(ora.named_parameters())
+        for name, p in model.named_parameters():
+            r = refp[name].grad
+            assert float((p.grad.cpu() - r).norm()) <= 3 * TOL * max(float(r.norm()), 1e-2 * lo.item()), ("gnn grad", trial, cfg, name)
+    for trial in range(10):
+        layers = int(rng.integers(1, 3))
+        cfg = dict(in_channels=int(rng.choice([4, 7])), out_channels=3,
+                   filter_resolution=[int(rng.choice([2, 3, 4, 5])) for _ in range(layers)],
+                   radius=float(rng.choice([0.6, 1.0, 1.7])), agg=str(rng.choice(["mean", "sum"])),
+                   self_loops=bool(rng.integers(0, 2)), continuous_conv_layers=layers,
+                   continuous_conv_dim=int(rng.choice([5, 16, 33, 64])))
+        if rng.random() < 0.5:
+            cfg["encoder_hiddens"] = [int(rng.integers(3, 12))]
+        if rng.random() < 0.5:
+            cfg["decoder_hiddens"] = [int(rng.integers(3, 12))]
+        torch.manual_seed(100 + trial)
+        ora = so.ContinuousConvModelOracle(**cfg)
+        model = contconv.ContinuousConvModel(device="cuda", **cfg)
+        model.load_state_dict(ora.state_dict(), strict=True)
+        ora.eval(); model.eval()
+        ref = ora.predict(pos, x7[:, 3:])
+        got = model.predict(pos.cuda(), x7[:, 3:].cuda()).cpu()
+        assert global_rel(got, ref) < 2 * TOL, ("cc fwd", trial, cfg)
+        ora.train(); model.train(); ora.zero_grad(); model.zero_grad()
+        lo = torch.sqrt(torch.nn.functional.mse_loss(ora.forward_x(x7), y))
+        lo.backward()
+        lg, _ = model.compute_loss(Data(x=x7.cuda(), batch=None, y=y.cuda()))
+        lg.backward()
+        refp = dict(ora.named_parameters())
+        for name, p in model.named_parameters():
+            r = refp[name].grad
+            assert float((p.grad.cpu() - r).norm()) <= 3 * TOL * max(float(r.norm()), 1e-2 * lo.item()), ("cc grad", trial, cfg, name)
