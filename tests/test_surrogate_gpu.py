@@ -627,3 +627,24 @@ def test_random_batched_graph_sweep(gpu_device):
         assert torch.equal(graphops.knn_graph(pos.cuda(), k, batch=bc).cpu(), so.knn_graph(pos, k, batch=b)), ("knn", trial)
         assert torch.equal(graphops.radius_graph(pos.cuda(), r, batch=bc, loop=loop, max_num_neighbors=cap).cpu(),
                            so.radius_graph(pos, r, batch=b, loop=loop, max_num_neighbors=cap)), ("radius", trial, sizes, r, cap)
+
+
+@pytest.mark.parametrize("n", [2, 5, 51, 130])
+def test_captured_gnn_step_equals_eager_for_small_systems(n, gpu_device):
+    """The captured (in place, hinted kNN, packed input) step against Trainer.step for systems around the k = 50
+    boundary: fewer bodies than neighbours asked for, exactly k + 1, a little more."""
+    import gnn
+    import trainer
+    torch.manual_seed(n)
+    model = gnn.GraphModel(input_dim=4, gnn_dim=32, message_passing_steps=2, aggr="mean", neighbors=10, device="cuda")
+    tr = trainer.Trainer(model, None, device="cuda", dt=0.01)
+    pos, vel, m = _plummer_pos(n, 40 + n)
+    pos, vel, m1 = pos.cuda(), vel.cuda(), (m * n)[:, None].cuda()
+    acc = model.predict(pos, torch.cat([vel, m1], 1))
+    adv = tr._capture_step(pos, vel, m1, acc, 0.01)
+    assert adv is not None
+    p, v, a = pos, vel, acc
+    for i in range(5):
+        p, v, a = tr.step(p, v, m1, a, 0.01)
+        gp, gv, ga = adv()
+        assert torch.equal(gp, p) and torch.equal(gv, v) and torch.equal(ga, a), (n, i)
