@@ -18,6 +18,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this stack needs dmabuf IPC; must be in the environment before the HIP runtime
+# comes up (i.e. before torch touches the device), so it is set at import time
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (os.path.join(ROOT, "nbody-deep-sim_amd"), ROOT):
     if _p not in sys.path:
@@ -28,28 +32,68 @@ PEAK_FP32_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 vector peak (= fp32 
 PARTICLES_PER_GPU = 65536
 
 
-def cpu_baseline(n, seed, budget_s, threads):
-    """The reference's torch-CPU algorithm (row-blocked port, oracle/galaxify_oracle.py) timed on
-    this host on a bounded sample: the force on the first R target rows against all n sources."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(n, seed, budget_s):
+    """The reference's torch-CPU algorithm (row-blocked port, oracle/galaxify_oracle.py) timed on this
+    host, SURVEY 8(d): whole leapfrog steps at N = 1 024 (configs[0]) and N = 16 384, and a bounded
+    sample of the N = 65 536 force (the first R target rows against all n sources). The headline
+    `value` is the N = 65 536 sample at the thread count that measured fastest."""
     import torch
     from nbd.plummer import generate_plummer
     from oracle import galaxify_oracle as go
-    torch.set_num_threads(threads)
+    affinity = len(os.sched_getaffinity(0))
+    out = {"unit": "pair-interactions/s", "kind": "port", "cores_total": os.cpu_count(),
+           "cores_affinity": affinity, "cpu_model": _cpu_model(), "sizes": {}}
+
     p, v, m = generate_plummer(n, seed=seed)
     pos = torch.tensor(p, dtype=torch.float32)
     mass = torch.tensor(m, dtype=torch.float32)
-    go.accelerations(pos, mass, 1.0, 0.1, block=256, tgt_slice=slice(0, 256))       # warm-up
-    t0 = time.perf_counter()
-    go.accelerations(pos, mass, 1.0, 0.1, block=512, tgt_slice=slice(0, 1024))
-    t_probe = time.perf_counter() - t0
-    rows = int(min(n, max(1024, 1024 * (budget_s / max(t_probe, 1e-6)))))
+
+    def sample_rate(threads, rows):
+        torch.set_num_threads(threads)
+        go.accelerations(pos, mass, 1.0, 0.1, block=256, tgt_slice=slice(0, 256))       # warm-up
+        t0 = time.perf_counter()
+        go.accelerations(pos, mass, 1.0, 0.1, block=512, tgt_slice=slice(0, rows))
+        return rows * n / (time.perf_counter() - t0)
+
+    # thread scan on a short probe: torch's intra-op pool does not always scale to every core of the box
+    scan = {}
+    for t in sorted({min(16, affinity), min(32, affinity), min(64, affinity), affinity}):
+        scan[t] = sample_rate(t, 2048)
+    best_t = max(scan, key=scan.get)
+    out["thread_scan_pairs_per_s"] = {str(k): v_ for k, v_ in scan.items()}
+    rows = int(min(n, max(2048, 0.5 * budget_s * scan[best_t] / n)))
     rows = max(512, (rows // 512) * 512)
     t0 = time.perf_counter()
-    go.accelerations(pos, mass, 1.0, 0.1, block=512, tgt_slice=slice(0, rows))
+    rate = sample_rate(best_t, rows)
     dt = time.perf_counter() - t0
-    return {"value": rows * n / dt, "unit": "pair-interactions/s", "cores": threads, "kind": "port",
-            "sample": f"force on the first {rows} of {n} targets x all {n} sources (Plummer, fp32), "
-                      f"row-blocked torch-CPU port of simulation.py:80-88, {dt:.1f} s"}
+    out.update({"value": rate, "cores": best_t,
+                "sample": f"force on the first {rows} of {n} targets x all {n} sources (Plummer, fp32), "
+                          f"row-blocked torch-CPU port of simulation.py:80-88, {best_t} threads, {dt:.1f} s"})
+
+    # whole leapfrog steps at the smaller SURVEY 8(d) sizes (OracleSimulator = simulation.py:153-170)
+    torch.set_num_threads(best_t)
+    for n_s, steps in ((1024, 50), (16384, 3)):
+        ps, vs, ms = generate_plummer(n_s, seed=seed)
+        ora = go.OracleSimulator(positions=ps, velocities=vs, masses=ms)
+        ora.leapfrog_step()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ora.leapfrog_step()
+        dt = time.perf_counter() - t0
+        out["sizes"][str(n_s)] = {"pairs_per_s": float(n_s) * n_s * steps / dt, "ms_per_step": dt / steps * 1e3,
+                                  "steps": steps, "threads": best_t}
+    out["sizes"][str(n)] = {"pairs_per_s": rate, "threads": best_t, "sample_rows": rows}
+    return out
 
 
 def main():
@@ -59,7 +103,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles-per-gpu", type=int, default=PARTICLES_PER_GPU)
     ap.add_argument("--n-total", type=int, default=0, help="fix the TOTAL particle count (strong scaling)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU baseline budget; 0 disables")
+    ap.add_argument("--prewarm-seconds", type=float, default=0.5,
+                    help="untimed steps run for this long before --warmup (clock ramp); 0 disables")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-surrogates", action="store_true", help="skip the secondary GNN / ContConv rollout timings")
     args = ap.parse_args()
@@ -84,7 +130,6 @@ def main():
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("NBD_DIST_BACKEND", "nccl")                           # nccl = RCCL over xGMI
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -103,6 +148,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # steady state: the chip's clocks ramp over the first ~0.2 s of load (the first launches run 15-30 %
+    # slow), so pre-warm by TIME before the caller's --warmup steps; reported in the JSON line
+    def prewarm(s_, seconds):
+        t_, k_ = time.perf_counter(), 0
+        while True:
+            for _ in range(10):
+                s_.step()
+            k_ += 10
+            torch.cuda.synchronize()
+            flag = torch.tensor([time.perf_counter() - t_ >= seconds], dtype=torch.int32, device="cuda")
+            if world > 1:                      # all ranks must agree on the step count (collective inside step)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.item():
+                return k_, time.perf_counter() - t_
+    pre_steps, pre_s = prewarm(sim, args.prewarm_seconds) if args.prewarm_seconds > 0 else (0, 0.0)
     for _ in range(args.warmup):
         sim.step()
     barrier()
@@ -128,15 +188,21 @@ def main():
                                  direct.f32(0.5 * sim.dt), direct.f32(sim.dt), sim._eps2, sim._g,
                                  sim._posm, sim._ws, ev_begin=e0, ev_end=e1)
             sim.accelerations = new_acc
-        else:                                          # sharded step: events around force(+finish)
+        else:                                          # sharded step: events around BOTH force launches
             half, dt = direct.f32(0.5 * sim.dt), direct.f32(sim.dt)
+            pt = sim.part
             direct.kick_drift(sim.positions, sim.velocities, sim.accelerations, sim._mass_local, half, dt,
                               posm=sim._posm_local)
-            sim._exchange()
+            handle = sim._gather.start(sim._posm_local, sim._posm)
+            sim._gather.finish(handle, sim._posm)      # measurement leg: no overlap, the kernels alone
+            loc = sim._posm_local[:direct.padded_len(pt.n_local)]
+            acc = torch.empty_like(sim.accelerations)
             e0.record()
-            sim.accelerations = sim._force()
+            direct.shard_force_local(loc, pt.n_local, sim.n, pt.lo, sim._eps2, sim._ws)
+            direct.shard_force_remote(sim._posm, sim.n, loc, pt.n_local, pt.lo, sim._eps2, sim._g, acc,
+                                      sim.velocities, half, sim._ws)
             e1.record()
-            direct.kick(sim.velocities, sim.accelerations, half)
+            sim.accelerations = acc
         evs.append((e0, e1))
     barrier()
     k_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
@@ -150,6 +216,7 @@ def main():
         p2, v2, m2 = generate_plummer(n_s, seed=args.seed)
         sim2 = simulation.LeapFrogSimulator(positions=p2, velocities=v2, masses=m2, g_const=1.0, softening=0.1,
                                             dt=0.01, calc_energy=False, device="cuda", process_group=group)
+        prewarm(sim2, min(args.prewarm_seconds, 0.2))
         for _ in range(args.warmup):
             sim2.step()
         barrier()
@@ -163,7 +230,9 @@ def main():
         el2 = t.item()
         strong_leg = {"n_particles": n_s, "value": float(n_s) * float(n_s) * args.steps / el2,
                       "unit": "pair-interactions/s", "ms_per_step": el2 / args.steps * 1e3, "scaling": "strong",
-                      "note": "same run, the single-GPU problem size split over all ranks (one all-gather per step)"}
+                      "launch_plan": direct.shard_plan(n_s, sim2.part.lo, sim2.part.n_local),
+                      "note": "same run, the single-GPU problem size split over all ranks (one all-gather per step, "
+                              "overlapped with the own-bodies force block)"}
 
     if rank != 0:
         if world > 1:
@@ -178,11 +247,13 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1 and not strong:
         traffic = json.load(open(tpath)).get("accel_kernel_hbm_bytes_per_launch")
-    plan = direct.accel_plan(n_total, n_loc)
+    plan = direct.accel_plan(n_total, n_loc) if world == 1 else direct.shard_plan(n_total, sim.part.lo, n_loc)
     out = {
         "metric": "pair-interactions/sec, direct O(N^2) leapfrog N-body, fp32",
         "value": value, "unit": "pair-interactions/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "warmup": args.warmup, "prewarm": {"seconds": pre_s, "steps": pre_steps,
+                                           "why": "clock ramp: untimed steps run by time before --warmup"},
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"Plummer sphere, {n_total} particles, direct all-pairs leapfrog step "
@@ -201,7 +272,7 @@ def main():
             "bound": "mfma", "compute_unit": "fp32 VALU (v_pk_fma_f32 / v_rsq_f32), no MFMA instructions",
             "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-            "kernel": "accel_kernel<false>", "kernel_ms": k_ms, "flop_per_pair": FLOP_PER_PAIR,
+            "kernel": "accel_kernel<false,8>", "kernel_ms": k_ms, "flop_per_pair": FLOP_PER_PAIR,
             "pairs_per_launch": pairs_per_launch,
             "note": "compute-bound on fp32 VALU issue (no dense contraction: MFMA not applicable); peak = fp32 "
                     "vector peak = fp32 MFMA peak. 20 flop/pair accounting; the instruction stream's own ceiling "
@@ -211,8 +282,7 @@ def main():
     if strong_leg is not None:
         out["strong_scaling_n65536"] = strong_leg
     if args.cpu_seconds > 0 and world == 1:
-        threads = min(len(os.sched_getaffinity(0)), 16)
-        out["cpu_baseline"] = cpu_baseline(min(n_total, 65536), args.seed, args.cpu_seconds, threads)
+        out["cpu_baseline"] = cpu_baseline(min(n_total, 65536), args.seed, args.cpu_seconds)
     elif world > 1:
         out["cpu_baseline"] = None
     if world == 1 and not strong and not args.no_surrogates:

@@ -69,6 +69,38 @@ int nbd_accel_f32(const float* posm_src, int n_src, const float* posm_tgt, int n
                   int tgt_global_offset, float softening_sq, float g_const, float* acc_out,
                   void* workspace, size_t workspace_bytes, nbd_stream_t stream);
 
+/* Tuning hook: nbd_accel_f32 with an explicit launch geometry (slabs = source splits across workgroups,
+ * 1..64; variant 0 = eight sources in flight per wave, 5 waves/SIMD; variant 1 = four, 8 waves/SIMD) and an
+ * optional excluded source range [exclude_lo, exclude_hi) (those sources contribute nothing). The launch
+ * plan of the library was chosen with it (tools/sweep_accel_plan.py); every geometry computes the same sums
+ * in a different association, so results agree to rounding. Workspace: slabs * n_tgt * 3 floats. */
+size_t nbd_accel_tuned_workspace_bytes(int n_tgt, int slabs);
+int nbd_accel_tuned_f32(const float* posm_src, int n_src, int exclude_lo, int exclude_hi, const float* posm_tgt,
+                        int n_tgt, int tgt_global_offset, float softening_sq, float g_const, float* acc_out,
+                        void* workspace, size_t workspace_bytes, int slabs, int variant, nbd_stream_t stream);
+
+/* ---- range-sharded step: one rank of a range partition owns bodies [lo, lo + n_local) of n_total
+ * (the reference has no distributed code -- this is the same LeapFrogSimulator.step,
+ * simulation.py:153-170, with the force sum of :80-88 split by source ownership). Per step and rank:
+ *   nbd_kick_drift_f32(local state) -> posm_local
+ *   [all-gather of posm_local into posm_all: issued by the host, asynchronous]
+ *   nbd_shard_force_local_f32        own bodies as sources; runs while the gather is in flight
+ *   [wait for the gather]
+ *   nbd_shard_force_remote_f32       all other bodies as sources, then acc = G * (fixed-order sum of every
+ *                                    partial-force slab of both launches) and v += c_kick * acc fused
+ * posm_local: float4[nbd_posm_padded_len(n_local)] (padding zero); posm_all: float4[padded(n_total)] in
+ * global order. Any lo / n_local is accepted (chunks of posm_all that straddle lo or lo + n_local are
+ * walked with an element mask). vel may be NULL (no kick: compute_accelerations / Euler). Workspace as
+ * nbd_shard_workspace_bytes, the same buffer for both calls of a step. Deterministic. */
+int nbd_shard_plan(int n_total, int lo, int n_local, int* slabs_local, int* chunks_per_wave_local,
+                   int* slabs_remote, int* chunks_per_wave_remote);
+size_t nbd_shard_workspace_bytes(int n_total, int lo, int n_local);
+int nbd_shard_force_local_f32(const float* posm_local, int n_local, float softening_sq, void* workspace,
+                              size_t workspace_bytes, int n_total, int lo, nbd_stream_t stream);
+int nbd_shard_force_remote_f32(const float* posm_all, int n_total, const float* posm_local, int n_local, int lo,
+                               float softening_sq, float g_const, float* acc_out, float* vel, float c_kick,
+                               void* workspace, size_t workspace_bytes, nbd_stream_t stream);
+
 /* v += c_kick * a ; x += c_drift * v ; posm = pack(x, m)   (in place on pos, vel)
  * LeapFrogSimulator.step first half, simulation.py:164,166 with c_kick = (float)(0.5*dt),
  * c_drift = (float)dt; two roundings per update (mul then add), as torch eager does.

@@ -8,7 +8,9 @@
 //   * the kernel is VALU-issue bound (16 FMA-slot equivalents per pair, v_rsq_f32 = 4 of them),
 //     so everything is arranged to keep the four SIMDs of a CU issuing packed fp32 math:
 //     each lane owns TWO targets held as float2 register pairs, so one broadcast source feeds
-//     v_pk_add/v_pk_fma/v_pk_mul on both; 8 waves/SIMD (<=64 VGPRs) hide LDS/rsq latency;
+//     v_pk_add/v_pk_fma/v_pk_mul on both; two register shapes of the same code are built: eight
+//     sources in flight per wave (90 VGPRs, 5 waves/SIMD: best issue rate, the default) and four
+//     (<=64 VGPRs, 8 waves/SIMD: more, smaller workgroup slots for launches with few targets);
 //   * every wave is autonomous: it streams its own slice of the source array in 64-body
 //     (1 KiB) chunks HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: coalesced float4
 //     loads, no VGPR staging), double-buffered behind a counted vmcnt, and reads the chunk
@@ -42,18 +44,31 @@ constexpr float kEps2Masked = 1e-24f;
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Which sources a launch walks: the 64-source chunks of `src` minus a run of skipped physical chunks,
+// with an element-wise exclusion in the (at most two) chunks that hold a partial piece of the excluded
+// index range. The un-sharded force uses the trivial view; the range-sharded step (nbd_shard_*) walks
+// "all bodies except my own [lo, hi)" with it while its own block runs from a separate launch.
+struct SrcView {
+  int n_src;           // real entries; the padding behind them is zero-mass
+  int n_chunks;        // logical chunks walked (physical chunks minus the skipped run)
+  int cpw;             // chunks per wave
+  int skip_c0, skip_cn;  // physical chunks [skip_c0, skip_c0 + skip_cn) are not visited
+  int ex_lo, ex_hi;    // source indices [ex_lo, ex_hi) contribute nothing (checked only where needed)
+  int edge0, edge1;    // physical chunks that straddle ex_lo / ex_hi (-1: none): these take the masked path
+};
+
 // One source against the lane's two targets. 12 packed ops + 2 v_rsq_f32.
 template <bool MASKED>
 __device__ __forceinline__ void interact(const f4 p, const f2 xi, const f2 yi, const f2 zi,
                                          const f2 e2, f2& ax, f2& ay, f2& az, int j, int i0,
-                                         int i1, int n_src) {
+                                         int i1, const SrcView& sv) {
   const f2 dx = f2{p.x, p.x} - xi, dy = f2{p.y, p.y} - yi, dz = f2{p.z, p.z} - zi;  // r_j - r_i
   f2 r2 = __builtin_elementwise_fma(dx, dx, e2);
   r2 = __builtin_elementwise_fma(dy, dy, r2);
   r2 = __builtin_elementwise_fma(dz, dz, r2);
   f2 s = {__builtin_amdgcn_rsqf(r2.x), __builtin_amdgcn_rsqf(r2.y)};
-  if (MASKED) {  // exact fill_diagonal_(0): only j == i is dropped; padding is dropped too
-    const bool live = j < n_src;
+  if (MASKED) {  // exact fill_diagonal_(0): only j == i is dropped; padding and the excluded range too
+    const bool live = j < sv.n_src && (unsigned)(j - sv.ex_lo) >= (unsigned)(sv.ex_hi - sv.ex_lo);
     s.x = (live && j != i0) ? s.x : 0.0f;
     s.y = (live && j != i1) ? s.y : 0.0f;
   }
@@ -71,21 +86,21 @@ __device__ __forceinline__ void interact(const f4 p, const f2 xi, const f2 yi, c
   az = __builtin_elementwise_fma(w, dz, az);
 }
 
-// kU sources at once for the un-masked kernel: same arithmetic as interact(), with the 2*kU v_rsq_f32
+// KU sources at once for the un-masked path: same arithmetic as interact(), with the 2*KU v_rsq_f32
 // issued back to back (__builtin_amdgcn_sched_group_barrier on the TRANS class). Switching between the
 // quarter-rate transcendental unit and the packed-math stream costs issue cycles on gfx950 (3 fma : 1
 // rsq mixes run ~10 % under the sum of their parts, tools/ubench_valu.hip), so the switches are
 // batched; the rsq stays a compiler builtin so that hipcc fills the transcendental -> VALU wait state
 // with independent work instead of the s_nop it must put behind an opaque asm block. Measured
-// (tools/k1_variants.hip, N = 65 536): kU = 8 at 90 VGPRs / 5 waves per SIMD beats kU = 4 at 58 VGPRs /
+// (tools/k1_variants.hip, N = 65 536): KU = 8 at 90 VGPRs / 5 waves per SIMD beats KU = 4 at 58 VGPRs /
 // 8 waves (1.004 vs 1.010 ms) and an inline-asm rsq block (1.021 ms).
-constexpr int kU = 8;
+template <int KU>
 __device__ __forceinline__ void interact_block(const f4* __restrict__ buf, const f2 xi, const f2 yi, const f2 zi,
                                                const f2 e2, f2& ax, f2& ay, f2& az) {
-  f4 p[kU];
-  f2 dx[kU], dy[kU], dz[kU], s[kU];
+  f4 p[KU];
+  f2 dx[KU], dy[KU], dz[KU], s[KU];
 #pragma unroll
-  for (int u = 0; u < kU; ++u) {
+  for (int u = 0; u < KU; ++u) {
     p[u] = buf[u];
     dx[u] = f2{p[u].x, p[u].x} - xi; dy[u] = f2{p[u].y, p[u].y} - yi; dz[u] = f2{p[u].z, p[u].z} - zi;
     f2 r2 = __builtin_elementwise_fma(dx[u], dx[u], e2);
@@ -93,10 +108,10 @@ __device__ __forceinline__ void interact_block(const f4* __restrict__ buf, const
     s[u] = __builtin_elementwise_fma(dz[u], dz[u], r2);
   }
 #pragma unroll
-  for (int u = 0; u < kU; ++u) s[u] = f2{__builtin_amdgcn_rsqf(s[u].x), __builtin_amdgcn_rsqf(s[u].y)};
-  __builtin_amdgcn_sched_group_barrier(0x400, 2 * kU, 0);      // 0x400 = TRANS: keep the rsq's together
+  for (int u = 0; u < KU; ++u) s[u] = f2{__builtin_amdgcn_rsqf(s[u].x), __builtin_amdgcn_rsqf(s[u].y)};
+  __builtin_amdgcn_sched_group_barrier(0x400, 2 * KU, 0);      // 0x400 = TRANS: keep the rsq's together
 #pragma unroll
-  for (int u = 0; u < kU; ++u) {
+  for (int u = 0; u < KU; ++u) {
     const f2 zm = {p[u].z, p[u].w};
     const f2 s3 = (s[u] * s[u]) * s[u];          // compiler-visible consumers of the rsq results (hazard-padded)
     f2 w;
@@ -108,10 +123,11 @@ __device__ __forceinline__ void interact_block(const f4* __restrict__ buf, const
 }
 
 // grid = (target groups of 128, slabs); block = 256.
-// Wave (blockIdx.y, w) handles source chunks [jw*cpw, (jw+1)*cpw) with jw = blockIdx.y*4 + w.
-template <bool MASKED>
-__global__ __launch_bounds__(64 * kWaves) void accel_kernel(
-    const f4* __restrict__ src, int n_src, int n_chunks, int cpw, const f4* __restrict__ tgt,
+// Wave (blockIdx.y, w) handles logical source chunks [jw*cpw, (jw+1)*cpw) with jw = blockIdx.y*4 + w.
+// KU = 8: 90 VGPRs, 5 waves/SIMD. KU = 4: capped at 64 VGPRs, 8 waves/SIMD.
+template <bool MASKED, int KU>
+__global__ __launch_bounds__(64 * kWaves, KU == 4 ? 8 : 5) void accel_kernel(
+    const f4* __restrict__ src, const SrcView sv, const f4* __restrict__ tgt,
     int n_tgt, int tgt_off, float eps2, float scale, float* __restrict__ out) {
   // [wave][buffer][64] staging + [wave][6][64] partials, ONE object (keeps hipcc's waits sane)
   __shared__ f4 lds[kWaves * 2 * kChunk + kWaves * 6 * 64 / 4];
@@ -126,29 +142,32 @@ __global__ __launch_bounds__(64 * kWaves) void accel_kernel(
   asm volatile("" : "+v"(e2));  // keep eps^2 in VGPRs: an SGPR operand halves v_pk_fma issue
 
   const int jw = blockIdx.y * kWaves + wave;
-  const int c_begin = min(jw * cpw, n_chunks), c_end = min(c_begin + cpw, n_chunks);
+  const int c_begin = min(jw * sv.cpw, sv.n_chunks), c_end = min(c_begin + sv.cpw, sv.n_chunks);
   f4* stage = &lds[wave * 2 * kChunk];
   const f4* s_lane = src + lane;
+  // logical -> physical chunk: hop over the skipped run
+  auto phys = [&](int c) { return c + (c >= sv.skip_c0 ? sv.skip_cn : 0); };
   if (c_begin < c_end)
-    __builtin_amdgcn_global_load_lds(GPTR(s_lane + (size_t)c_begin * kChunk), LPTR(stage), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GPTR(s_lane + (size_t)phys(c_begin) * kChunk), LPTR(stage), 16, 0, 0);
   for (int c = c_begin; c < c_end; ++c) {
     const int b = (c - c_begin) & 1;
     if (c + 1 < c_end) {
-      __builtin_amdgcn_global_load_lds(GPTR(s_lane + (size_t)(c + 1) * kChunk),
+      __builtin_amdgcn_global_load_lds(GPTR(s_lane + (size_t)phys(c + 1) * kChunk),
                                        LPTR(stage + (b ^ 1) * kChunk), 16, 0, 0);
       asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // chunk c has landed, c+1 in flight
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     const f4* buf = stage + b * kChunk;
-    const int j0 = c * kChunk;
-    if (MASKED) {
+    const int pc = phys(c);
+    const int j0 = pc * kChunk;
+    if (MASKED || pc == sv.edge0 || pc == sv.edge1) {
 #pragma unroll 4
       for (int j = 0; j < kChunk; ++j)
-        interact<true>(buf[j], xi, yi, zi, e2, ax, ay, az, j0 + j, tgt_off + i0, tgt_off + i1, n_src);
+        interact<true>(buf[j], xi, yi, zi, e2, ax, ay, az, j0 + j, tgt_off + i0, tgt_off + i1, sv);
     } else {
 #pragma unroll 1
-      for (int j = 0; j < kChunk; j += kU) interact_block(buf + j, xi, yi, zi, e2, ax, ay, az);
+      for (int j = 0; j < kChunk; j += KU) interact_block<KU>(buf + j, xi, yi, zi, e2, ax, ay, az);
     }
   }
 
@@ -345,43 +364,85 @@ inline int energy_slabs(int groups) {
   return s < 1 ? 1 : (s > 32 ? 32 : s);
 }
 
-struct AccelPlan { int groups, slabs, n_chunks, cpw; };
+struct AccelPlan { int groups, slabs, n_chunks, cpw, variant; };
 
-AccelPlan plan_accel(int n_src, int n_tgt) {
+// Launch geometry for `n_chunks` logical source chunks against n_tgt targets.
+//
+// A workgroup is 4 waves (one per SIMD of its CU) on 128 targets; variant 0 (KU = 8, 90 VGPRs) keeps 5
+// workgroups per CU resident, so one residency round of the chip is 256 x 5 = 1280 workgroups. Large
+// launches: ~6 rounds of workgroups with >= 16 chunks (1024 sources) per wave -- measured 2-3 % faster
+// than exactly one round at N = 65 536, the tail balances dynamically. Launches that cannot reach two
+// rounds that way (few targets: the per-rank block of the range-sharded step) are planned as EXACTLY one
+// round instead: slabs = floor(1280 / groups), every SIMD then holds the same number of waves and the cost
+// is cpw chunk-times; among the slab counts that give the same cpw the smallest is taken (fewer slabs to
+// sum). Tuned on hardware with nbd_accel_tuned_f32 (tools/sweep_accel_plan.py, profiles/r02_plan_sweep.json).
+constexpr int kSlotsPerRound = 1280;  // 256 CUs x 5 resident workgroups (variant 0)
+AccelPlan plan_chunks(int n_chunks, int n_tgt) {
   AccelPlan p;
+  p.variant = 0;
   p.groups = ceil_div(n_tgt, kTgtPerWG);
-  p.n_chunks = ceil_div(n_src, kChunk);
-  // Source split across workgroups. Preferred: ~4 residency rounds (8192 workgroups; measured 2-3 %
-  // faster than exactly one round at N = 65 536, the tail is balanced dynamically) with >= 16 chunks
-  // (1024 sources) per wave. If that cannot even fill the chip once (few targets), go down to one
-  // chunk per wave to get as close to 2048 workgroups = 8 per CU as the problem allows.
-  const int want_fill = ceil_div(2048, p.groups), want_pref = ceil_div(8192, p.groups);
-  const int cap_pref = p.n_chunks / (16 * kWaves), cap_fill = p.n_chunks / kWaves;
-  int slabs = want_pref < cap_pref ? want_pref : cap_pref;
-  if (slabs < want_fill) slabs = want_fill < cap_fill ? want_fill : cap_fill;
+  p.n_chunks = n_chunks;
+  const int cap = n_chunks / kWaves < 1 ? 1 : (n_chunks / kWaves > kMaxSlabs ? kMaxSlabs : n_chunks / kWaves);
+  int slabs;
+  const int pref = ceil_div(8192, p.groups), cap_pref = n_chunks / (16 * kWaves);
+  if ((pref < cap_pref ? pref : cap_pref) * p.groups >= 2 * kSlotsPerRound) {
+    slabs = pref < cap_pref ? pref : cap_pref;
+  } else {
+    slabs = kSlotsPerRound / p.groups;
+    if (slabs < 1) slabs = 1;
+    if (slabs > cap) slabs = cap;
+    const int cpw = ceil_div(n_chunks, slabs * kWaves);
+    while (slabs > 1 && ceil_div(n_chunks, (slabs - 1) * kWaves) == cpw) --slabs;
+  }
   if (slabs > kMaxSlabs) slabs = kMaxSlabs;
   if (slabs < 1) slabs = 1;
   p.slabs = slabs;
-  p.cpw = ceil_div(p.n_chunks, p.slabs * kWaves);
+  p.cpw = ceil_div(n_chunks, p.slabs * kWaves);
   return p;
 }
+
+AccelPlan plan_accel(int n_src, int n_tgt) { return plan_chunks(ceil_div(n_src, kChunk), n_tgt); }
 
 inline int check(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 inline int launch_status() { return check(hipGetLastError()); }
 
+// all sources of an n_src array
+SrcView full_view(int n_src, const AccelPlan& p) {
+  SrcView v;
+  v.n_src = n_src; v.n_chunks = p.n_chunks; v.cpw = p.cpw;
+  v.skip_c0 = p.n_chunks; v.skip_cn = 0; v.ex_lo = 0; v.ex_hi = 0; v.edge0 = -1; v.edge1 = -1;
+  return v;
+}
+
+// logical chunk count of "n_src sources without the indices [ex_lo, ex_hi)": whole chunks inside the
+// excluded range are hopped over, chunks that straddle one of its ends are walked with the element mask
+int excluded_view(int n_src, int ex_lo, int ex_hi, SrcView* v) {
+  const int phys = ceil_div(n_src, kChunk);
+  int c0 = ceil_div(ex_lo, kChunk), c1 = ex_hi / kChunk;      // whole chunks [c0, c1) lie inside
+  if (ex_hi >= n_src) c1 = phys;                               // the tail chunk holds padding only beyond ex_hi
+  if (c1 < c0) c1 = c0;
+  if (v) {
+    v->n_src = n_src; v->skip_c0 = c0; v->skip_cn = c1 - c0; v->ex_lo = ex_lo; v->ex_hi = ex_hi;
+    v->edge0 = (ex_lo % kChunk) ? ex_lo / kChunk : -1;
+    v->edge1 = (ex_hi % kChunk && ex_hi < n_src) ? ex_hi / kChunk : -1;
+    if (ex_hi <= ex_lo) { v->skip_c0 = phys; v->skip_cn = 0; v->edge0 = v->edge1 = -1; }
+  }
+  return ex_hi <= ex_lo ? phys : phys - (c1 - c0);
+}
+
 // force into slabs (or straight into acc_out when one slab), no finishing pass
-int launch_accel(const float* posm_src, int n_src, const float* posm_tgt, int n_tgt, int off,
+int launch_accel(const float* posm_src, SrcView sv, const float* posm_tgt, int n_tgt, int off,
                  float eps2, float direct_scale, float* slabs_or_acc, const AccelPlan& p,
                  hipStream_t st) {
   dim3 grid(p.groups, p.slabs), block(64 * kWaves);
   const f4* s = reinterpret_cast<const f4*>(posm_src);
   const f4* t = reinterpret_cast<const f4*>(posm_tgt);
-  if (eps2 < kEps2Masked)
-    accel_kernel<true><<<grid, block, 0, st>>>(s, n_src, p.n_chunks, p.cpw, t, n_tgt, off, eps2,
-                                               direct_scale, slabs_or_acc);
-  else
-    accel_kernel<false><<<grid, block, 0, st>>>(s, n_src, p.n_chunks, p.cpw, t, n_tgt, off, eps2,
-                                                direct_scale, slabs_or_acc);
+  sv.n_chunks = p.n_chunks; sv.cpw = p.cpw;
+  const bool masked = eps2 < kEps2Masked;
+#define NBD_LAUNCH(M, K) accel_kernel<M, K><<<grid, block, 0, st>>>(s, sv, t, n_tgt, off, eps2, direct_scale, slabs_or_acc)
+  if (p.variant == 1) { if (masked) NBD_LAUNCH(true, 4); else NBD_LAUNCH(false, 4); }
+  else                { if (masked) NBD_LAUNCH(true, 8); else NBD_LAUNCH(false, 8); }
+#undef NBD_LAUNCH
   return launch_status();
 }
 
@@ -447,17 +508,120 @@ int nbd_accel_f32(const float* posm_src, int n_src, const float* posm_tgt, int n
   if (!posm_src || misaligned16(posm_src)) return NBD_E_BADARG;
   const AccelPlan p = plan_accel(n_src, n_tgt);
   if (p.slabs == 1)
-    return launch_accel(posm_src, n_src, posm_tgt, n_tgt, tgt_global_offset, softening_sq, g_const,
-                        acc_out, p, st);
+    return launch_accel(posm_src, full_view(n_src, p), posm_tgt, n_tgt, tgt_global_offset, softening_sq,
+                        g_const, acc_out, p, st);
   const size_t need = (size_t)p.slabs * n_tgt * 3 * sizeof(float);
   if (!workspace || workspace_bytes < need) return NBD_E_WORKSPACE;
   float* slabs = static_cast<float*>(workspace);
-  int rc = launch_accel(posm_src, n_src, posm_tgt, n_tgt, tgt_global_offset, softening_sq, 1.0f,
-                        slabs, p, st);
+  int rc = launch_accel(posm_src, full_view(n_src, p), posm_tgt, n_tgt, tgt_global_offset, softening_sq,
+                        1.0f, slabs, p, st);
   if (rc) return rc;
   const int n3 = n_tgt * 3;
   finish_kernel<<<ceil_div(n3, 256), 256, 0, st>>>(slabs, p.slabs, (size_t)n3, g_const, acc_out,
                                                    nullptr, 0.f, n3);
+  return launch_status();
+}
+
+// ---- tuning hook: the force with an explicit launch geometry (tools/sweep_accel_plan.py, tests)
+size_t nbd_accel_tuned_workspace_bytes(int n_tgt, int slabs) {
+  if (n_tgt <= 0 || slabs <= 0) return 0;
+  return (size_t)slabs * n_tgt * 3 * sizeof(float);
+}
+
+int nbd_accel_tuned_f32(const float* posm_src, int n_src, int exclude_lo, int exclude_hi, const float* posm_tgt,
+                        int n_tgt, int tgt_global_offset, float softening_sq, float g_const, float* acc_out,
+                        void* workspace, size_t workspace_bytes, int slabs, int variant, nbd_stream_t stream) {
+  if (n_src <= 0 || n_tgt <= 0 || slabs < 1 || slabs > kMaxSlabs || variant < 0 || variant > 1) return NBD_E_BADARG;
+  if (exclude_lo < 0 || exclude_hi < exclude_lo || exclude_hi > n_src) return NBD_E_BADARG;
+  if (!acc_out || !posm_tgt || !posm_src || misaligned16(posm_tgt) || misaligned16(posm_src)) return NBD_E_BADARG;
+  if (!workspace || workspace_bytes < nbd_accel_tuned_workspace_bytes(n_tgt, slabs)) return NBD_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  SrcView sv;
+  AccelPlan p;
+  p.n_chunks = excluded_view(n_src, exclude_lo, exclude_hi, &sv);
+  p.groups = ceil_div(n_tgt, kTgtPerWG);
+  p.slabs = slabs;
+  p.variant = variant;
+  p.cpw = ceil_div(p.n_chunks > 0 ? p.n_chunks : 1, slabs * kWaves);
+  float* sl = static_cast<float*>(workspace);
+  const int n3 = n_tgt * 3;
+  if (p.n_chunks == 0) {
+    zero_f32_kernel<<<ceil_div(n3, 256), 256, 0, st>>>(acc_out, (size_t)n3);
+    return launch_status();
+  }
+  int rc = launch_accel(posm_src, sv, posm_tgt, n_tgt, tgt_global_offset, softening_sq, 1.0f, sl, p, st);
+  if (rc) return rc;
+  finish_kernel<<<ceil_div(n3, 256), 256, 0, st>>>(sl, p.slabs, (size_t)n3, g_const, acc_out, nullptr, 0.f, n3);
+  return launch_status();
+}
+
+// ---- range-sharded step (one rank of a torch.distributed group). The rank's targets are its
+// own bodies [lo, lo + n_local). The force is issued in two launches so that the all-gather of the other
+// ranks' bodies can be in flight during the first:
+//   local  : sources = the rank's own packed bodies (posm_local, just written by nbd_kick_drift_f32)
+//   remote : sources = the gathered array without [lo, lo + n_local), then the fixed-order slab sum,
+//            acc = G * sum, and the second kick fused (finish_kernel), as in nbd_leapfrog_step_f32.
+struct ShardPlan { AccelPlan local, remote; };
+
+ShardPlan plan_shard(int n_total, int lo, int n_local) {
+  ShardPlan sp;
+  sp.local = plan_chunks(ceil_div(n_local, kChunk), n_local);
+  const int rc = excluded_view(n_total, lo, lo + n_local, nullptr);
+  sp.remote = plan_chunks(rc > 0 ? rc : 1, n_local);
+  if (rc == 0) { sp.remote.slabs = 0; sp.remote.n_chunks = 0; }
+  return sp;
+}
+
+int nbd_shard_plan(int n_total, int lo, int n_local, int* slabs_local, int* cpw_local, int* slabs_remote,
+                   int* cpw_remote) {
+  if (n_total <= 0 || lo < 0 || n_local <= 0 || lo + n_local > n_total) return NBD_E_BADARG;
+  const ShardPlan sp = plan_shard(n_total, lo, n_local);
+  if (slabs_local) *slabs_local = sp.local.slabs;
+  if (cpw_local) *cpw_local = sp.local.cpw;
+  if (slabs_remote) *slabs_remote = sp.remote.slabs;
+  if (cpw_remote) *cpw_remote = sp.remote.cpw;
+  return 0;
+}
+
+size_t nbd_shard_workspace_bytes(int n_total, int lo, int n_local) {
+  if (n_total <= 0 || lo < 0 || n_local <= 0 || lo + n_local > n_total) return 0;
+  const ShardPlan sp = plan_shard(n_total, lo, n_local);
+  return (size_t)(sp.local.slabs + sp.remote.slabs) * n_local * 3 * sizeof(float);
+}
+
+int nbd_shard_force_local_f32(const float* posm_local, int n_local, float softening_sq, void* workspace,
+                              size_t workspace_bytes, int n_total, int lo, nbd_stream_t stream) {
+  if (n_local < 0 || n_total < 0 || lo < 0 || lo + n_local > n_total) return NBD_E_BADARG;
+  if (n_local == 0) return 0;
+  if (!posm_local || misaligned16(posm_local)) return NBD_E_BADARG;
+  if (!workspace || workspace_bytes < nbd_shard_workspace_bytes(n_total, lo, n_local)) return NBD_E_WORKSPACE;
+  const ShardPlan sp = plan_shard(n_total, lo, n_local);
+  // targets and sources are the same array: the diagonal is at j == i (offset 0)
+  return launch_accel(posm_local, full_view(n_local, sp.local), posm_local, n_local, 0, softening_sq, 1.0f,
+                      static_cast<float*>(workspace), sp.local, (hipStream_t)stream);
+}
+
+int nbd_shard_force_remote_f32(const float* posm_all, int n_total, const float* posm_local, int n_local, int lo,
+                               float softening_sq, float g_const, float* acc_out, float* vel, float c_kick,
+                               void* workspace, size_t workspace_bytes, nbd_stream_t stream) {
+  if (n_local < 0 || n_total < 0 || lo < 0 || lo + n_local > n_total) return NBD_E_BADARG;
+  if (n_local == 0) return 0;
+  if (!posm_all || !posm_local || !acc_out || misaligned16(posm_all) || misaligned16(posm_local)) return NBD_E_BADARG;
+  if (!workspace || workspace_bytes < nbd_shard_workspace_bytes(n_total, lo, n_local)) return NBD_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const ShardPlan sp = plan_shard(n_total, lo, n_local);
+  float* slabs = static_cast<float*>(workspace);
+  const int n3 = 3 * n_local;
+  if (sp.remote.slabs > 0) {
+    SrcView sv;
+    excluded_view(n_total, lo, lo + n_local, &sv);
+    // the diagonal never occurs here (every j in [lo, lo + n_local) is excluded); lo keeps the index meaning
+    int rc = launch_accel(posm_all, sv, posm_local, n_local, lo, softening_sq, 1.0f,
+                          slabs + (size_t)sp.local.slabs * n3, sp.remote, st);
+    if (rc) return rc;
+  }
+  finish_kernel<<<ceil_div(n3, 256), 256, 0, st>>>(slabs, sp.local.slabs + sp.remote.slabs, (size_t)n3, g_const,
+                                                   acc_out, vel, c_kick, n3);
   return launch_status();
 }
 
@@ -500,7 +664,7 @@ int nbd_leapfrog_step_ev_f32(float* pos, float* vel, const float* acc_in, float*
   if (rc) return rc;
   float* slabs = static_cast<float*>(workspace);
   if (ev_force_begin && (rc = check(hipEventRecord((hipEvent_t)ev_force_begin, st)))) return rc;
-  rc = launch_accel(posm, n, posm, n, 0, softening_sq, 1.0f, slabs, p, st);
+  rc = launch_accel(posm, full_view(n, p), posm, n, 0, softening_sq, 1.0f, slabs, p, st);
   if (rc) return rc;
   if (ev_force_end && (rc = check(hipEventRecord((hipEvent_t)ev_force_end, st)))) return rc;
   const int n3 = 3 * n;
@@ -530,7 +694,7 @@ int nbd_euler_step_f32(float* pos, float* vel, float* acc_out, const float* mass
   int rc = nbd_pack_posm_f32(pos, mass, n, posm, stream);
   if (rc) return rc;
   float* slabs = static_cast<float*>(workspace);
-  rc = launch_accel(posm, n, posm, n, 0, softening_sq, 1.0f, slabs, p, st);
+  rc = launch_accel(posm, full_view(n, p), posm, n, 0, softening_sq, 1.0f, slabs, p, st);
   if (rc) return rc;
   const int n3 = 3 * n;
   finish_kernel<<<ceil_div(n3, 256), 256, 0, st>>>(slabs, p.slabs, (size_t)n3, g_const, acc_out, vel, dt, n3);

@@ -91,11 +91,18 @@ class BaseSimulator:
         # scratch owned by the simulator: packed sources (all ranks' bodies), slabs, energy partials
         self._posm = direct.alloc_posm(self.n, self.device)
         self._posm.zero_()
-        self._ws = direct.step_workspace(max(self.n, 1), self.device) if world == 1 else \
-            direct.accel_workspace(self.n, self.part.n_local, self.device)
-        self._gather_scratch = None
-        self._posm_local = direct.alloc_posm(self.part.n_local, self.device) if world > 1 else None
-        self._mass_local = self.masses[lo:hi].contiguous() if world > 1 else self.masses
+        if world == 1:
+            self._ws = direct.step_workspace(max(self.n, 1), self.device)
+            self._posm_local, self._mass_local, self._gather = self._posm, self.masses, None
+        else:
+            # the rank's own packed bodies: source of its local force block and send buffer of the gather
+            # (max_count rows so that ragged shards send equal, zero-padded pieces)
+            self._posm_local = direct.alloc_posm(self.part.max_count, self.device)
+            self._posm_local.zero_()
+            self._mass_local = self.masses[lo:hi].contiguous()
+            self._ws = direct.shard_workspace(self.n, lo, self.part.n_local, self.device) \
+                if self.part.n_local else None
+            self._gather = nbd_dist.RowGather(self.part, 4, torch.float32, self.device, process_group)
 
         self.accelerations = self.compute_accelerations()
 
@@ -105,25 +112,40 @@ class BaseSimulator:
         if self.part.world_size == 1:
             direct.pack_posm(self.positions, self.masses, out=self._posm)
         else:
-            direct.pack_posm(self.positions, self._mass_local, out=self._posm_local)
-            self._exchange()
+            self._pack_local()
+            self._gather.finish(self._gather.start(self._posm_local, self._posm), self._posm)
 
-    def _exchange(self):
-        nbd_dist.allgather_rows(self._posm_local[:self.part.n_local], self.part, self._posm,
-                                group=self.process_group, scratch=self._gather_scratch)
+    def _pack_local(self):
+        n_loc = self.part.n_local
+        if n_loc:
+            direct.pack_posm(self.positions, self._mass_local, out=self._posm_local[:direct.padded_len(n_loc)])
 
-    def _force(self) -> torch.Tensor:
+    def _force_sharded(self, vel=None, c_kick: float = 0.0) -> torch.Tensor:
+        """Force on the rank's bodies from `_posm_local` (already packed): start the all-gather, run the
+        local x local block while it is in flight, then the remote block + slab sum (+ fused kick)."""
         p = self.part
-        return direct.accel(self._posm, self.n, self._posm[p.lo:], p.n_local, p.lo, self._eps2, self._g,
-                            workspace=self._ws)
+        handle = self._gather.start(self._posm_local, self._posm)
+        acc = torch.empty((p.n_local, 3), dtype=torch.float32, device=self.device)
+        if p.n_local:
+            local = self._posm_local[:direct.padded_len(p.n_local)]
+            direct.shard_force_local(local, p.n_local, self.n, p.lo, self._eps2, self._ws)
+        self._gather.finish(handle, self._posm)
+        if p.n_local:
+            direct.shard_force_remote(self._posm, self.n, local, p.n_local, p.lo, self._eps2, self._g, acc,
+                                      vel, c_kick, self._ws)
+        return acc
 
     def compute_accelerations(self) -> torch.Tensor:
         """a_i = G sum_{j!=i} m_j (r_j - r_i)/(|r_j - r_i|^2 + eps^2)^(3/2) -> new (n_local,3) tensor
         (simulation.py:71-89)."""
         if self.n == 0:
             return torch.zeros((0, 3), dtype=torch.float32, device=self.device)
-        self._refresh_sources()
-        return self._force()
+        if self.part.world_size == 1:
+            direct.pack_posm(self.positions, self.masses, out=self._posm)
+            return direct.accel(self._posm, self.n, self._posm, self.n, 0, self._eps2, self._g,
+                                workspace=self._ws)
+        self._pack_local()
+        return self._force_sharded()
 
     def compute_energies(self):
         """(U, K) as Python floats (simulation.py:91-115). Sharded: every rank evaluates the
@@ -222,12 +244,12 @@ class LeapFrogSimulator(BaseSimulator):
                                  half, dt, self._eps2, self._g, self._posm, self._ws)
             self.accelerations = new_acc
             return
-        # sharded: local kick+drift+pack -> one all-gather -> local targets x all sources -> kick
-        direct.kick_drift(self.positions, self.velocities, self.accelerations, self._mass_local, half, dt,
-                          posm=self._posm_local)
-        self._exchange()
-        self.accelerations = self._force()
-        direct.kick(self.velocities, self.accelerations, half)
+        # sharded: kick+drift+pack of the own bodies -> all-gather in flight || own x own force block ->
+        # own x remote block + slab sum + second kick. Four launches and one collective.
+        if self.part.n_local:
+            direct.kick_drift(self.positions, self.velocities, self.accelerations, self._mass_local, half, dt,
+                              posm=self._posm_local)
+        self.accelerations = self._force_sharded(self.velocities, half)
 
 
 class EulerSimulator(BaseSimulator):
@@ -242,6 +264,7 @@ class EulerSimulator(BaseSimulator):
                               self._g, self._posm, self._ws)
             self.accelerations = new_acc
             return
-        self.accelerations = self.compute_accelerations()
-        direct.kick(self.velocities, self.accelerations, dt)
-        direct.drift(self.positions, self.velocities, dt)
+        self._pack_local()
+        self.accelerations = self._force_sharded(self.velocities, dt)        # a(t), v += dt a fused
+        if self.part.n_local:
+            direct.drift(self.positions, self.velocities, dt)

@@ -33,7 +33,7 @@ def build(verbose: bool = False) -> str:
         print(res.stdout)
         print(res.stderr)
     if res.returncode != 0:
-        raise NbdError("building libnbd_hip.so failed (hipcc/make); see output above")
+        raise NbdError("building libnbd_hip.so failed (hipcc/make):\n" + (res.stderr or res.stdout)[-4000:])
     return LIB_PATH
 
 
@@ -59,6 +59,15 @@ SIGNATURES = {
     "nbd_accel_plan": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "nbd_accel_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_float, c_void_p,
                               c_void_p, c_size_t, c_void_p]),
+    "nbd_accel_tuned_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "nbd_accel_tuned_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_float,
+                                    c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "nbd_shard_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                               POINTER(c_int)]),
+    "nbd_shard_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "nbd_shard_force_local_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "nbd_shard_force_remote_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_float, c_void_p,
+                                           c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "nbd_kick_drift_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
                                    c_void_p, c_void_p]),
     "nbd_kick_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p]),
@@ -142,15 +151,16 @@ def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
+            why = ""
             try:                      # a fresh checkout has sources only: compile now if hipcc is here
                 build()
-            except Exception:
-                pass
-        if not os.path.exists(LIB_PATH):
-            raise NbdError(
-                f"{LIB_PATH} not found: the HIP extension is not built. Run "
-                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
-                "There is no CPU fallback for this path.")
+            except (NbdError, OSError) as exc:      # keep hipcc's / make's own message for the caller
+                why = f"\nThe automatic build failed: {exc}"
+            if not os.path.exists(LIB_PATH):
+                raise NbdError(
+                    f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                    "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                    "There is no CPU fallback for this path." + why)
         handle = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol

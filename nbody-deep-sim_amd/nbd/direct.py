@@ -79,6 +79,66 @@ def accel(posm_src: torch.Tensor, n_src: int, posm_tgt: torch.Tensor, n_tgt: int
     return out
 
 
+def accel_tuned(posm_src: torch.Tensor, n_src: int, posm_tgt: torch.Tensor, n_tgt: int, tgt_offset: int,
+                softening_sq: float, g_const: float, slabs: int, variant: int = 0, exclude=(0, 0),
+                out: torch.Tensor | None = None, workspace: torch.Tensor | None = None) -> torch.Tensor:
+    """`accel` with an explicit launch geometry and an optional excluded source range (tuning hook)."""
+    _chk(posm_src, (padded_len(n_src), 4), "posm_src")
+    _chk(posm_tgt, None, "posm_tgt")
+    if posm_tgt.dim() != 2 or posm_tgt.shape[1] != 4 or posm_tgt.shape[0] < n_tgt:
+        raise _lib.NbdError(f"posm_tgt: need >= {n_tgt} rows of 4, got {tuple(posm_tgt.shape)}")
+    dev = posm_tgt.device
+    if out is None:
+        out = torch.empty((n_tgt, 3), dtype=torch.float32, device=dev)
+    _chk(out, (n_tgt, 3), "acc_out")
+    need = _lib.lib().nbd_accel_tuned_workspace_bytes(n_tgt, slabs)
+    if workspace is None or _nbytes(workspace) < need:
+        workspace = alloc_bytes(need, dev)
+    with _lib.on_device(dev):
+        _lib.check(_lib.lib().nbd_accel_tuned_f32(
+            posm_src.data_ptr(), n_src, int(exclude[0]), int(exclude[1]), posm_tgt.data_ptr(), n_tgt, tgt_offset,
+            float(softening_sq), float(g_const), out.data_ptr(), workspace.data_ptr(), _nbytes(workspace),
+            int(slabs), int(variant), _lib.current_stream(dev)), "nbd_accel_tuned_f32")
+    return out
+
+
+def shard_plan(n_total: int, lo: int, n_local: int) -> dict:
+    a, b, c, d = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _lib.check(_lib.lib().nbd_shard_plan(n_total, lo, n_local, a, b, c, d), "nbd_shard_plan")
+    return {"slabs_local": a.value, "chunks_per_wave_local": b.value, "slabs_remote": c.value,
+            "chunks_per_wave_remote": d.value}
+
+
+def shard_workspace(n_total: int, lo: int, n_local: int, device) -> torch.Tensor:
+    return alloc_bytes(_lib.lib().nbd_shard_workspace_bytes(n_total, lo, n_local), device)
+
+
+def shard_force_local(posm_local: torch.Tensor, n_local: int, n_total: int, lo: int, softening_sq: float,
+                      workspace: torch.Tensor) -> None:
+    """First launch of the sharded force: own bodies as sources (runs while the all-gather is in flight)."""
+    _chk(posm_local, (padded_len(n_local), 4), "posm_local")
+    with _lib.on_device(posm_local.device):
+        _lib.check(_lib.lib().nbd_shard_force_local_f32(
+            posm_local.data_ptr(), n_local, float(softening_sq), workspace.data_ptr(), _nbytes(workspace),
+            n_total, lo, _lib.current_stream(posm_local.device)), "nbd_shard_force_local_f32")
+
+
+def shard_force_remote(posm_all: torch.Tensor, n_total: int, posm_local: torch.Tensor, n_local: int, lo: int,
+                       softening_sq: float, g_const: float, acc_out: torch.Tensor, vel: torch.Tensor | None,
+                       c_kick: float, workspace: torch.Tensor) -> None:
+    """Second launch: every other body as a source, then acc = G * sum(slabs) and v += c_kick * acc."""
+    _chk(posm_all, (padded_len(n_total), 4), "posm_all")
+    _chk(posm_local, (padded_len(n_local), 4), "posm_local")
+    _chk(acc_out, (n_local, 3), "acc_out")
+    if vel is not None:
+        _chk(vel, (n_local, 3), "vel")
+    with _lib.on_device(posm_all.device):
+        _lib.check(_lib.lib().nbd_shard_force_remote_f32(
+            posm_all.data_ptr(), n_total, posm_local.data_ptr(), n_local, lo, float(softening_sq),
+            float(g_const), acc_out.data_ptr(), _lib.ptr(vel), float(c_kick), workspace.data_ptr(),
+            _nbytes(workspace), _lib.current_stream(posm_all.device)), "nbd_shard_force_remote_f32")
+
+
 def f32(x: float) -> float:
     """The value torch uses when a Python double scalar meets an fp32 tensor."""
     return float(np.float32(x))

@@ -4,7 +4,9 @@ The reference has no distributed code at all; this layer is the build's addition
 per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 Rank p owns the contiguous particle range [lo, hi); per force evaluation every rank needs all
 packed sources {x,y,z,m}, so the only collective is ONE all-gather of float4[n/P] per step.
-Targets are independent given the sources: no reduction, no halo, no other exchange.
+Targets are independent given the sources: no reduction, no halo, no other exchange. The gather is
+asynchronous (RowGather.start/finish): the simulator runs the force of the rank's own bodies on
+each other while the other ranks' bodies are in flight.
 
 Nothing here touches a kernel, so it runs unchanged on CPU tensors under gloo.
 """
@@ -33,33 +35,57 @@ class RangePartition:
         self.max_count = max(self.counts) if self.counts else 0
 
 
-def allgather_rows(local: torch.Tensor, part: RangePartition, out: torch.Tensor,
-                   group=None, scratch: torch.Tensor | None = None) -> torch.Tensor:
-    """Gather every rank's `local` rows (n_local, C) into out[:n] in global particle order.
+class RowGather:
+    """The per-step exchange: every rank's (n_local, C) rows -> `out[:n]` in global particle order.
 
-    Equal shards: one all_gather_into_tensor straight into `out` (a single ncclAllGather).
-    Ragged shards: each rank pads to max_count, one gather into `scratch`, then the valid
-    slices are compacted into `out` -- still exactly one collective per call.
+    Exactly one collective per exchange, asynchronous: `start()` enqueues it (on RCCL's own stream behind
+    the caller's current stream) and returns at once, so kernels launched next overlap the transfer;
+    `finish()` makes the current stream wait for it. All buffers are allocated here, once.
+
+    Equal shards: one all_gather_into_tensor straight into `out`. Ragged shards (n % P != 0): every rank
+    sends `max_count` rows (its own rows + zero padding: callers keep `local` that long), one gather into
+    a scratch array, then one index_select compacts the valid rows into `out`.
     """
+
+    def __init__(self, part: RangePartition, cols: int, dtype, device, group=None):
+        self.part, self.group = part, group
+        self.send_rows = part.n_local if part.uniform else part.max_count
+        self.scratch = self.index = None
+        if part.world_size > 1 and not part.uniform:
+            m = part.max_count
+            self.scratch = torch.empty((part.world_size * m, cols), dtype=dtype, device=device)
+            self.index = torch.cat([torch.arange(r * m, r * m + c, dtype=torch.int64)
+                                    for r, c in enumerate(part.counts)]).to(device)
+
+    def start(self, local: torch.Tensor, out: torch.Tensor):
+        """`local`: at least `send_rows` contiguous rows (rows past n_local must be zero padding)."""
+        part = self.part
+        if local.shape[0] < self.send_rows:
+            raise ValueError(f"local has {local.shape[0]} rows, the exchange sends {self.send_rows}")
+        if part.world_size == 1:
+            out[:part.n].copy_(local[:part.n])
+            return None
+        dst = out[:part.n] if part.uniform else self.scratch
+        return dist.all_gather_into_tensor(dst, local[:self.send_rows], group=self.group, async_op=True)
+
+    def finish(self, handle, out: torch.Tensor) -> torch.Tensor:
+        if handle is not None:
+            handle.wait()          # device tensors: the current stream waits; host tensors (gloo): blocks
+            if self.scratch is not None:
+                torch.index_select(self.scratch, 0, self.index, out=out[:self.part.n])
+        return out
+
+
+def allgather_rows(local: torch.Tensor, part: RangePartition, out: torch.Tensor, group=None) -> torch.Tensor:
+    """Blocking form for occasional use (state gathers for output, energies): allocates per call."""
     if local.shape[0] != part.n_local:
         raise ValueError(f"local has {local.shape[0]} rows, partition says {part.n_local}")
-    cols = local.shape[1]
-    if part.world_size == 1:
-        out[:part.n].copy_(local)
-        return out
-    if part.uniform:
-        dist.all_gather_into_tensor(out[:part.n], local.contiguous(), group=group)
-        return out
-    m = part.max_count
-    if scratch is None or scratch.shape[0] < part.world_size * m:
-        scratch = torch.empty((part.world_size * m, cols), dtype=local.dtype, device=local.device)
-    padded = torch.zeros((m, cols), dtype=local.dtype, device=local.device)
-    padded[:part.n_local].copy_(local)
-    dist.all_gather_into_tensor(scratch[:part.world_size * m], padded, group=group)
-    for r in range(part.world_size):
-        c = part.counts[r]
-        out[part.offsets[r]:part.offsets[r] + c].copy_(scratch[r * m:r * m + c])
-    return out
+    g = RowGather(part, local.shape[1], local.dtype, local.device, group)
+    if g.send_rows > local.shape[0]:
+        padded = torch.zeros((g.send_rows, local.shape[1]), dtype=local.dtype, device=local.device)
+        padded[:part.n_local].copy_(local)
+        local = padded
+    return g.finish(g.start(local.contiguous(), out), out)
 
 
 def group_info(group=None) -> tuple[int, int]:

@@ -36,6 +36,7 @@ class Trainer:
         self.scheduler = scheduler
         # rollouts replay ONE captured hipGraph per step (the step is ~17 short launches: launch-bound)
         self.use_hip_graph = True
+        self.hip_graph_min_steps = 5       # shorter rollouts do not amortise the capture
 
     def train_from_dir(self, data_path, epochs, batch_size, save_every, save_path=None, create_save_path=False):
         """trainer.py:20-92. Returns (epoch_losses, epoch_mse_losses). Checkpoints are `model_{epoch}.pt`
@@ -152,10 +153,22 @@ class Trainer:
     # ------------------------------------------------------------------ trainer.py:228-344
     def evaluate_rollout(self, filename, data, scene, sim_steps, dt, df):
         data = data.to(self.device)
-        mask = data.step == 0
-        feats, accs = data.x[mask], data.y[mask]
+        # Ground truth of every step in ONE pass: the reference selects `data.x[data.step == step]` inside the loop
+        # (trainer.py:281-284) -- a boolean mask per step, i.e. a device->host count per step here. A stable sort
+        # by step gives the same rows in the same order for all steps at once; the only host read-back of the
+        # rollout is the per-step row count below (the reference indexes gt rows by prediction row, so every
+        # step must hold the n bodies of step 0).
+        step_ids = data.step.reshape(-1).to(torch.int64)
+        order = torch.argsort(step_ids, stable=True)
+        counts = torch.bincount(step_ids.clamp(min=0), minlength=sim_steps)[:sim_steps].cpu()
+        n = int(counts[0])
+        if not bool((counts == n).all()) or bool((step_ids < 0).any()):
+            raise ValueError(f"evaluate_rollout: every step 0..{sim_steps - 1} must hold the {n} bodies of step 0 "
+                             f"(rows per step: {counts.tolist()})")
+        gt = torch.cat([data.x[:, :6], data.y], dim=1)[order[:sim_steps * n]].reshape(sim_steps, n, 9)
+        first = order[:n]
+        feats = data.x[first]
         pos, vel, m = feats[:, :3].contiguous(), feats[:, 3:6].contiguous(), feats[:, 6:].contiguous()
-        n = pos.shape[0]
 
         def timed(fn):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -166,19 +179,18 @@ class Trainer:
 
         pred_accs, ev = timed(lambda: self.model.predict(pos, feats[:, 3:].contiguous()))
         events = [ev]
-        # per step: [gt_pos gt_vel gt_acc | pred_pos pred_vel pred_acc] (n, 18), kept on the device
-        blocks = [torch.cat([pos, vel, accs, pos, vel, pred_accs], dim=1)]
-        graphed = self._capture_step(pos, vel, m, pred_accs, dt) if (self.use_hip_graph and sim_steps > 4) else None
+        # per step [pred_pos pred_vel pred_acc] (n, 9), written into one preallocated device table
+        pred = torch.empty((sim_steps, n, 9), dtype=gt.dtype, device=gt.device)
+        torch.cat([pos, vel, pred_accs], dim=1, out=pred[0])
+        graphed = self._capture_step(pos, vel, m, pred_accs, dt) if (self.use_hip_graph and sim_steps >= self.hip_graph_min_steps) else None
         for step in range(1, sim_steps):
             if graphed is not None:
                 (pos, vel, pred_accs), ev = timed(lambda: graphed(clone=False))
             else:
                 (pos, vel, pred_accs), ev = timed(lambda: self.step(pos, vel, m, pred_accs, dt))
             events.append(ev)
-            gt_mask = data.step == step
-            gt_feats, gt_accs = data.x[gt_mask], data.y[gt_mask]
-            blocks.append(torch.cat([gt_feats[:, :3], gt_feats[:, 3:6], gt_accs, pos, vel, pred_accs], dim=1))
-        table = torch.stack(blocks).cpu().numpy().astype(np.float64)               # ONE device->host copy
+            torch.cat([pos, vel, pred_accs], dim=1, out=pred[step])
+        table = torch.cat([gt, pred], dim=2).cpu().numpy().astype(np.float64)      # ONE device->host copy
         times = np.array([a.elapsed_time(b) * 1e-3 for a, b in events])
         steps = np.repeat(np.arange(sim_steps), n)
         df_new = pd.DataFrame(table.reshape(sim_steps * n, 18), columns=ROLLOUT_COLUMNS[3:21])

@@ -61,11 +61,16 @@ def _segments(n: int, batch):
     return segs
 
 
-def _d2(pos: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
+def _d2(pos: torch.Tensor, lo: int, hi: int, r0: int | None = None, r1: int | None = None) -> torch.Tensor:
+    """d2[i - r0, j - lo] for centres i in [r0, r1) (default: the whole segment) and candidates j in [lo, hi)."""
     p = pos[lo:hi].to(torch.float32)
-    d = p.unsqueeze(0) - p.unsqueeze(1)            # d[i, j] = p_j - p_i
+    c = p if r0 is None else pos[r0:r1].to(torch.float32)
+    d = p.unsqueeze(0) - c.unsqueeze(1)            # d[i, j] = p_j - p_i
     dx, dy, dz = d[..., 0], d[..., 1], d[..., 2]
     return (dx * dx + dy * dy) + dz * dz           # fp32, this association
+
+
+_ROW_BLOCK = 2048      # centres per block: bounds the (rows, segment) temporaries; the arithmetic is per pair
 
 
 def knn_graph(pos: torch.Tensor, k: int, batch=None, loop: bool = False) -> torch.Tensor:
@@ -97,14 +102,17 @@ def radius_graph(pos: torch.Tensor, r: float, batch=None, loop: bool = False,
     src, dst = [], []
     for lo, hi in _segments(n, batch):
         m = hi - lo
-        ok = _d2(pos, lo, hi) < r2
-        if not loop:
-            ok = ok & ~torch.eye(m, dtype=torch.bool)
-        rank = torch.cumsum(ok.to(torch.int64), dim=1)          # 1-based rank in index order
-        ok = ok & (rank <= max_num_neighbors)
-        i_idx, j_idx = torch.nonzero(ok, as_tuple=True)         # row-major: grouped by centre, j ascending
-        src.append(j_idx + lo)
-        dst.append(i_idx + lo)
+        for b0 in range(lo, hi, _ROW_BLOCK):
+            b1 = min(b0 + _ROW_BLOCK, hi)
+            ok = _d2(pos, lo, hi, b0, b1) < r2
+            if not loop:
+                rows = torch.arange(b1 - b0)
+                ok[rows, rows + (b0 - lo)] = False
+            rank = torch.cumsum(ok.to(torch.int32), dim=1)          # 1-based rank in index order
+            ok = ok & (rank <= max_num_neighbors)
+            i_idx, j_idx = torch.nonzero(ok, as_tuple=True)         # row-major: grouped by centre, j ascending
+            src.append(j_idx + lo)
+            dst.append(i_idx + b0)
     if not src:
         return torch.zeros((2, 0), dtype=torch.int64)
     return torch.stack([torch.cat(src), torch.cat(dst)]).to(torch.int64)

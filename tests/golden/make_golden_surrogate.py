@@ -4,6 +4,8 @@ torch_cluster are not installed, so `import contconv` / `import trainer` fail at
 
   contconv.py  ContinuousConv.ball_to_cube, ContinuousConv.trilinear_interpolate   (contconv.py:30-33, 53-78)
   trainer.py   Trainer.step, Trainer.evaluate_rollout                              (trainer.py:217-344)
+  trainer.py   Trainer.test_from_dir / evaluate_stepwise: the aggregation into the two result frames,
+               pos/vel/acc_rmse = sqrt(mean_xyz(mean signed error^2)) and mean loss per scene (trainer.py:94-215)
 
 The two classes are compiled from the reference's source text as it lies under /root/reference (class
 definition only, via ast -- nothing is copied into this repository) and run on seeded inputs; the
@@ -99,6 +101,98 @@ def trainer_vectors():
     print("trainer: rollout frame", df.shape, list(df.columns)[:6], "...")
 
 
+class ToyEvalModel(ToyModel):
+    """Adds what Trainer.test_from_dir reads from a model: `.neighbors` and `.eval_graph_batch`
+    (gnn.py:193-203 returns (rmse, mse, seconds)); the time is a constant so the frame is reproducible."""
+    neighbors = 3
+
+    def eval_graph_batch(self, data):
+        pred = self.predict(data.x[:, :3], data.x[:, 3:])
+        mse = ((pred - data.y) ** 2).mean()
+        return mse.sqrt().item(), mse.item(), 0.125
+
+
+def _csv_rows(rng, scenes):
+    """fp32 dataset rows in the reference's CSV layout (s01-dataset-generation.py:108-125)."""
+    rows = []
+    for scene, (n, steps) in enumerate(scenes):
+        mass = (rng.random(n) + 0.5).astype(np.float32)
+        for step in range(steps):
+            block = rng.standard_normal((n, 9)).astype(np.float32)
+            for i in range(n):
+                rows.append([scene, step, mass[i]] + list(block[i]))
+    return np.array(rows, dtype=np.float64)
+
+
+CSV_COLS = ["scene", "step", "mass", "x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az"]
+
+
+def write_dataset_csv(path, rows):
+    """rows (R, 12) float64 holding fp32 values -> the reference's wire format (only the columns datautils reads
+    plus the ones it ignores set to constants); repr() of the double is exact for an fp32 value."""
+    with open(path, "w") as f:
+        f.write("scene,scene_type,step,step_time,mass,x,y,z,vx,vy,vz,ax,ay,az,u,k\n")
+        for r in rows:
+            vals = [str(int(r[0])), "toy", str(int(r[1])), "0.0"] + [repr(float(v)) for v in r[2:]] + ["0.0", "0.0"]
+            f.write(",".join(vals) + "\n")
+
+
+def test_from_dir_vectors():
+    """Run the reference's Trainer.test_from_dir (class compiled from its source where it lies) on two small CSV
+    files. datautils.get_dataloader needs PyG (absent): the name is bound, in the exec namespace only, to a loader
+    that follows datautils.py:23-53 without the PyG containers -- groupby (scene, step) in file order, x = [pos |
+    vel | mass], y = acc, per-node scene / step, consecutive graphs concatenated into batches (shuffle=False); the
+    toy model ignores edges, so no neighbour search is involved."""
+    import tempfile
+    import tqdm
+    from datetime import datetime
+    from glob import glob
+    from nbd.data import Data
+
+    def get_dataloader(csv_path, batch_size=32, k=8, shuffle=True):
+        assert shuffle is False
+        df = pd.read_csv(csv_path)
+        graphs = []
+        for (scene, step), group in df.groupby(["scene", "step"]):
+            pos = torch.tensor(group[["x", "y", "z"]].values, dtype=torch.float)
+            vel = torch.tensor(group[["vx", "vy", "vz"]].values, dtype=torch.float)
+            acc = torch.tensor(group[["ax", "ay", "az"]].values, dtype=torch.float)
+            mass = torch.tensor(group["mass"].values, dtype=torch.float).unsqueeze(1)
+            graphs.append(dict(x=torch.cat([pos, vel, mass], dim=1), y=acc, scene=torch.tensor([scene] * len(pos)),
+                               step=torch.tensor([step] * len(pos))))
+        return [Data(**{key: torch.cat([g[key] for g in graphs[b:b + batch_size]]) for key in graphs[0]})
+                for b in range(0, len(graphs), batch_size)]
+
+    cls = load_class(f"{REF}/trainer.py", "Trainer", {"torch": torch, "pd": pd, "time": time, "os": os, "glob": glob,
+                                                       "tqdm": tqdm, "datetime": datetime,
+                                                       "get_dataloader": get_dataloader})
+    rng = np.random.default_rng(11)
+    sim_steps = 4
+    files = {"toy_a.csv": _csv_rows(rng, [(5, sim_steps), (6, sim_steps)]), "toy_b.csv": _csv_rows(rng, [(4, sim_steps)])}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, rows in files.items():
+            write_dataset_csv(os.path.join(tmp, name), rows)
+        tr = cls(ToyEvalModel(), optimizer=None, device="cpu", dt=0.01)
+        df_step, df_roll = tr.test_from_dir(tmp, sim_steps=sim_steps)
+    df_step, df_roll = df_step.sort_index(), df_roll.sort_index()
+    out = {f"csv_{name[:-4]}": rows for name, rows in files.items()}
+    out.update(sim_steps=np.int64(sim_steps), dt=np.float64(0.01), csv_columns=np.array(CSV_COLS),
+               stepwise_index_filename=np.array([i[0] for i in df_step.index]),
+               stepwise_index_scene=np.array([i[1] for i in df_step.index], dtype=np.int64),
+               stepwise_columns=np.array(list(df_step.columns)),
+               stepwise_values=df_step.to_numpy(dtype=np.float64),
+               rollout_index_filename=np.array([i[0] for i in df_roll.index]),
+               rollout_index_scene=np.array([i[1] for i in df_roll.index], dtype=np.int64),
+               rollout_index_step=np.array([i[2] for i in df_roll.index], dtype=np.int64),
+               rollout_columns=np.array(list(df_roll.columns)),
+               rollout_values=df_roll.to_numpy(dtype=np.float64))
+    np.savez_compressed(os.path.join(HERE, "surrogate_ref_test_from_dir.npz"), **out)
+    print("test_from_dir: stepwise", df_step.shape, "rollout", df_roll.shape)
+    print(df_step)
+    print(df_roll.head(6))
+
+
 if __name__ == "__main__":
     contconv_vectors()
     trainer_vectors()
+    test_from_dir_vectors()

@@ -2,7 +2,7 @@
 
 What is exercised is the PRODUCT's distributed control flow -- nbd/dist.py (partition, the one
 all-gather per step) and the sharded branches of galaxify.simulation (local kick-drift-pack ->
-exchange -> local targets x all sources with tgt_global_offset -> kick). The HIP entry points
+asynchronous exchange || own x own force block -> own x remote block + kick). The HIP entry points
 are replaced, in this test only, by CPU stand-ins built on the pinned oracle, so that the sharded
 result can be compared with the un-sharded oracle on the same inputs."""
 import os
@@ -54,7 +54,7 @@ def _install_cpu_standins():
         vel += ck * acc
         pos += cd * vel
         if posm is not None:
-            pack_posm(pos, mass, out=posm)
+            pack_posm(pos, mass, out=posm[:padded(pos.shape[0])])
 
     def kick(vel, acc, c):
         vel += c * acc
@@ -62,9 +62,40 @@ def _install_cpu_standins():
     def drift(pos, vel, c):
         pos += c * vel
 
+    # the two launches of the sharded force (nbd_shard_force_local/remote_f32): the stand-ins evaluate the
+    # same two partial sums on the oracle -- own bodies as sources first (posm_local only: the gather may
+    # still be in flight), every other body after the gather -- and check the order the host issues them in
+    state = {"local": None}
+
+    def partial(src_pos, src_mass, tgt_pos, g, eps2, drop_diag):
+        diff = src_pos.unsqueeze(0) - tgt_pos.unsqueeze(1)
+        inv = ((diff ** 2).sum(2) + float(np.float32(eps2))).pow(-1.5)
+        if drop_diag:
+            inv.fill_diagonal_(0.0)
+        return (diff * inv.unsqueeze(2) * src_mass.unsqueeze(0).unsqueeze(2)).sum(1)
+
+    def shard_force_local(posm_local, n_local, n_total, lo, eps2, ws):
+        assert state["local"] is None, "local block issued twice without a remote block"
+        own = posm_local[:n_local]
+        state["local"] = partial(own[:, :3], own[:, 3], own[:, :3], 1.0, eps2, True)
+
+    def shard_force_remote(posm_all, n_total, posm_local, n_local, lo, eps2, g, acc_out, vel, c_kick, ws):
+        assert state["local"] is not None, "remote block issued before the local block"
+        assert torch.equal(posm_all[lo:lo + n_local], posm_local[:n_local]), "gather must have completed"
+        assert not posm_all[n_total:].any() and not posm_local[n_local:].any(), "padding must stay zero"
+        keep = torch.ones(n_total, dtype=torch.bool); keep[lo:lo + n_local] = False
+        rem = posm_all[:n_total][keep]
+        total = state["local"] + partial(rem[:, :3], rem[:, 3], posm_local[:n_local, :3], 1.0, eps2, False)
+        state["local"] = None
+        acc_out.copy_(g * total)
+        if vel is not None:
+            vel += c_kick * acc_out
+
     dummy = lambda *a, **k: torch.zeros(16, dtype=torch.uint8)
     for name, fn in dict(alloc_posm=alloc_posm, pack_posm=pack_posm, accel=accel, kick_drift=kick_drift,
-                         kick=kick, drift=drift, step_workspace=dummy, accel_workspace=dummy).items():
+                         kick=kick, drift=drift, step_workspace=dummy, accel_workspace=dummy,
+                         shard_workspace=dummy, shard_force_local=shard_force_local,
+                         shard_force_remote=shard_force_remote, padded_len=padded).items():
         setattr(direct, name, fn)
     _lib.lib = lambda: None
     simulation._resolve_device = lambda device: torch.device("cpu")
@@ -95,7 +126,8 @@ def _worker(rank, world, port, n, steps, integrator, out_dir):
 
 
 @pytest.mark.parametrize("world,n,integrator", [(2, 512, "LeapFrogSimulator"), (2, 301, "LeapFrogSimulator"),
-                                                (3, 200, "LeapFrogSimulator"), (2, 256, "EulerSimulator")])
+                                                (3, 200, "LeapFrogSimulator"), (2, 256, "EulerSimulator"),
+                                                (3, 2, "LeapFrogSimulator"), (2, 255, "EulerSimulator")])
 def test_sharded_steps_match_unsharded_oracle(world, n, integrator, tmp_path):
     from nbd.plummer import generate_plummer
     from oracle import galaxify_oracle as go

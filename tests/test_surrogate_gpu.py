@@ -514,6 +514,73 @@ def test_trainer_rollout_reproduces_reference_frame(gpu_device):
         assert df["filename"].tolist() == list(g["rollout_filename"])
 
 
+def _write_toy_csv(path, rows):
+    """The dataset CSV layout of s01-dataset-generation.py:108-125 from (R, 12) rows holding fp32 values."""
+    with open(path, "w") as f:
+        f.write("scene,scene_type,step,step_time,mass,x,y,z,vx,vy,vz,ax,ay,az,u,k\n")
+        for r in rows:
+            f.write(",".join([str(int(r[0])), "toy", str(int(r[1])), "0.0"] + [repr(float(v)) for v in r[2:]]
+                             + ["0.0", "0.0"]) + "\n")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_test_from_dir_reproduces_reference_frames(use_graph, tmp_path, gpu_device):
+    """Trainer.test_from_dir / evaluate_stepwise against the two frames the REFERENCE's Trainer class
+    returned for the same CSV files and an fp32-exact toy model (tests/golden/make_golden_surrogate.py):
+    pos/vel/acc_rmse = sqrt(mean_xyz(mean signed error^2)) per (file, scene, step) and the mean loss per
+    (file, scene) (trainer.py:177-200). Here the CSVs go through the product's datautils (kNN on the GPU) and
+    the rollout through the HIP kick/drift kernels, eager and as a captured hipGraph."""
+    import trainer
+    g = _ref_vectors("test_from_dir")
+    for key in g.files:
+        if key.startswith("csv_") and key != "csv_columns":
+            _write_toy_csv(tmp_path / f"{key[4:]}.csv", g[key])
+
+    class Toy(torch.nn.Module):
+        neighbors = 3
+
+        def predict(self, pos, feat):
+            return (feat[:, 3:4] * (-pos)) * 0.5 + feat[:, :3] * 0.25
+
+        def eval_graph_batch(self, data):
+            pred = self.predict(data.x[:, :3], data.x[:, 3:])
+            mse = ((pred - data.y) ** 2).mean()
+            return mse.sqrt().item(), mse.item(), 0.125
+    tr = trainer.Trainer(Toy(), None, device="cuda", dt=float(g["dt"]))
+    tr.use_hip_graph = use_graph
+    steps = int(g["sim_steps"])
+    tr.hip_graph_min_steps = 2         # the fixture has 4 steps: capture anyway
+    df_step, df_roll = tr.test_from_dir(str(tmp_path), sim_steps=steps)
+    df_step, df_roll = df_step.sort_index(), df_roll.sort_index()
+    assert list(df_step.columns) == list(g["stepwise_columns"]) and list(df_roll.columns) == list(g["rollout_columns"])
+    assert [i[0] for i in df_step.index] == list(g["stepwise_index_filename"])
+    assert [int(i[1]) for i in df_step.index] == list(g["stepwise_index_scene"])
+    assert [i[0] for i in df_roll.index] == list(g["rollout_index_filename"])
+    assert [int(i[1]) for i in df_roll.index] == list(g["rollout_index_scene"])
+    assert [int(i[2]) for i in df_roll.index] == list(g["rollout_index_step"])
+    # per-row values are fp32-exact on both sides; the float64 group means may associate differently
+    assert np.allclose(df_step.to_numpy(dtype=np.float64), g["stepwise_values"], rtol=1e-12, atol=0)
+    assert np.allclose(df_roll.to_numpy(dtype=np.float64), g["rollout_values"], rtol=1e-9, atol=1e-15)
+    assert (g["rollout_values"][:, 2] > 0).all() and g["rollout_values"][0, 0] == 0      # a real, non-trivial frame
+
+
+def test_evaluate_rollout_rejects_ragged_steps(gpu_device):
+    """A batch whose steps do not all hold the bodies of step 0 cannot be rolled out (the reference indexes the
+    ground truth by prediction row and fails with an IndexError there); here it is reported up front."""
+    import pandas as pd
+    import trainer
+    from nbd.data import Data
+
+    class Toy(torch.nn.Module):
+        def predict(self, pos, feat):
+            return -pos
+    tr = trainer.Trainer(Toy(), None, device="cuda", dt=0.01)
+    x = torch.randn(11, 7).cuda()
+    data = Data(x=x, y=torch.randn(11, 3).cuda(), step=torch.tensor([0] * 4 + [1] * 4 + [2] * 3).cuda())
+    with pytest.raises(ValueError):
+        tr.evaluate_rollout("f.csv", data, 0, 3, 0.01, pd.DataFrame())
+
+
 @pytest.mark.parametrize("n,k", [(500, 10), (4096, 50), (700, 70), (65, 64)])
 def test_knn_graph_result_does_not_depend_on_the_hint(n, k, gpu_device):
     """nbd_knn_graph_hint_f32: a previous graph bounds the search; a perfect, stale, duplicated or garbage hint
@@ -605,6 +672,65 @@ def test_contconv_full_size_config_rows_match_oracle_and_layer_is_linear(gpu_dev
         assert float(ref.abs().max()) > 0
         assert global_rel(o1.cpu()[rows], ref) < TOL
     assert 10 < ei.shape[1] / n <= 32                                  # capped at 32 per centre (uncapped mean ~32)
+
+
+BENCH_SCALE_16384 = 4.599349753792708      # tools/bench_surrogates.py: Plummer positions x this -> mean radius-1 degree 32
+
+
+def test_radius_graph_index_exact_at_config_size(gpu_device):
+    """configs[3]'s own size: radius_graph at N = 16 384 with the bench's position scale, every edge index
+    against the oracle's brute force (2.7e8 distance tests on the host, row-blocked)."""
+    from nbd import graphops
+    from oracle import surrogate_oracle as so
+    n = 16384
+    pos, _, _ = _plummer_pos(n, 1234)
+    pos = pos * BENCH_SCALE_16384
+    ref = so.radius_graph(pos, 1.0, loop=True, max_num_neighbors=32)
+    got = graphops.radius_graph(pos.cuda(), 1.0, loop=True, max_num_neighbors=32).cpu()
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    assert ref.shape[1] == 277746                                  # the edge count the bench reports
+    ref_nl = so.radius_graph(pos, 1.0, loop=False, max_num_neighbors=32)
+    assert torch.equal(graphops.radius_graph(pos.cuda(), 1.0, loop=False, max_num_neighbors=32).cpu(), ref_nl)
+
+
+def test_contconv_published_model_at_config_size_matches_oracle_rows(gpu_device):
+    """configs[3] end to end: the PUBLISHED ContinuousConvModel (contconv_experiment.py:62-76: encoder MLP
+    [4,32,64,128] with BatchNorm, two ContinuousConv layers 128 -> 128 with D = 6 and 4, LayerNorm, decoder
+    [64,32] -> 3) at N = 16 384. The HIP model runs the whole system from its own radius search; the oracle
+    evaluates a sample of rows exactly, on the ORACLE's edge list: layer 2 at the sampled rows needs layer 1 at
+    their neighbours, which needs the encoder output at the neighbours' neighbours (the encoder is per node)."""
+    import contconv
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(21)
+    n = 16384
+    cfg = dict(in_channels=4, out_channels=3, filter_resolution=[6, 4], radius=1.0, agg="mean", self_loops=True,
+               continuous_conv_layers=2, continuous_conv_dim=128, encoder_hiddens=[32, 64], decoder_hiddens=[64, 32])
+    ora = so.ContinuousConvModelOracle(**cfg)
+    with torch.no_grad():
+        for nrm in ora.node_encoder.norms:
+            nrm.module.running_mean.uniform_(-0.5, 0.5); nrm.module.running_var.uniform_(0.5, 2.0)
+            nrm.module.weight.uniform_(0.5, 1.5); nrm.module.bias.uniform_(-0.3, 0.3)
+    ora.eval()
+    model = contconv.ContinuousConvModel(device="cuda", **cfg)
+    _copy_state(model, ora)
+    pos, vel, m = _plummer_pos(n, 1234)
+    pos = pos * BENCH_SCALE_16384
+    feat = torch.cat([vel, m[:, None] * n], 1)
+    got = model.predict(pos.cuda(), feat.cuda()).cpu()
+
+    ei = so.radius_graph(pos, 1.0, loop=True, max_num_neighbors=32)           # the oracle's own edge list
+    rows = torch.randperm(n, generator=torch.Generator().manual_seed(5))[:40]
+    keep2 = torch.isin(ei[0], rows)                                           # aggregation at edge_index[0]
+    need1 = torch.unique(torch.cat([rows, ei[1][keep2]]))
+    keep1 = torch.isin(ei[0], need1)
+    with torch.no_grad():
+        x = torch.cat([pos, feat[:, 3:]], dim=1)
+        enc = ora.node_encoder(x)
+        h1 = torch.tanh(ora.contconv[0](pos, enc, ei[:, keep1]))              # exact on `need1`
+        h2 = torch.tanh(ora.contconv[1](pos, h1, ei[:, keep2]))               # exact on `rows`
+        ref = ora.output(ora.layer_norm(torch.cat((enc, h2), dim=-1)))[rows]
+    assert float(h2[rows].abs().mean()) > 0.05                     # tanh in its useful range (mean |h2| ~ 0.2)
+    assert global_rel(got[rows], ref) < TOL and row_rel(got[rows], ref) < 10 * TOL
 
 
 def test_random_batched_graph_sweep(gpu_device):
