@@ -30,6 +30,7 @@ extern "C" {
 #define NBD_E_UNSUPPORTED (-3)
 
 #define NBD_SRC_PAD 64      /* packed source arrays are padded to a multiple of this          */
+#define NBD_CC_TILE 128     /* nodes per tile of the fused ContinuousConv kernels             */
 
 typedef void* nbd_stream_t;
 
@@ -371,6 +372,33 @@ size_t nbd_layernorm_bwd_workspace_bytes(int n, int c);
 int nbd_layernorm_bwd_f32(const float* x, int ldx, int c, const float* gamma, float eps, const float* dy, int lddy,
                           float* dx, int lddx, float* dgamma, float* dbeta, int n, void* workspace,
                           size_t workspace_bytes, nbd_stream_t stream);
+
+/* ---- ContinuousConv.forward (contconv.py:80-98), block-sparse and fused: only the (node, filter cell) blocks
+ * some edge touches are multiplied, and the binned features never reach HBM (csrc/contconv_fused.hip).
+ * Inference path for in_channels % 4 == 0, in_channels <= 128 (nbd_contconv_fused_supported); other shapes and
+ * the training path use nbd_contconv_bin_f32 + nbd_linear_f32.
+ *
+ * nbd_contconv_pairs_f32: the per-(tile of NBD_CC_TILE nodes, cell) lists of (edge corner) pairs {source node,
+ *   window * trilinear weight}, grouped by node -- geometry of contconv.py:84-90 evaluated once per edge and
+ *   filter resolution. rowptr/centres: edges grouped by aggregation target (edge_index[0]); centres[e] =
+ *   edge_index[1]. cell_map (int32 [D^3], -1 = cell dropped) or NULL; n_cells = cells kept. edge_capacity >=
+ *   rowptr[n] sizes the lists (host-known bound, e.g. n * max_num_neighbors: no device read-back).
+ * nbd_contconv_fused_f32: out[n][:] = act(rowscale[n] * sum_cells A[n][cell] . F[cell]) with
+ *   filters_shuffled = the (cell, in, out) filters in MFMA fragment order: float index
+ *   ((((cell * ceil(O/32) + cb) * ceil(I/8) + kq) * 64 + lane) * 4 + c) holds F[cell][8 kq + 4 (lane >> 5) + c][32 cb +
+ *   (lane & 31)], zero beyond I / O (nbd_contconv_filter_floats floats in all). act: 0 none, 1 tanh.
+ *   rowscale may be NULL. Deterministic. */
+int nbd_contconv_fused_supported(int in_channels, int out_channels, int n_cells);
+size_t nbd_contconv_pairs_bytes(int n, int64_t edge_capacity, int n_cells);
+int nbd_contconv_pairs_f32(const float* pos, const int* rowptr, const int* centres, int n, int64_t edge_capacity,
+                           int filter_resolution, float radius_sq, const int* cell_map, int n_cells,
+                           void* pair_lists, size_t pair_lists_bytes, nbd_stream_t stream);
+size_t nbd_contconv_fused_workspace_bytes(int n, int n_cells, int out_channels);
+size_t nbd_contconv_filter_floats(int in_channels, int out_channels, int n_cells);
+int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const int* rowptr, int n, int64_t edge_capacity,
+                           const void* pair_lists, const float* filters_shuffled, int n_cells, int out_channels,
+                           const float* rowscale, int act, float* out, int ldo, void* workspace,
+                           size_t workspace_bytes, nbd_stream_t stream);
 
 /* scale[i] from the CSR degree d_i: mode 0 = 1/max(d,1), 1 = d, 2 = (d > 0). */
 int nbd_degree_scale_f32(const int* rowptr, int n, int mode, float* scale, nbd_stream_t stream);

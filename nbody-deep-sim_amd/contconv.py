@@ -39,8 +39,8 @@ class ContinuousConv(nn.Module):
         self.in_channels, self.out_channels = in_channels, out_channels
         self.radius, self.agg = radius, agg
         self.filter_resolution = filter_resolution
-        if agg not in ("mean", "sum", "add"):
-            raise NotImplementedError(f"agg={agg!r}: the feature-side binning needs a linear aggregation")
+        if agg not in ("mean", "sum", "add", "max", "min"):
+            raise NotImplementedError(f"agg={agg!r}: scatter reductions provided: sum/add, mean, max, min")
         self.filters = nn.Parameter(torch.randn(filter_resolution, filter_resolution, filter_resolution,
                                                 in_channels, out_channels))            # contconv.py:20-28
 
@@ -63,9 +63,20 @@ class ContinuousConv(nn.Module):
         idx, _, k = self.cells()
         return self.filters.detach().reshape(d * d * d, i, o).index_select(0, idx).reshape(k * i, o).t().contiguous()
 
-    def forward(self, positions, features, edge_index=None, lists=None, act=None, out=None, wt=None):
+    def weight_fused(self):
+        """filters in the MFMA fragment order of the fused kernel (nnops.contconv_shuffle_filters)."""
+        idx, _, _ = self.cells()
+        return nnops.contconv_shuffle_filters(self.filters, idx)
+
+    def fused_ok(self) -> bool:
+        return self.use_fused and nnops.contconv_fused_supported(self.in_channels, self.out_channels, self.cells()[2])
+
+    use_fused = True         # block-sparse fused kernels (csrc/contconv_fused.hip) where the shape allows
+
+    def forward(self, positions, features, edge_index=None, lists=None, act=None, out=None, wt=None, pairs=None):
         """contconv.py:80-98. Give either the sync-free `lists` (graphops.radius_lists) or a PyG-style
-        edge_index [2,E] (row 0 = aggregation target, row 1 = feature source)."""
+        edge_index [2,E] (row 0 = aggregation target, row 1 = feature source). `pairs`: the pair lists of
+        this graph and filter resolution when the caller already has them (layers of one model that share D)."""
         n = positions.shape[0]
         if lists is not None:
             rowptr, centres = lists.rowptr, lists.centres
@@ -78,6 +89,8 @@ class ContinuousConv(nn.Module):
             if centres.numel() == 0:
                 centres = torch.zeros(1, dtype=torch.int32, device=positions.device)
         r2 = float(np.float32(self.radius ** 2))                       # contconv.py:86: python double -> fp32
+        if self.agg in ("max", "min"):
+            return self._forward_extreme(positions, features, rowptr, centres, act, out)
         scale = nnops.degree_scale(rowptr, n, 0, positions.device) if self.agg == "mean" else None
         if torch.is_grad_enabled() and (self.filters.requires_grad or features.requires_grad):
             if lists is not None:            # the radius search's per-centre lists ARE the by-source grouping
@@ -90,7 +103,18 @@ class ContinuousConv(nn.Module):
             if out is not None:
                 raise NbdError("ContinuousConv.forward: out= is an inference-only option")
             return res
-        wt = self.weight_t() if wt is None else wt
+        if self.fused_ok() and n > 0:
+            # block-sparse path: pair lists -> fused gather + MFMA + per-node accumulation; A stays on chip
+            _, cmap, n_cells = self.cells()
+            feats = features if (features.stride(-1) == 1 and features.stride(0) % 2 == 0 and
+                                 features.data_ptr() % 8 == 0) else features.contiguous()
+            if pairs is None:
+                pairs = nnops.contconv_pairs(positions.contiguous(), rowptr, centres, centres.numel(),
+                                             self.filter_resolution, r2, cmap, n_cells)
+            wf = wt if (wt is not None and wt.dim() == 1) else self.weight_fused()
+            return nnops.contconv_fused(feats, rowptr, pairs[0], pairs[1], wf, n_cells, self.out_channels,
+                                        rowscale=scale, act=act, out=out)
+        wt = self.weight_t() if (wt is None or wt.dim() == 1) else wt
         if out is None:
             out = torch.empty((n, self.out_channels), dtype=torch.float32, device=positions.device)
         # bin + contract in node chunks: the chunk's A block (<= A_CHUNK_BYTES) is produced and consumed
@@ -107,6 +131,41 @@ class ContinuousConv(nn.Module):
             nnops.linear(a_buf[:cnt], wt, None, act=act, out=out[lo:lo + cnt],
                          rowscale=None if scale is None else scale[lo:lo + cnt])
         return out
+
+
+    def _forward_extreme(self, positions, features, rowptr, centres, act, out):
+        """agg = "max" / "min" (scatter's other reductions, contconv.py:95-97): the feature-side binning needs a
+        LINEAR aggregation, so the per-edge messages are materialised -- every edge becomes a row of its own in
+        a virtual graph (row N + e at the position of the edge's aggregation target, one edge, sum aggregation)
+        through the same kernels -- and reduced per target by nbd_segment_reduce_f32. Inference only."""
+        if torch.is_grad_enabled() and (self.filters.requires_grad or features.requires_grad):
+            raise NotImplementedError("ContinuousConv(agg='max'/'min') has no backward kernels; use torch.no_grad()")
+        n, dev = positions.shape[0], positions.device
+        e = int(centres.numel()) if rowptr is None else int(rowptr[-1])       # one read-back: this path is not the hot one
+        tgt = torch.repeat_interleave(torch.arange(n, device=dev), (rowptr[1:] - rowptr[:-1]).to(torch.int64),
+                                      output_size=e)
+        pos_v = torch.cat([positions, positions[tgt]]).contiguous()
+        feat_v = torch.cat([features, torch.zeros((e, features.shape[1]), dtype=features.dtype, device=dev)])
+        rowptr_v = torch.cat([torch.zeros(n + 1, dtype=torch.int32, device=dev),
+                              torch.arange(1, e + 1, dtype=torch.int32, device=dev)])
+        cen_v = centres[:e].contiguous() if e else torch.zeros(1, dtype=torch.int32, device=dev)
+        agg, self.agg = self.agg, "sum"
+        try:
+            msgs = self.forward(pos_v, feat_v, lists=graphops.RadiusLists(n=n + e, cap=0, nbr=None, deg=None, last=None,
+                                                                            rowptr=rowptr_v, centres=cen_v))[n:]
+        finally:
+            self.agg = agg
+        if agg == "min":
+            msgs = -msgs
+        red = nnops.segment_reduce(msgs.contiguous(), rowptr, n, "max")
+        if agg == "min":
+            red = -red
+        if act == "tanh":
+            red = torch.tanh(red)
+        if out is not None:
+            out.copy_(red)
+            return out
+        return red
 
 
 class ContinuousConvModel(nn.Module):
@@ -158,7 +217,8 @@ class ContinuousConvModel(nn.Module):
 
     def _build_weights(self):
         enc = self.node_encoder.folded() if isinstance(self.node_encoder, MLP) else None
-        return {"enc": enc, "wt": [layer.weight_t() for layer in self.contconv], "head": head_chain(self.output)}
+        return {"enc": enc, "wt": [layer.weight_fused() if layer.fused_ok() else layer.weight_t() for layer in self.contconv],
+                "head": head_chain(self.output)}
 
     def forward(self, data):                                                         # contconv.py:218-234
         needs_train_path = self.training and (isinstance(self.node_encoder, MLP) and self.node_encoder.has_norm
@@ -184,9 +244,19 @@ class ContinuousConvModel(nn.Module):
         else:
             run_chain(x, w["enc"], out_last=enc_view)
         h = enc_view
+        pair_cache = {}                              # layers with the same filter resolution share their pair lists
         for li, layer in enumerate(self.contconv):
             last = li == len(self.contconv) - 1
-            h = layer(pos, h, lists=lists, act="tanh", out=conv_view if last else None, wt=w["wt"][li])
+            pairs = None
+            if layer.fused_ok() and n > 0:
+                key = (layer.filter_resolution, float(layer.radius))
+                if key not in pair_cache:
+                    _, cmap, n_cells = layer.cells()
+                    pair_cache[key] = nnops.contconv_pairs(pos, lists.rowptr, lists.centres, lists.centres.numel(),
+                                                           layer.filter_resolution, float(np.float32(layer.radius ** 2)),
+                                                           cmap, n_cells)
+                pairs = pair_cache[key]
+            h = layer(pos, h, lists=lists, act="tanh", out=conv_view if last else None, wt=w["wt"][li], pairs=pairs)
         ln = nnops.layernorm(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
                              self.layer_norm.eps)
         return run_chain(ln, w["head"])

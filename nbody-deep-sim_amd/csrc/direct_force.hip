@@ -51,7 +51,7 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 struct SrcView {
   int n_src;           // real entries; the padding behind them is zero-mass
   int n_chunks;        // logical chunks walked (physical chunks minus the skipped run)
-  int cpw;             // chunks per wave
+  int cpw_q, cpw_r;    // balanced split: every wave walks cpw_q chunks, the first cpw_r waves one more
   int skip_c0, skip_cn;  // physical chunks [skip_c0, skip_c0 + skip_cn) are not visited
   int ex_lo, ex_hi;    // source indices [ex_lo, ex_hi) contribute nothing (checked only where needed)
   int edge0, edge1;    // physical chunks that straddle ex_lo / ex_hi (-1: none): these take the masked path
@@ -123,7 +123,8 @@ __device__ __forceinline__ void interact_block(const f4* __restrict__ buf, const
 }
 
 // grid = (target groups of 128, slabs); block = 256.
-// Wave (blockIdx.y, w) handles logical source chunks [jw*cpw, (jw+1)*cpw) with jw = blockIdx.y*4 + w.
+// Wave jw = blockIdx.y*4 + w handles the logical source chunks [jw*q + min(jw, r), ... + q (+1 if jw < r)):
+// all chunks are spread over all waves to within one chunk (no idle tail waves).
 // KU = 8: 90 VGPRs, 5 waves/SIMD. KU = 4: capped at 64 VGPRs, 8 waves/SIMD.
 template <bool MASKED, int KU>
 __global__ __launch_bounds__(64 * kWaves, KU == 4 ? 8 : 5) void accel_kernel(
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(64 * kWaves, KU == 4 ? 8 : 5) void accel_kernel(
   asm volatile("" : "+v"(e2));  // keep eps^2 in VGPRs: an SGPR operand halves v_pk_fma issue
 
   const int jw = blockIdx.y * kWaves + wave;
-  const int c_begin = min(jw * sv.cpw, sv.n_chunks), c_end = min(c_begin + sv.cpw, sv.n_chunks);
+  const int c_begin = jw * sv.cpw_q + min(jw, sv.cpw_r), c_end = c_begin + sv.cpw_q + (jw < sv.cpw_r ? 1 : 0);
   f4* stage = &lds[wave * 2 * kChunk];
   const f4* s_lane = src + lane;
   // logical -> physical chunk: hop over the skipped run
@@ -190,15 +191,24 @@ __global__ __launch_bounds__(64 * kWaves, KU == 4 ? 8 : 5) void accel_kernel(
   }
 }
 
-// acc = g * (slab_0 + slab_1 + ...), optional fused kick v += c * acc (simulation.py:88,170)
+// acc = g * (slab_0 + slab_1 + ...), optional fused kick v += c * acc (simulation.py:88,170).
+// Block = 4 waves on 64 consecutive outputs: wave w sums slabs w, w+4, w+8, ... (coalesced 256-B loads, all
+// in flight), the four partial sums are combined as (p0 + p1) + (p2 + p3) through LDS -- a fixed association,
+// so the result is bit-reproducible. One thread per output summing every slab serially took 9 us for the
+// 28 slabs x 24 576 outputs of a sharded rank (96 workgroups, one dependent chain each); this form 3 us.
 __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ slabs, int n_slabs,
                                                      size_t slab_stride, float g, float* __restrict__ acc,
                                                      float* __restrict__ vel, float c_kick, int n3) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n3) return;
-  float sum = slabs[i];
-  for (int s = 1; s < n_slabs; ++s) sum += slabs[s * slab_stride + i];
-  const float a = __fmul_rn(g, sum);
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float sum = 0.f;
+  if (i < n3)
+    for (int s = w; s < n_slabs; s += 4) sum += slabs[s * slab_stride + i];
+  part[w][lane] = sum;
+  __syncthreads();
+  if (w != 0 || i >= n3) return;
+  const float a = __fmul_rn(g, (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
   acc[i] = a;
   if (vel) vel[i] = __fadd_rn(vel[i], __fmul_rn(c_kick, a));
 }
@@ -364,35 +374,49 @@ inline int energy_slabs(int groups) {
   return s < 1 ? 1 : (s > 32 ? 32 : s);
 }
 
-struct AccelPlan { int groups, slabs, n_chunks, cpw, variant; };
+struct AccelPlan { int groups, slabs, n_chunks, cpw, variant; };   // cpw = the LARGEST chunk count of a wave
 
 // Launch geometry for `n_chunks` logical source chunks against n_tgt targets.
 //
-// A workgroup is 4 waves (one per SIMD of its CU) on 128 targets; variant 0 (KU = 8, 90 VGPRs) keeps 5
-// workgroups per CU resident, so one residency round of the chip is 256 x 5 = 1280 workgroups. Large
-// launches: ~6 rounds of workgroups with >= 16 chunks (1024 sources) per wave -- measured 2-3 % faster
-// than exactly one round at N = 65 536, the tail balances dynamically. Launches that cannot reach two
-// rounds that way (few targets: the per-rank block of the range-sharded step) are planned as EXACTLY one
-// round instead: slabs = floor(1280 / groups), every SIMD then holds the same number of waves and the cost
-// is cpw chunk-times; among the slab counts that give the same cpw the smallest is taken (fewer slabs to
-// sum). Tuned on hardware with nbd_accel_tuned_f32 (tools/sweep_accel_plan.py, profiles/r02_plan_sweep.json).
-constexpr int kSlotsPerRound = 1280;  // 256 CUs x 5 resident workgroups (variant 0)
+// A workgroup is 4 waves (one per SIMD of its CU) on 128 targets; the kernel is VALU-issue bound, so a
+// launch costs (to first order) the largest number of chunk-times any SIMD is handed:
+//     cost(slabs) = [workgroups per CU] x [chunks per wave]       (workgroups go to the CUs round-robin)
+// divided by the issue efficiency at that many waves per SIMD and plus a per-workgroup prologue/epilogue
+// term. Fitted to the hardware sweep of every slab count (nbd_accel_tuned_f32, tools/sweep_accel_plan.py,
+// profiles/r02_plan_sweep*.jsonl): e.g. 8192 targets x 57 344 sources (the remote block of one of 8 ranks):
+// 2/3/4/>=5 workgroups per CU at equal chunk totals ran at 0.935/0.975/0.99/1.0 of the best rate, a slab
+// count that leaves the work uneven across CUs (9 slabs: 576 workgroups) 30 % slower. Large launches keep
+// ~32 workgroups per CU with >= 16 chunks (1024 sources) per wave: the tail then balances dynamically.
+constexpr int kCUs = 256;
+double plan_cost(int groups, int n_chunks, int slabs) {
+  static const double eff[6] = {1.0, 0.70, 0.935, 0.975, 0.99, 1.0};
+  const int waves = slabs * kWaves, q = n_chunks / waves, r = n_chunks % waves;
+  const int wgs = groups * slabs, per_cu = ceil_div(wgs, kCUs);
+  const int heavy_per_cu = ceil_div(groups * ceil_div(r, kWaves), kCUs);   // workgroups holding a (q+1)-chunk wave
+  const double chunks = (double)per_cu * q + (heavy_per_cu < per_cu ? heavy_per_cu : per_cu);
+  // exactly one residency round (<= 5 workgroups per CU) has no slack for uneven placement: +3 % measured
+  // (128 groups x 10 slabs: 268 us, x 20 slabs: 261 us); 0.25 chunk-times of prologue/epilogue per workgroup
+  return chunks / eff[per_cu < 5 ? per_cu : 5] * (per_cu <= 5 ? 1.03 : 1.0) + 0.25 * per_cu;
+}
+
 AccelPlan plan_chunks(int n_chunks, int n_tgt) {
   AccelPlan p;
   p.variant = 0;
   p.groups = ceil_div(n_tgt, kTgtPerWG);
   p.n_chunks = n_chunks;
-  const int cap = n_chunks / kWaves < 1 ? 1 : (n_chunks / kWaves > kMaxSlabs ? kMaxSlabs : n_chunks / kWaves);
+  int cap = n_chunks / kWaves;                     // at least one chunk per wave
+  cap = cap < 1 ? 1 : (cap > kMaxSlabs ? kMaxSlabs : cap);
   int slabs;
   const int pref = ceil_div(8192, p.groups), cap_pref = n_chunks / (16 * kWaves);
-  if ((pref < cap_pref ? pref : cap_pref) * p.groups >= 2 * kSlotsPerRound) {
+  if ((pref < cap_pref ? pref : cap_pref) * p.groups >= 10 * kCUs) {
     slabs = pref < cap_pref ? pref : cap_pref;
   } else {
-    slabs = kSlotsPerRound / p.groups;
-    if (slabs < 1) slabs = 1;
-    if (slabs > cap) slabs = cap;
-    const int cpw = ceil_div(n_chunks, slabs * kWaves);
-    while (slabs > 1 && ceil_div(n_chunks, (slabs - 1) * kWaves) == cpw) --slabs;
+    slabs = 1;
+    double best = plan_cost(p.groups, n_chunks, 1);
+    for (int s = 2; s <= cap; ++s) {
+      const double c = plan_cost(p.groups, n_chunks, s);
+      if (c < best * 0.999) { best = c; slabs = s; }       // ties: fewer slabs to sum
+    }
   }
   if (slabs > kMaxSlabs) slabs = kMaxSlabs;
   if (slabs < 1) slabs = 1;
@@ -409,7 +433,7 @@ inline int launch_status() { return check(hipGetLastError()); }
 // all sources of an n_src array
 SrcView full_view(int n_src, const AccelPlan& p) {
   SrcView v;
-  v.n_src = n_src; v.n_chunks = p.n_chunks; v.cpw = p.cpw;
+  v.n_src = n_src; v.n_chunks = p.n_chunks; v.cpw_q = 0; v.cpw_r = 0;
   v.skip_c0 = p.n_chunks; v.skip_cn = 0; v.ex_lo = 0; v.ex_hi = 0; v.edge0 = -1; v.edge1 = -1;
   return v;
 }
@@ -437,7 +461,8 @@ int launch_accel(const float* posm_src, SrcView sv, const float* posm_tgt, int n
   dim3 grid(p.groups, p.slabs), block(64 * kWaves);
   const f4* s = reinterpret_cast<const f4*>(posm_src);
   const f4* t = reinterpret_cast<const f4*>(posm_tgt);
-  sv.n_chunks = p.n_chunks; sv.cpw = p.cpw;
+  sv.n_chunks = p.n_chunks;
+  sv.cpw_q = p.n_chunks / (p.slabs * kWaves); sv.cpw_r = p.n_chunks % (p.slabs * kWaves);
   const bool masked = eps2 < kEps2Masked;
 #define NBD_LAUNCH(M, K) accel_kernel<M, K><<<grid, block, 0, st>>>(s, sv, t, n_tgt, off, eps2, direct_scale, slabs_or_acc)
   if (p.variant == 1) { if (masked) NBD_LAUNCH(true, 4); else NBD_LAUNCH(false, 4); }
@@ -517,7 +542,7 @@ int nbd_accel_f32(const float* posm_src, int n_src, const float* posm_tgt, int n
                         1.0f, slabs, p, st);
   if (rc) return rc;
   const int n3 = n_tgt * 3;
-  finish_kernel<<<ceil_div(n3, 256), 256, 0, st>>>(slabs, p.slabs, (size_t)n3, g_const, acc_out,
+  finish_kernel<<<ceil_div(n3, 64), 256, 0, st>>>(slabs, p.slabs, (size_t)n3, g_const, acc_out,
                                                    nullptr, 0.f, n3);
   return launch_status();
 }
@@ -551,7 +576,7 @@ int nbd_accel_tuned_f32(const float* posm_src, int n_src, int exclude_lo, int ex
   }
   int rc = launch_accel(posm_src, sv, posm_tgt, n_tgt, tgt_global_offset, softening_sq, 1.0f, sl, p, st);
   if (rc) return rc;
-  finish_kernel<<<ceil_div(n3, 256), 256, 0, st>>>(sl, p.slabs, (size_t)n3, g_const, acc_out, nullptr, 0.f, n3);
+  finish_kernel<<<ceil_div(n3, 64), 256, 0, st>>>(sl, p.slabs, (size_t)n3, g_const, acc_out, nullptr, 0.f, n3);
   return launch_status();
 }
 
@@ -620,7 +645,7 @@ int nbd_shard_force_remote_f32(const float* posm_all, int n_total, const float* 
                           slabs + (size_t)sp.local.slabs * n3, sp.remote, st);
     if (rc) return rc;
   }
-  finish_kernel<<<ceil_div(n3, 256), 256, 0, st>>>(slabs, sp.local.slabs + sp.remote.slabs, (size_t)n3, g_const,
+  finish_kernel<<<ceil_div(n3, 64), 256, 0, st>>>(slabs, sp.local.slabs + sp.remote.slabs, (size_t)n3, g_const,
                                                    acc_out, vel, c_kick, n3);
   return launch_status();
 }
@@ -668,7 +693,7 @@ int nbd_leapfrog_step_ev_f32(float* pos, float* vel, const float* acc_in, float*
   if (rc) return rc;
   if (ev_force_end && (rc = check(hipEventRecord((hipEvent_t)ev_force_end, st)))) return rc;
   const int n3 = 3 * n;
-  finish_kernel<<<ceil_div(n3, 256), 256, 0, st>>>(slabs, p.slabs, (size_t)n3, g_const, acc_out, vel,
+  finish_kernel<<<ceil_div(n3, 64), 256, 0, st>>>(slabs, p.slabs, (size_t)n3, g_const, acc_out, vel,
                                                    dt_half, n3);
   return launch_status();
 }
@@ -697,7 +722,7 @@ int nbd_euler_step_f32(float* pos, float* vel, float* acc_out, const float* mass
   rc = launch_accel(posm, full_view(n, p), posm, n, 0, softening_sq, 1.0f, slabs, p, st);
   if (rc) return rc;
   const int n3 = 3 * n;
-  finish_kernel<<<ceil_div(n3, 256), 256, 0, st>>>(slabs, p.slabs, (size_t)n3, g_const, acc_out, vel, dt, n3);
+  finish_kernel<<<ceil_div(n3, 64), 256, 0, st>>>(slabs, p.slabs, (size_t)n3, g_const, acc_out, vel, dt, n3);
   rc = launch_status();
   if (rc) return rc;
   return nbd_drift_f32(pos, vel, n, dt, stream);

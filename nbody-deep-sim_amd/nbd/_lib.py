@@ -114,6 +114,14 @@ SIGNATURES = {
                                   c_void_p]),
     "nbd_contconv_bin_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_float, c_void_p, c_int, c_void_p, c_void_p]),
+    "nbd_contconv_fused_supported": (c_int, [c_int, c_int, c_int]),
+    "nbd_contconv_pairs_bytes": (c_size_t, [c_int, c_int64, c_int]),
+    "nbd_contconv_pairs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_int,
+                                       c_void_p, c_size_t, c_void_p]),
+    "nbd_contconv_fused_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "nbd_contconv_filter_floats": (c_size_t, [c_int, c_int, c_int]),
+    "nbd_contconv_fused_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_int,
+                                       c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "nbd_degree_scale_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nbd_gnn_layer_f32": (c_int, [POINTER(GnnLayerArgs), c_void_p]),
     # --- backward kernels (csrc/train.hip) and the transposed adjacency they gather over

@@ -161,6 +161,71 @@ def contconv_bin(pos, feat, rowptr, centres, d, radius_sq, out=None, node_begin=
     return out
 
 
+def contconv_fused_supported(i_ch: int, o_ch: int, n_cells: int) -> bool:
+    return bool(_lib.lib().nbd_contconv_fused_supported(int(i_ch), int(o_ch), int(n_cells)))
+
+
+def contconv_shuffle_filters(filters: torch.Tensor, cells: torch.Tensor) -> torch.Tensor:
+    """filters (D,D,D,I,O) -> the MFMA fragment order nbd_contconv_fused_f32 reads (see include/nbd.h):
+    [cell (the kept ones)][32-column block][8-k block][lane][4], lane = 32 * (k % 8 >= 4) + column % 32,
+    zero padded to I % 8 == 0 and O % 32 == 0. A layout transform of the weights: done once per weight update."""
+    d, i_ch, o_ch = filters.shape[0], filters.shape[3], filters.shape[4]
+    k = int(cells.numel())
+    f = filters.detach().reshape(d * d * d, i_ch, o_ch).index_select(0, cells)
+    ip, op = (i_ch + 7) // 8 * 8, (o_ch + 31) // 32 * 32
+    if ip != i_ch or op != o_ch:
+        f = torch.nn.functional.pad(f, (0, op - o_ch, 0, ip - i_ch))
+    f = f.reshape(k, ip // 8, 2, 4, op // 32, 32)              # [cell][kq][kb][c][cb][n]
+    f = f.permute(0, 4, 1, 2, 5, 3).contiguous()              # [cell][cb][kq][kb][n][c]
+    return f.reshape(-1)
+
+
+def contconv_pairs(pos, rowptr, centres, edge_capacity: int, d: int, radius_sq: float, cell_map, n_cells: int):
+    """Pair lists of one (graph, filter resolution): opaque device buffer for contconv_fused (see include/nbd.h)."""
+    n = pos.shape[0]
+    if pos.shape != (n, 3) or pos.dtype != torch.float32 or not pos.is_contiguous():
+        raise _lib.NbdError("pos must be contiguous fp32 (n,3)")
+    if rowptr.dtype != torch.int32 or rowptr.numel() != n + 1 or centres.dtype != torch.int32:
+        raise _lib.NbdError("rowptr int32 [n+1] / centres int32 required")
+    if centres.numel() > edge_capacity:
+        edge_capacity = centres.numel()
+    if cell_map is not None and (cell_map.dtype != torch.int32 or cell_map.numel() != d * d * d or not cell_map.is_cuda):
+        raise _lib.NbdError("cell_map must be an int32 CUDA tensor of d^3 entries")
+    L = _lib.lib()
+    nbytes = L.nbd_contconv_pairs_bytes(n, int(edge_capacity), int(n_cells))
+    buf = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=pos.device)
+    with _lib.on_device(pos.device):
+        _lib.check(L.nbd_contconv_pairs_f32(pos.data_ptr(), rowptr.data_ptr(), centres.data_ptr(), n, int(edge_capacity),
+                                            int(d), float(radius_sq), _lib.ptr(cell_map), int(n_cells), buf.data_ptr(),
+                                            buf.numel(), _lib.current_stream(pos.device)), "nbd_contconv_pairs_f32")
+    return buf, int(edge_capacity)
+
+
+def contconv_fused(feat, rowptr, pair_buf, edge_capacity: int, filt_shuffled, n_cells: int, o_ch: int, rowscale=None,
+                   act=None, out=None):
+    """out (n, o_ch) = act(rowscale * sum_cells A[n][cell] . F[cell]): the block-sparse fused ContinuousConv."""
+    n, i_ch = rowptr.numel() - 1, feat.shape[1]          # rows = aggregation targets; feat rows = source nodes
+    ldf = _mat(feat, "feat")
+    L = _lib.lib()
+    if filt_shuffled.dtype != torch.float32 or not filt_shuffled.is_contiguous() or \
+            filt_shuffled.numel() != L.nbd_contconv_filter_floats(i_ch, o_ch, n_cells):
+        raise _lib.NbdError("filt_shuffled: wrong size for (in, out, cells) -- use contconv_shuffle_filters")
+    if out is None:
+        out = torch.empty((n, o_ch), dtype=torch.float32, device=feat.device)
+    ldo = _mat(out, "out")
+    if out.shape != (n, o_ch):
+        raise _lib.NbdError(f"out must be ({n}, {o_ch})")
+    need = L.nbd_contconv_fused_workspace_bytes(n, n_cells, o_ch)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=feat.device)
+    with _lib.on_device(feat.device):
+        _lib.check(L.nbd_contconv_fused_f32(feat.data_ptr(), ldf, i_ch, rowptr.data_ptr(), n, int(edge_capacity),
+                                            pair_buf.data_ptr(), filt_shuffled.data_ptr(), int(n_cells), int(o_ch),
+                                            _lib.ptr(rowscale), 1 if act == "tanh" else 0, out.data_ptr(), ldo,
+                                            ws.data_ptr(), ws.numel(), _lib.current_stream(feat.device)),
+                   "nbd_contconv_fused_f32")
+    return out
+
+
 def degree_scale(rowptr, n, mode, device):
     out = torch.empty(n, dtype=torch.float32, device=device)
     with _lib.on_device(device):

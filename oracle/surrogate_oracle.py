@@ -38,7 +38,8 @@ the HIP path is tested against:
       PyG's default norm is "batch_norm": the ContConv encoder has it (norm not passed,
       contconv.py:136-141), the GNN encoder does not (norm=None, gnn.py:62). Inference uses the
       running statistics (predict/eval_graph_batch call eval()).
-  scatter(src, index, dim_size, reduce)   [contconv.py:95-97]   sum, or sum / max(count, 1) for mean.
+  scatter(src, index, dim_size, reduce)   [contconv.py:95-97]   sum, or sum / max(count, 1) for mean;
+      "max" / "min": per-channel extreme of the messages of a row, 0 for a row without messages.
 """
 from __future__ import annotations
 
@@ -232,6 +233,8 @@ class ContinuousConvOracle(torch.nn.Module):
     def forward(self, positions, features, edge_index, edge_block=4096):
         row, col = edge_index[0], edge_index[1]
         out = torch.zeros((positions.shape[0], self.out_channels), dtype=features.dtype)
+        extreme = self.agg in ("max", "min")           # scatter(reduce="max"/"min"): per-edge messages, rows without
+        messages = []                                  # edges stay 0 (torch_scatter fills empty segments with 0)
         for e0 in range(0, row.numel(), edge_block):       # blocked only to bound the (E,I,O) temporary
             rw, cl = row[e0:e0 + edge_block], col[e0:e0 + edge_block]
             r = positions[cl] - positions[rw]                                              # :84
@@ -242,7 +245,15 @@ class ContinuousConvOracle(torch.nn.Module):
             grid = (mapped + 1) * ((self.filter_resolution - 1) / 2)                       # :90
             filt = self.trilinear_interpolate(grid)
             conv = torch.einsum("eio,ei->eo", filt, features[cl]) * window.unsqueeze(1)    # :92-93
-            out.index_add_(0, rw, conv)
+            if extreme:
+                messages.append(conv)
+            else:
+                out.index_add_(0, rw, conv)
+        if extreme:
+            if messages:
+                out.scatter_reduce_(0, row.unsqueeze(1).expand(-1, self.out_channels), torch.cat(messages),
+                                    reduce="amax" if self.agg == "max" else "amin", include_self=False)
+            return out
         if self.agg == "mean":                                                             # :95-97
             cnt = torch.zeros(positions.shape[0]).index_add_(0, row, torch.ones(row.numel()))
             out = out / cnt.clamp(min=1).unsqueeze(-1)

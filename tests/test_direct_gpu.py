@@ -440,7 +440,8 @@ def test_split_force_matches_one_launch(n, lo, n_loc, eps, gpu_device):
     direct.shard_force_local(posm_local, n_loc, n, lo, eps2, ws)
     direct.shard_force_remote(posm, n, posm_local, n_loc, lo, eps2, g, acc, vel, 0.25, ws)
     assert torch.isfinite(acc).all()
-    assert row_rel(_np(acc), _np(ref)) < 2e-6
+    # two valid fp32 summation orders of the same pairs; without softening close pairs dominate single rows
+    assert row_rel(_np(acc), _np(ref)) < (2e-6 if eps > 0 else 5e-6)
     assert torch.equal(vel, torch.full_like(vel, 0.5) + 0.25 * acc)
     # determinism of the split path
     acc2 = torch.empty_like(acc)

@@ -224,6 +224,72 @@ def test_contconv_layer_matches_oracle(agg, D, I, O, gpu_device):
         assert global_rel(got_d, ref_d) < TOL
 
 
+@pytest.mark.parametrize("n,D,I,O,agg,r,cap", [
+    (400, 4, 8, 16, "mean", 1.0, 32), (1000, 6, 128, 128, "mean", 1.0, 32), (129, 3, 4, 20, "sum", 1.0, 32),
+    (513, 5, 96, 130, "mean", 0.8, 32), (300, 4, 32, 64, "sum", 3.0, 300), (64, 2, 12, 33, "mean", 1.0, 32),
+    (2000, 6, 64, 96, "mean", 0.6, 32), (1, 4, 8, 8, "mean", 1.0, 32)])
+def test_contconv_fused_kernels_match_oracle_and_binned_path(n, D, I, O, agg, r, cap, gpu_device):
+    """csrc/contconv_fused.hip (pair lists + gather/MFMA/accumulate in one kernel) against the oracle and against
+    the round-1 formulation (dense binned matrix + GEMM) on the same edges: ragged tile counts, nodes without
+    edges, rows with hundreds of pairs (r = 3, uncapped), channel counts off the MFMA grid, both aggregations."""
+    import contconv
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(n + D)
+    pos, _, _ = _plummer_pos(n, 30 + D)
+    feat = torch.randn(n, I)
+    ora = so.ContinuousConvOracle(I, O, D, radius=r, agg=agg)
+    layer = contconv.ContinuousConv(I, O, D, radius=r, agg=agg).cuda()
+    _copy_state(layer, ora)
+    assert layer.fused_ok()
+    ei = so.radius_graph(pos, r, loop=True, max_num_neighbors=cap)
+    with torch.no_grad():
+        ref = ora(pos, feat, ei)
+        got = layer(pos.cuda(), feat.cuda(), edge_index=ei.cuda())
+        again = layer(pos.cuda(), feat.cuda(), edge_index=ei.cuda())
+        assert torch.equal(got, again)                                      # deterministic
+        layer.use_fused = False
+        old = layer(pos.cuda(), feat.cuda(), edge_index=ei.cuda())
+        layer.use_fused = True
+        got_t = layer(pos.cuda(), feat.cuda(), edge_index=ei.cuda(), act="tanh")
+    assert global_rel(got.cpu(), ref) < TOL and row_rel(got.cpu(), ref) < 10 * TOL
+    assert global_rel(got.cpu(), old.cpu()) < TOL
+    assert global_rel(got_t.cpu(), torch.tanh(ref)) < TOL
+    # a strided output / input view (how the model passes its concatenation buffer)
+    buf = torch.zeros((n, I + O + 2), device="cuda")
+    buf[:, :I] = feat.cuda()
+    with torch.no_grad():
+        layer(pos.cuda(), buf[:, :I], edge_index=ei.cuda(), out=buf[:, I:I + O]) if (I + O + 2) % 2 == 0 else None
+    if (I + O + 2) % 2 == 0:
+        assert torch.equal(buf[:, I:I + O], got) and float(buf[:, I + O:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("agg", ["max", "min"])
+@pytest.mark.parametrize("D,I,O", [(4, 8, 16), (3, 70, 40)])
+def test_contconv_extreme_aggregations_match_oracle(agg, D, I, O, gpu_device):
+    """scatter(reduce="max"/"min") (contconv.py:95-97 passes `agg` straight through): per-edge messages
+    materialised through the virtual one-edge-per-row graph, then the segment reduction; rows without edges 0.
+    (I = 70 is off the fused kernel's grid: the binned + GEMM path carries the messages there.)"""
+    import contconv
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(D)
+    pos, _, _ = _plummer_pos(300, 9)
+    feat = torch.randn(300, I)
+    ora = so.ContinuousConvOracle(I, O, D, radius=1.0, agg=agg)
+    layer = contconv.ContinuousConv(I, O, D, radius=1.0, agg=agg).cuda()
+    _copy_state(layer, ora)
+    ei = so.radius_graph(pos, 1.0, loop=False, max_num_neighbors=32)          # no self loops: isolated nodes exist
+    assert (torch.bincount(ei[0], minlength=300) == 0).any()
+    with torch.no_grad():
+        ref = ora(pos, feat, ei)
+        got = layer(pos.cuda(), feat.cuda(), edge_index=ei.cuda()).cpu()
+    assert global_rel(got, ref) < TOL and row_rel(got, ref) < 10 * TOL
+    assert float(got[torch.bincount(ei[0], minlength=300) == 0].abs().max()) == 0.0
+    with pytest.raises(NotImplementedError):
+        contconv.ContinuousConv(I, O, D, agg="mul")
+    with pytest.raises(NotImplementedError):
+        layer(pos.cuda(), feat.cuda().requires_grad_(True), edge_index=ei.cuda())
+
+
 def test_contconv_model_matches_oracle(gpu_device):
     import contconv
     from oracle import surrogate_oracle as so
@@ -558,8 +624,10 @@ def test_test_from_dir_reproduces_reference_frames(use_graph, tmp_path, gpu_devi
     assert [i[0] for i in df_roll.index] == list(g["rollout_index_filename"])
     assert [int(i[1]) for i in df_roll.index] == list(g["rollout_index_scene"])
     assert [int(i[2]) for i in df_roll.index] == list(g["rollout_index_step"])
-    # per-row values are fp32-exact on both sides; the float64 group means may associate differently
-    assert np.allclose(df_step.to_numpy(dtype=np.float64), g["stepwise_values"], rtol=1e-12, atol=0)
+    # stepwise: `loss` is the toy model's own fp32 .mean() over a graph (reduction order differs CPU vs GPU:
+    # ~1e-7), averaged per scene by the trainer; step_time is the constant the model returns
+    assert np.allclose(df_step.to_numpy(dtype=np.float64), g["stepwise_values"], rtol=1e-6, atol=0)
+    # rollout: per-row values are fp32-exact on both sides; the float64 group means may associate differently
     assert np.allclose(df_roll.to_numpy(dtype=np.float64), g["rollout_values"], rtol=1e-9, atol=1e-15)
     assert (g["rollout_values"][:, 2] > 0).all() and g["rollout_values"][0, 0] == 0      # a real, non-trivial frame
 
