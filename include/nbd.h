@@ -31,6 +31,7 @@ extern "C" {
 
 #define NBD_SRC_PAD 64      /* packed source arrays are padded to a multiple of this          */
 #define NBD_CC_TILE 128     /* nodes per tile of the fused ContinuousConv kernels             */
+#define NBD_CC_MAX_RES 4    /* filter resolutions per nbd_contconv_pairs_batch_f32 call       */
 
 typedef void* nbd_stream_t;
 
@@ -384,15 +385,21 @@ int nbd_layernorm_bwd_f32(const float* x, int ldx, int c, const float* gamma, fl
  *   edge_index[1]. cell_map (int32 [D^3], -1 = cell dropped) or NULL; n_cells = cells kept. edge_capacity >=
  *   rowptr[n] sizes the lists (host-known bound, e.g. n * max_num_neighbors: no device read-back).
  * nbd_contconv_fused_f32: out[n][:] = act(rowscale[n] * sum_cells A[n][cell] . F[cell]) with
- *   filters_shuffled = the (cell, in, out) filters in MFMA fragment order: float index
- *   ((((cell * ceil(O/32) + cb) * ceil(I/8) + kq) * 64 + lane) * 4 + c) holds F[cell][8 kq + 4 (lane >> 5) + c][32 cb +
- *   (lane & 31)], zero beyond I / O (nbd_contconv_filter_floats floats in all). act: 0 none, 1 tanh.
+ *   filters_shuffled = the (cell, in, out) filters in MFMA fragment order (v_mfma_f32_16x16x4_f32): float index
+ *   ((((cell * ceil(O/16) + cb) * ceil(I/16) + g) * 64 + lane) * 4 + j) holds F[cell][16 g + 4 (lane >> 4) + j][16 cb +
+ *   (lane & 15)], zero beyond I / O (nbd_contconv_filter_floats floats in all). act: 0 none, 1 tanh.
  *   rowscale may be NULL. Deterministic. */
 int nbd_contconv_fused_supported(int in_channels, int out_channels, int n_cells);
 size_t nbd_contconv_pairs_bytes(int n, int64_t edge_capacity, int n_cells);
 int nbd_contconv_pairs_f32(const float* pos, const int* rowptr, const int* centres, int n, int64_t edge_capacity,
                            int filter_resolution, float radius_sq, const int* cell_map, int n_cells,
                            void* pair_lists, size_t pair_lists_bytes, nbd_stream_t stream);
+/* The pair lists of up to NBD_CC_MAX_RES filter resolutions of ONE graph in a single launch (the layers of a
+ * model share the graph and differ in D). Host arrays of n_res entries each. */
+int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int* centres, int n, int64_t edge_capacity,
+                                 float radius_sq, int n_res, const int* filter_resolutions, const int* const* cell_maps,
+                                 const int* n_cells, void* const* pair_lists, const size_t* pair_lists_bytes,
+                                 nbd_stream_t stream);
 size_t nbd_contconv_fused_workspace_bytes(int n, int n_cells, int out_channels);
 size_t nbd_contconv_filter_floats(int in_channels, int out_channels, int n_cells);
 int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const int* rowptr, int n, int64_t edge_capacity,

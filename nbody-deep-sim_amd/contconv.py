@@ -244,18 +244,22 @@ class ContinuousConvModel(nn.Module):
         else:
             run_chain(x, w["enc"], out_last=enc_view)
         h = enc_view
-        pair_cache = {}                              # layers with the same filter resolution share their pair lists
+        # pair lists: one launch for all the filter resolutions of the model (layers share the graph)
+        pair_cache = {}
+        if n > 0:
+            keys, jobs = [], []
+            for layer in self.contconv:
+                key = (layer.filter_resolution, float(layer.radius))
+                if layer.fused_ok() and key not in keys:
+                    _, cmap, n_cells = layer.cells()
+                    keys.append(key); jobs.append((layer.filter_resolution, cmap, n_cells))
+            for lo in range(0, len(jobs), 4):
+                got = nnops.contconv_pairs_batch(pos, lists.rowptr, lists.centres, lists.centres.numel(),
+                                                 float(np.float32(self.radius ** 2)), jobs[lo:lo + 4])
+                pair_cache.update(zip(keys[lo:lo + 4], got))
         for li, layer in enumerate(self.contconv):
             last = li == len(self.contconv) - 1
-            pairs = None
-            if layer.fused_ok() and n > 0:
-                key = (layer.filter_resolution, float(layer.radius))
-                if key not in pair_cache:
-                    _, cmap, n_cells = layer.cells()
-                    pair_cache[key] = nnops.contconv_pairs(pos, lists.rowptr, lists.centres, lists.centres.numel(),
-                                                           layer.filter_resolution, float(np.float32(layer.radius ** 2)),
-                                                           cmap, n_cells)
-                pairs = pair_cache[key]
+            pairs = pair_cache.get((layer.filter_resolution, float(layer.radius))) if layer.fused_ok() else None
             h = layer(pos, h, lists=lists, act="tanh", out=conv_view if last else None, wt=w["wt"][li], pairs=pairs)
         ln = nnops.layernorm(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
                              self.layer_norm.eps)

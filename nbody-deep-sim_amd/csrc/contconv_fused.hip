@@ -24,6 +24,7 @@
 //                            (scale, activation). No float atomics across waves: deterministic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/nbd.h"
 
@@ -39,7 +40,8 @@ inline int status() { hipError_t e = hipGetLastError(); return e == hipSuccess ?
 constexpr int TN = NBD_CC_TILE;      // nodes per tile (128)
 constexpr int SUB = 32;              // packed rows per MFMA step
 constexpr int LDA = 132;             // A row stride in floats: 16-B aligned, conflict-free ds_read_b128 fragments
-constexpr int MAXC = 256;            // filter cells (reachable) supported: D <= 6
+constexpr int MAXC = 160;            // filter cells kept (reachable) supported: D = 6 at R = 1 has exactly 160; the pair
+                                     // kernel's LDS tables (7 bytes per (node, cell) + scan scratch) fill the 160 KiB at that
 constexpr int CHUNK_MAX = 64;        // cells per workgroup of the fused kernel
 
 struct Geo { int ix, iy, iz; float tx, ty, tz, window; };
@@ -84,64 +86,98 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 }
 
 // ---------------------------------------------------------------------------------------------- pair lists
-// One workgroup (8 waves) per tile of 128 nodes. LDS: cnt[node][cell] (u16 pairs of a (node, cell) block,
-// packed two per word), pwithin[node][cell] (u32: pairs of the same cell in lower nodes of the tile),
-// rowidx[node][cell] (u8: touched lower nodes of the same cell).
-//   A  wave per node, lane per edge: geometry, 8 LDS counter increments
-//   B  wave per cell, lanes over nodes: prefix sums down the tile -> rows and pairs per cell
+// One workgroup (16 waves) per (tile of 128 nodes, filter resolution): the lists of every resolution a model
+// uses are built by ONE launch (grid.y), which also fills the chip (a tile count of 128 is half the CUs).
+// LDS: cnt[node][cell] (u16 pairs of a (node, cell) block, packed two per word), pwithin[node][cell] (u32: pairs
+// of the same cell in lower nodes of the tile), rowidx[node][cell] (u8: touched lower nodes of the same cell),
+// the tile's slice of rowptr and the cell map.
+//   A  lane per edge over the tile's whole edge range (coalesced, every lane busy; the node of an edge by
+//      binary search in the LDS copy of rowptr): geometry, 8 LDS counter increments. Order-free.
+//   B  prefix sums down the tile per cell, two levels: thread (16-node segment, cell) sums its segment, then
+//      walks it again from the sum of the lower segments (LDS reads only, conflict-free: neighbouring threads
+//      take neighbouring cells). (First form: one shuffle-based wave scan per cell and quantity, 27 us.)
 //   B2 prefix over cells -> desc[tile][cell] = {first row, rows}
 //   B3 rows[] = {node_local, first pair}
-//   C  wave per node again: each pair takes the next slot of its (node, cell) block. A node belongs to one
-//      wave and its edges are visited in CSR order, so slots are assigned in a fixed order.
+//   C  half a wave per node, lane per edge: each pair takes the next slot of its (node, cell) block. Nodes are
+//      handed out through a counter (dense tiles hold nodes with ~200 edges next to nodes with 5); a node
+//      belongs to one half-wave and its edges are visited in CSR order, so the slots -- and with them the order
+//      in which the fused kernel sums a block's pairs -- do not depend on which half-wave took the node.
 // Global layout, per tile t with e_t = rowptr[128 t]: rows at 8 e_t + t (one sentinel row per tile),
 // pairs at 8 e_t: an edge has at most 8 corners, so the bases need no scan across tiles.
-__global__ __launch_bounds__(512) void contconv_pairs_kernel(
-    const float* __restrict__ pos, const int* __restrict__ rowptr, const int* __restrict__ centres, int n, int D,
-    float r2max, const int* __restrict__ cell_map, int n_cells, int2* __restrict__ desc, int2* __restrict__ rows,
-    int2* __restrict__ pairs) {
+struct PairJob {
+  int D, n_cells;
+  const int* cell_map;
+  int2 *desc, *rows, *pairs;
+};
+struct PairJobs { PairJob j[NBD_CC_MAX_RES]; };
+
+constexpr int PAIR_THREADS = 1024;
+constexpr int SEG = 16, NSEG = TN / SEG;                   // node segments of the two-level scan
+__global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
+    const float* __restrict__ pos, const int* __restrict__ rowptr, const int* __restrict__ centres, int n, float r2max,
+    const PairJobs jobs) {
   extern __shared__ unsigned smem[];
+  const PairJob& job = jobs.j[blockIdx.y];
+  const int D = job.D, n_cells = job.n_cells;
+  int2* __restrict__ desc = job.desc;
+  int2* __restrict__ rows = job.rows;
+  int2* __restrict__ pairs = job.pairs;
   const int kc = (n_cells + 3) & ~3;                       // padded cell count (even: two u16 per word)
   unsigned* cnt32 = smem;                                   // [TN][kc/2]
   unsigned* pwithin = cnt32 + TN * kc / 2;                  // [TN][kc]
   unsigned char* rowidx = reinterpret_cast<unsigned char*>(pwithin + TN * kc);   // [TN][kc]
   __shared__ int cell_rows[MAXC], cell_pairs[MAXC], cell_rowbase[MAXC], cell_pairbase[MAXC];
+  __shared__ int seg_pairs[NSEG][MAXC], seg_rows[NSEG][MAXC];
+  __shared__ int rp[TN + 1];
+  __shared__ int cmap[216];                                 // D <= 6
+  __shared__ int next_node;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x, n0 = tile * TN, n_here = min(TN, n - n0);
-  const int e_t = rowptr[n0];
-  const size_t row_base = (size_t)8 * e_t + tile, pair_base = (size_t)8 * e_t;
   const float half = (float)(D - 1) / 2.0f;
 
-  for (int i = tid; i < TN * kc / 2; i += 512) cnt32[i] = 0;
+  if (tid <= TN) rp[tid] = rowptr[min(n0 + tid, n)];
+  if (tid < D * D * D) cmap[tid] = job.cell_map ? job.cell_map[tid] : tid;
+  if (tid == 0) next_node = 0;
+  for (int i = tid; i < TN * kc / 2; i += PAIR_THREADS) cnt32[i] = 0;
   __syncthreads();
+  const int e_t = rp[0], e_end = rp[n_here];
+  const size_t row_base = (size_t)8 * e_t + tile, pair_base = (size_t)8 * e_t;
 
-  // ---- A: counts
-  for (int nl = wave; nl < n_here; nl += 8) {
-    const int node = n0 + nl;
-    const float xn = pos[3 * node], yn = pos[3 * node + 1], zn = pos[3 * node + 2];
-    const int e0 = rowptr[node], e1 = rowptr[node + 1];
-    for (int e = e0 + lane; e < e1; e += 64) {
-      const Geo g = edge_geo(pos, centres[e], xn, yn, zn, r2max, half);
-      if (g.window == 0.f) continue;                       // outside the radius: the reference multiplies by 0
+  // ---- A: counts (lane = edge)
+  for (int e = e_t + tid; e < e_end; e += PAIR_THREADS) {
+    int lo = 0, hi = n_here;                               // largest nl with rp[nl] <= e
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rp[mid] <= e) lo = mid; else hi = mid; }
+    const int nl = lo, node = n0 + nl;
+    const Geo g = edge_geo(pos, centres[e], pos[3 * node], pos[3 * node + 1], pos[3 * node + 2], r2max, half);
+    if (g.window == 0.f) continue;                         // outside the radius: the reference multiplies by 0
 #pragma unroll
-      for (int corner = 0; corner < 8; ++corner) {
-        float w;
-        const int k = corner_cell(g, corner, D, cell_map, &w);
-        if (k >= 0) atomicAdd(&cnt32[(nl * kc + k) >> 1], 1u << (16 * (k & 1)));
-      }
+    for (int corner = 0; corner < 8; ++corner) {
+      float w;
+      const int k = corner_cell(g, corner, D, cmap, &w);
+      if (k >= 0) atomicAdd(&cnt32[(nl * kc + k) >> 1], 1u << (16 * (k & 1)));
     }
   }
   __syncthreads();
 
-  // ---- B: per cell, prefix over the nodes of the tile (lane holds nodes 2*lane and 2*lane + 1)
+  // ---- B: per cell, prefix over the nodes of the tile, in 16-node segments
   const unsigned short* cnt16 = reinterpret_cast<const unsigned short*>(cnt32);
-  for (int k = wave; k < n_cells; k += 8) {
-    const int v0 = cnt16[(2 * lane) * kc + k], v1 = cnt16[(2 * lane + 1) * kc + k];
-    const int r0 = v0 > 0, r1 = v1 > 0;
-    const int pi = wave_incl_scan(v0 + v1, lane), ri = wave_incl_scan(r0 + r1, lane);
-    const int pe = pi - (v0 + v1), re = ri - (r0 + r1);     // exclusive
-    pwithin[(2 * lane) * kc + k] = pe;      rowidx[(2 * lane) * kc + k] = (unsigned char)re;
-    pwithin[(2 * lane + 1) * kc + k] = pe + v0; rowidx[(2 * lane + 1) * kc + k] = (unsigned char)(re + r0);
-    if (lane == 63) { cell_pairs[k] = pi; cell_rows[k] = ri; }
+  for (int w = tid; w < NSEG * n_cells; w += PAIR_THREADS) {
+    const int sg = w / n_cells, k = w - sg * n_cells;       // neighbouring threads: neighbouring cells
+    int ps = 0, rs = 0;
+    for (int i = 0; i < SEG; ++i) { const int v = cnt16[(sg * SEG + i) * kc + k]; ps += v; rs += v > 0; }
+    seg_pairs[sg][k] = ps; seg_rows[sg][k] = rs;
+  }
+  __syncthreads();
+  for (int w = tid; w < NSEG * n_cells; w += PAIR_THREADS) {
+    const int sg = w / n_cells, k = w - sg * n_cells;
+    int pe = 0, re = 0;
+    for (int q = 0; q < sg; ++q) { pe += seg_pairs[q][k]; re += seg_rows[q][k]; }
+    for (int i = 0; i < SEG; ++i) {
+      const int nl = sg * SEG + i, v = cnt16[nl * kc + k];
+      pwithin[nl * kc + k] = pe; rowidx[nl * kc + k] = (unsigned char)re;
+      pe += v; re += v > 0;
+    }
+    if (sg == NSEG - 1) { cell_pairs[k] = pe; cell_rows[k] = re; }
   }
   __syncthreads();
 
@@ -164,190 +200,337 @@ __global__ __launch_bounds__(512) void contconv_pairs_kernel(
   }
   __syncthreads();
 
-  // ---- B3: row records
-  for (int i = tid; i < TN * n_cells; i += 512) {
-    const int nl = i / n_cells, k = i - nl * n_cells;
-    if (cnt16[nl * kc + k] > 0)
-      rows[row_base + cell_rowbase[k] + rowidx[nl * kc + k]] = make_int2(nl, cell_pairbase[k] + (int)pwithin[nl * kc + k]);
-  }
-
+  // ---- B3: row records (wave = nodes, lanes = cells: no division)
+  for (int nl = wave; nl < n_here; nl += PAIR_THREADS / 64)
+    for (int k = lane; k < n_cells; k += 64)
+      if (cnt16[nl * kc + k] > 0)
+        rows[row_base + cell_rowbase[k] + rowidx[nl * kc + k]] = make_int2(nl, cell_pairbase[k] + (int)pwithin[nl * kc + k]);
   __syncthreads();          // B3 reads the counters that C counts down
 
-  // ---- C: place the pairs (counters count down: slot = old - 1)
-  for (int nl = wave; nl < n_here; nl += 8) {
+  // ---- C: place the pairs (counters count down: slot = old - 1). A half-wave takes the next node from the
+  // counter; its 32 lanes walk the node's edges in order.
+  const int hl = lane & 31;
+  for (;;) {
+    int nl = 0;
+    if (hl == 0) nl = atomicAdd(&next_node, 1);
+    nl = __shfl(nl, lane & 32);                            // broadcast inside the half-wave
+    if (nl >= n_here) break;
     const int node = n0 + nl;
     const float xn = pos[3 * node], yn = pos[3 * node + 1], zn = pos[3 * node + 2];
-    const int e0 = rowptr[node], e1 = rowptr[node + 1];
-    for (int e = e0 + lane; e < e1; e += 64) {
-      const int c = centres[e];
-      const Geo g = edge_geo(pos, c, xn, yn, zn, r2max, half);
+    const int e0 = rp[nl], e1 = rp[nl + 1];
+    // the source of the NEXT trip is fetched before this trip's counters and stores (a dense tile's nodes have
+    // ~200 edges: seven trips per node, each otherwise paying centres -> pos -> store in sequence)
+    int c = (e0 + hl < e1) ? centres[e0 + hl] : 0;
+    float px = pos[3 * c], py = pos[3 * c + 1], pz = pos[3 * c + 2];
+    for (int e = e0 + hl; e < e1; e += 32) {
+      const int c_cur = c;
+      const float sx = px, sy = py, sz = pz;
+      if (e + 32 < e1) { c = centres[e + 32]; px = pos[3 * c]; py = pos[3 * c + 1]; pz = pos[3 * c + 2]; }
+      const float src[3] = {sx, sy, sz};
+      const Geo g = edge_geo(src, 0, xn, yn, zn, r2max, half);
       if (g.window == 0.f) continue;
 #pragma unroll
       for (int corner = 0; corner < 8; ++corner) {
         float w;
-        const int k = corner_cell(g, corner, D, cell_map, &w);
+        const int k = corner_cell(g, corner, D, cmap, &w);
         if (k < 0) continue;
         const unsigned old = atomicSub(&cnt32[(nl * kc + k) >> 1], 1u << (16 * (k & 1)));
         const int slot = (int)((old >> (16 * (k & 1))) & 0xffffu) - 1;
-        pairs[pair_base + cell_pairbase[k] + pwithin[nl * kc + k] + slot] = make_int2(c, __float_as_int(w));
+        pairs[pair_base + cell_pairbase[k] + pwithin[nl * kc + k] + slot] = make_int2(c_cur, __float_as_int(w));
       }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------- fused conv
-// grid = (tiles, cell chunks, column groups of 128); block = 512 threads: waves 0-3 consume (MFMA, 32 output
-// columns each), waves 4-7 produce (gather + sum of the packed A rows). One s_barrier per step.
-struct Step { int cell, row_begin, n_rows; };
+// grid = (tiles, cell chunks, column groups of 128); block = 1024 threads: waves 0-7 consume (MFMA, 16 output
+// columns each), waves 8-15 produce (gather + sum of the packed A rows; two waves per ring buffer).
+//
+// A "step" is 32 packed rows of one cell. Producer wave p builds the steps p, p+4, p+8, ... into ring buffer p
+// (it owns that buffer); consumer waves walk all steps in order. The two sides meet only through LDS flags
+// -- full[b] = sequence number of the step buffer b holds, done[b] = consumer waves that have finished with
+// it -- so a producer's load latency (row records -> pairs -> feature rows, three dependent trips to L2) is
+// hidden behind three other steps, and the consumers never wait for each other: every wave owns its 32
+// output columns of the LDS accumulator. (First version: one s_barrier per step, 7 us per step against
+// 1.8 us of MFMA.)
+constexpr int NBUF = 4;
+constexpr int CC_CONSUMERS = 8;                  // consumer waves (16 output columns each)
+constexpr int CC_PRODUCERS = 2 * NBUF;           // producer waves: two per ring buffer, 16 packed rows each
+constexpr int CC_THREADS = (CC_CONSUMERS + CC_PRODUCERS) * 64;
+constexpr int HSUB = SUB / 2;
+typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr int MAX_STEPS = CHUNK_MAX * (TN / SUB);
 
-__global__ __launch_bounds__(512) void contconv_fused_kernel(
+// Flags live in LDS and guard LDS data only: relaxed workgroup-scope atomics + fences restricted to the local
+// address space, so that signalling never drains the global loads a wave keeps in flight (filter-fragment and
+// row-record prefetches).
+#define CC_WAIT(flag, cond)                                                                                  \
+  do {                                                                                                       \
+    while (!(__hip_atomic_load(&(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) cond))               \
+      __builtin_amdgcn_s_sleep(1);                                                                           \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");                                          \
+  } while (0)
+#define CC_RELEASE_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+
+__device__ unsigned long long cc_dbg[4096 * 16 * 8];
+__device__ unsigned long long cc_dbg2[4096 * 8];      // TEMPORARY: per workgroup {t_start, t_setup, t_loop_end, t_end, hw_id, xcc}     // TEMPORARY: per (workgroup, wave) phase cycle totals (ABL == 5)
+#define CC_T() (ABL == 5 ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
+
+template <int ABL, int KG>
+__global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
     const float* __restrict__ feat, int ldf, int I, const int* __restrict__ rowptr, int n,
     const int2* __restrict__ desc, const int2* __restrict__ rows, const int2* __restrict__ pairs,
     const f4* __restrict__ filt, int n_cells, int kq_count, int colblocks, int cells_per_chunk, int O,
     float* __restrict__ partial) {
-  extern __shared__ float lds[];
-  float* out_acc = lds;                                    // [TN][128]
-  float* a_buf = out_acc + TN * 128;                       // [2][SUB][LDA]
-  int* rowmap = reinterpret_cast<int*>(a_buf + 2 * SUB * LDA);   // [2][SUB]
+  // f4-typed so that the dynamic region starts 16-byte aligned behind the static __shared__ variables: declared
+  // as float[] it began at an 8-byte offset and EVERY ds_read_b128 / ds_write_b64 below took the unaligned path
+  // (SQ_LDS_UNALIGNED_STALL = 85 % of all LDS cycles, LDS array 69 % busy, MFMA pipe 27 %)
+  extern __shared__ f4 lds_aligned[];
+  float* lds = reinterpret_cast<float*>(lds_aligned);
+  float* out_acc = lds;                                    // [TN + 1][128]: row TN swallows a step's padding rows
+  float* a_buf = out_acc + (TN + 1) * 128;                 // [NBUF][SUB][LDA]
+  int* rowmap = reinterpret_cast<int*>(a_buf + NBUF * SUB * LDA);   // [NBUF][SUB]
   __shared__ int s_cell[CHUNK_MAX], s_rowbeg[CHUNK_MAX], s_nrows[CHUNK_MAX];
-  __shared__ int s_ncell;
+  __shared__ unsigned char st_cell[MAX_STEPS], st_sub[MAX_STEPS];  // step -> (compact cell, 32-row slice)
+  __shared__ int s_ncell, s_nsteps;
+  __shared__ int full[NBUF], done[NBUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long tw0 = (ABL == 5) ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const int tile = blockIdx.x, n0 = tile * TN;
   const int k_begin = blockIdx.y * cells_per_chunk, k_end = min(n_cells, k_begin + cells_per_chunk);
   const int e_t = rowptr[n0];
   const int2* t_rows = rows + (size_t)8 * e_t + tile;
   const int2* t_pairs = pairs + (size_t)8 * e_t;
 
-  // non-empty cells of this chunk, compacted (wave 0; cells_per_chunk <= 64)
+  // non-empty cells of this chunk, compacted, and the step table (wave 0; cells_per_chunk <= 64)
   if (wave == 0) {
     const int k = k_begin + lane;
     int2 d = make_int2(0, 0);
     if (k < k_end) d = desc[(size_t)tile * n_cells + k];
     const unsigned long long m = __ballot(d.y > 0);
+    const int nsub = (d.y + SUB - 1) / SUB;
+    int incl = nsub;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
     if (d.y > 0) {
       const int j = __popcll(m & ((1ull << lane) - 1ull));
       s_cell[j] = k; s_rowbeg[j] = d.x; s_nrows[j] = d.y;
+      for (int u = 0; u < nsub; ++u) { st_cell[incl - nsub + u] = (unsigned char)j; st_sub[incl - nsub + u] = (unsigned char)u; }
     }
+    if (lane == 63) s_nsteps = incl;
     if (lane == 0) s_ncell = __popcll(m);
+    if (lane < NBUF) { full[lane] = 0; done[lane] = 0; }
   }
-  for (int i = tid; i < TN * 128 / 4; i += 512) reinterpret_cast<f4*>(out_acc)[i] = f4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < (TN + 1) * 128 / 4; i += CC_THREADS) reinterpret_cast<f4*>(out_acc)[i] = f4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  const int ncell = s_ncell;
+  const int nsteps = s_nsteps;
+  const unsigned long long tw1 = (ABL == 5) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
-  const bool producer = wave >= 4;
-  const int w4 = wave & 3;
-  const int cb = blockIdx.z * 4 + w4;                      // consumer: 32-column block of the output
-  const bool has_cols = cb < colblocks;
-
-  // ---- producer: packed A rows of one step into a_buf[buf]
-  auto produce = [&](int j, int sub, int buf) {
-    const int nrows = s_nrows[j], rbeg = s_rowbeg[j];
-    const int r_first = sub * SUB + 8 * w4;                // this wave's 8 rows of the step
-    const int cnt = max(0, min(8, nrows - r_first));
-    float* a_dst = a_buf + (buf * SUB + 8 * w4) * LDA;
-    int2 rinfo = make_int2(-1, 0);
-    if (lane <= cnt && cnt > 0) rinfo = t_rows[rbeg + r_first + lane];     // row `cnt` = the next row (or sentinel)
-    if (lane < 8) rowmap[buf * SUB + 8 * w4 + lane] = lane < cnt ? rinfo.x : -1;
-    if (cnt == 0) return;
-    const int p_begin = __builtin_amdgcn_readlane(rinfo.y, 0), p_end = __builtin_amdgcn_readlane(rinfo.y, cnt);
+  if (wave >= CC_CONSUMERS) {
+    const int w4 = (wave - CC_CONSUMERS) & (NBUF - 1);    // ring buffer this wave fills
+    const int hf = (wave - CC_CONSUMERS) / NBUF;           // which 16 rows of each step
+    // ---------------- producer: rows [16 hf, 16 hf + 16) of the steps w4, w4 + 4, ... into buffer w4
+    // The wave is instruction-issue bound (two waves per SIMD), so the per-pair work is kept to a handful of
+    // instructions: the pair records of 64 pairs sit one per lane; a row's byte offset is one VALU multiply for
+    // all 64; a feature row is then `v_readlane -> s_add -> global_load (scalar base + lane offset)`, and its
+    // accumulation `v_readlane -> v_pk_fma_f32`. Rows are fetched 16 at a time with the next 16 in flight
+    // (the gather wants tens of KiB outstanding per CU: MI355X_MICROARCH.md "Indexed rows"), and the wave's next
+    // step's row records are fetched while this one is summed. (First form: 64-bit index math, a predicate
+    // around every load and a clamp per pair -- 25+ instructions per pair, 5.7 us per step.)
+    constexpr int PB = 16;
+    float* a_dst = a_buf + (w4 * SUB + hf * HSUB) * LDA;
     const bool live = 2 * lane < I;
-    const float* f_lane = feat + 2 * lane;
-    int cur = 0;                                           // row being accumulated
-    int next_begin = __builtin_amdgcn_readlane(rinfo.y, 1);
-    f2 acc = {0.f, 0.f};
-    for (int base = p_begin; base < p_end; base += 64) {
+    const unsigned lane8 = (unsigned)min(2 * lane, I - 2) * 4u;      // clamped: every lane reads inside the row
+    const char* fbytes = reinterpret_cast<const char*>(feat);
+    const unsigned ldb = (unsigned)ldf * 4u;
+    auto row_records = [&](int s) {
+      const int j = st_cell[s];
+      const int cnt = max(0, min(HSUB, s_nrows[j] - st_sub[s] * SUB - hf * HSUB));      // this half's rows (may be 0)
+      int2 r = make_int2(-1, 0);
+      if (lane <= cnt && cnt > 0) r = t_rows[s_rowbeg[j] + st_sub[s] * SUB + hf * HSUB + lane];   // row `cnt` = the next row (or the sentinel)
+      return r;
+    };
+    int2 rinfo = make_int2(-1, 0);
+    if (w4 < nsteps) rinfo = row_records(w4);
+    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0};
+    for (int s = w4, use = 0; s < nsteps; s += NBUF, ++use) {
+      const unsigned long long t0 = CC_T();
+      const int cnt = max(0, min(HSUB, s_nrows[st_cell[s]] - st_sub[s] * SUB - hf * HSUB));
+      const int p_begin = __builtin_amdgcn_readlane(rinfo.y, 0), p_end = __builtin_amdgcn_readlane(rinfo.y, cnt);
+      const unsigned long long t1 = CC_T();
       int2 pr = make_int2(0, 0);
-      if (base + lane < p_end) pr = t_pairs[base + lane];
-      const int here = min(64, p_end - base);
-      for (int i0 = 0; i0 < here; i0 += 4) {
-        f2 f[4];
-        float w[4];
+      if (p_begin + lane < p_end) pr = t_pairs[p_begin + lane];      // first 64 pairs
+      const int2 rinfo_cur = rinfo;
+      if (s + NBUF < nsteps) rinfo = row_records(s + NBUF);          // next step's records: in flight from here on
+      const unsigned long long t2 = CC_T();
+      if (use > 0) CC_WAIT(done[w4], >= CC_CONSUMERS * use);         // the consumers are done with this buffer
+      const unsigned long long t3 = CC_T();
+      if (lane < HSUB) rowmap[w4 * SUB + hf * HSUB + lane] = lane < cnt ? rinfo_cur.x : TN;     // padding rows -> the dummy row
+      int cur = 0;
+      int next_begin = __builtin_amdgcn_readlane(rinfo_cur.y, 1);
+      f2 acc = {0.f, 0.f};
+      auto flush = [&]() {                                           // row `cur` is complete
+        *reinterpret_cast<f2*>(a_dst + cur * LDA + 2 * lane) = live ? acc : f2{0.f, 0.f};
+        acc = f2{0.f, 0.f};
+        ++cur;
+        next_begin = __builtin_amdgcn_readlane(rinfo_cur.y, cur + 1);
+      };
+      for (int base = p_begin; base < p_end; base += 64) {
+        int2 pr_next = make_int2(0, 0);
+        if (base + 64 + lane < p_end) pr_next = t_pairs[base + 64 + lane];
+        const int here = min(64, p_end - base);
+        const unsigned roff = (unsigned)pr.x * ldb;                  // byte offset of each pair's feature row
+        f2 fa[PB], fb[PB];
+        auto issue = [&](f2* f, int first) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                      // four feature rows in flight
-          const int i = min(i0 + u, here - 1);
-          const int c = __builtin_amdgcn_readlane(pr.x, i);
-          w[u] = __int_as_float(__builtin_amdgcn_readlane(pr.y, i));
-          f[u] = live ? *reinterpret_cast<const f2*>(f_lane + (size_t)c * ldf) : f2{0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (i0 + u >= here) break;
-          if (base + i0 + u == next_begin) {               // row boundary (wave-uniform)
-            *reinterpret_cast<f2*>(a_dst + cur * LDA + 2 * lane) = acc;
-            acc = f2{0.f, 0.f};
-            ++cur;
-            next_begin = __builtin_amdgcn_readlane(rinfo.y, min(cur + 1, 63));
+          for (int u = 0; u < PB; ++u) {
+            const char* rowp = fbytes + (unsigned)__builtin_amdgcn_readlane((int)roff, first + u);
+            f[u] = (ABL == 1) ? f2{1.f, 1.f} : *reinterpret_cast<const f2*>(rowp + lane8);
           }
-          acc.x = fmaf(w[u], f[u].x, acc.x);
-          acc.y = fmaf(w[u], f[u].y, acc.y);
+        };
+        auto sum = [&](const f2* f, int first) {
+#pragma unroll
+          for (int u = 0; u < PB; ++u) {
+            if (base + first + u == next_begin) flush();             // wave-uniform
+            const float w = __int_as_float(__builtin_amdgcn_readlane(pr.y, first + u));
+            acc = __builtin_elementwise_fma(f2{w, w}, f[u], acc);
+          }
+        };
+        int i = 0;
+        if (here >= PB) {
+          issue(fa, 0);
+          for (;;) {
+            bool more = i + 2 * PB <= here;
+            if (more) issue(fb, i + PB);
+            sum(fa, i);
+            i += PB;
+            if (!more) break;
+            more = i + 2 * PB <= here;
+            if (more) issue(fa, i + PB);
+            sum(fb, i);
+            i += PB;
+            if (!more) break;
+          }
         }
+        for (; i < here; ++i) {                                      // the chunk's last < 16 pairs
+          const char* rowp = fbytes + (unsigned)__builtin_amdgcn_readlane((int)roff, i);
+          const f2 f = (ABL == 1) ? f2{1.f, 1.f} : *reinterpret_cast<const f2*>(rowp + lane8);
+          if (base + i == next_begin) flush();
+          const float w = __int_as_float(__builtin_amdgcn_readlane(pr.y, i));
+          acc = __builtin_elementwise_fma(f2{w, w}, f, acc);
+        }
+        pr = pr_next;
+      }
+      if (cnt > 0) *reinterpret_cast<f2*>(a_dst + cur * LDA + 2 * lane) = live ? acc : f2{0.f, 0.f};
+      CC_RELEASE_FENCE();
+      if (lane == 0) __hip_atomic_fetch_add(&full[w4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // both halves -> 2 (use + 1)
+      if (ABL == 5) {
+        const unsigned long long t4 = CC_T();
+        tp[0] += t1 - t0; tp[1] += t2 - t1; tp[2] += t3 - t2; tp[3] += t4 - t3; tp[4] += (unsigned long long)(p_end - p_begin); tp[5] += 1;
       }
     }
-    *reinterpret_cast<f2*>(a_dst + cur * LDA + 2 * lane) = acc;
-  };
-
-  // ---- consumer state
-  f4 bfrag[16];
-  auto load_b = [&](int cell) {
-    const f4* src = filt + (((size_t)cell * colblocks + cb) * kq_count) * 64 + lane;
+    if (ABL == 5 && lane == 0) {
+      const size_t wg = (size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y;
+      for (int q = 0; q < 6; ++q) cc_dbg[(wg * 16 + wave) * 8 + q] = tp[q];
+    }
+  } else {
+    // ---------------- consumer: 16 output columns, all steps in order
+    // Two consumer waves share a SIMD (waves w and w + 4): while one scatters its results or waits on a flag,
+    // the other's MFMAs keep the matrix pipe busy. Each wave multiplies the step's 32 packed rows (two 16-row
+    // tiles = two independent accumulator chains) by its 16 columns of the cell's filter with
+    // v_mfma_f32_16x16x4_f32; the fragment (I/16 dwordx4 per lane) sits in registers, the next cell's is fetched
+    // into a second set while this one multiplies (the two sets alternate: no copies).
+    // (With ONE consumer wave per SIMD on 32 columns, 32x32x2 MFMA, a step took 6500 cycles against 4096 of
+    // matrix work: the scatter and the flag handling of that one wave were all lost matrix time.)
+    const int cw = wave;                                   // 0..7
+    const int cb = blockIdx.z * CC_CONSUMERS + cw;         // 16-column block of the output
+    const bool has_cols = cb < colblocks;
+    f4 bf0[KG], bf1[KG];
+    auto load_b = [&](f4* dstv, int cell) {
+      const f4* src = filt + (((size_t)cell * colblocks + cb) * kq_count) * 64 + lane;
 #pragma unroll
-    for (int kq = 0; kq < 16; ++kq)
-      if (kq < kq_count) bfrag[kq] = src[(size_t)kq * 64];
-  };
-  auto consume = [&](int buf) {
-    f16v acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* a_base = a_buf + (buf * SUB + (lane & 31)) * LDA + (lane >> 5) * 4;
-#pragma unroll
-    for (int kq = 0; kq < 16; ++kq) {
-      if (kq < kq_count) {
-        const f4 a = *reinterpret_cast<const f4*>(a_base + kq * 8);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], bfrag[kq][c], acc, 0, 0, 0);
+      for (int g = 0; g < KG; ++g) dstv[g] = (g < kq_count) ? src[(size_t)g * 64] : f4{0.f, 0.f, 0.f, 0.f};
+    };
+    int cur_j = -1, par = 1;
+    if (has_cols && nsteps > 0) load_b(bf0, s_cell[0]);
+    float* o_col = out_acc + cw * 16 + (lane & 15);
+    unsigned long long tc[6] = {0, 0, 0, 0, 0, 0};
+#define CC_STEP(BC)                                                                                          \
+    {                                                                                                        \
+      f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};                                          \
+      const float* a_base = a_buf + (b * SUB + (lane & 15)) * LDA + (lane >> 4) * 4;                         \
+      _Pragma("unroll") for (int g = 0; g < KG; ++g) {                                                       \
+        const f4 a0 = *reinterpret_cast<const f4*>(a_base + g * 16);                                         \
+        const f4 a1 = *reinterpret_cast<const f4*>(a_base + 16 * LDA + g * 16);                              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
+          if (ABL != 2) {                                                                                    \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], BC[g][j], acc0, 0, 0, 0);                     \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], BC[g][j], acc1, 0, 0, 0);                     \
+          } else { acc0[j] += a0[j] * BC[g][j]; acc1[j] += a1[j] * BC[g][j]; }                               \
+        }                                                                                                    \
+      }                                                                                                      \
+      /* C row = 4 (lane >> 4) + reg (+ 16 for the second tile), column = lane & 15 -> node of the tile */  \
+      const int4 n0v = *reinterpret_cast<const int4*>(rowmap + b * SUB + 4 * (lane >> 4));                   \
+      const int4 n1v = *reinterpret_cast<const int4*>(rowmap + b * SUB + 16 + 4 * (lane >> 4));              \
+      /* the buffer can go back to its producer: A and the row map are in registers */                      \
+      CC_RELEASE_FENCE();                                                                                    \
+      if (lane == 0) __hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    \
+      const int nd[8] = {n0v.x, n0v.y, n0v.z, n0v.w, n1v.x, n1v.y, n1v.z, n1v.w};                            \
+      float old[8];                                                                                          \
+      _Pragma("unroll") for (int r = 0; r < 8; ++r) old[r] = o_col[nd[r] * 128];                             \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) o_col[nd[r] * 128] = old[r] + acc0[r];                   \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) o_col[nd[4 + r] * 128] = old[4 + r] + acc1[r];           \
+    }
+    for (int s = 0; s < nsteps; ++s) {
+      const unsigned long long t0 = CC_T();
+      const int b = s & (NBUF - 1), use = s / NBUF;
+      const int j = st_cell[s];
+      if (has_cols && j != cur_j) {                        // new cell: switch to the prefetched set, fetch the next
+        cur_j = j;
+        par ^= 1;
+        if (j + 1 < s_ncell) { if (par) load_b(bf0, s_cell[j + 1]); else load_b(bf1, s_cell[j + 1]); }
+      }
+      const unsigned long long t1 = CC_T();
+      CC_WAIT(full[b], == 2 * (use + 1));
+      const unsigned long long t2 = CC_T();
+      if (has_cols) {
+        if (par) CC_STEP(bf1) else CC_STEP(bf0)
+        if (ABL == 5) {
+          const unsigned long long t4 = CC_T();
+          tc[0] += t1 - t0; tc[1] += t2 - t1; tc[2] += t4 - t2; tc[5] += 1;
+        }
+      } else if (lane == 0) {
+        __hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
-    // scatter-add: C row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column = lane & 31; packed row -> node of the tile.
-    // Within a step the rows are distinct nodes and every column block belongs to one wave: plain
-    // read-modify-write by the owner, no cross-wave race.
-    const int* rm = rowmap + buf * SUB + 4 * (lane >> 5);
-    float* o_col = out_acc + w4 * 32 + (lane & 31);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int node = rm[(r & 3) + 8 * (r >> 2)];
-      if (node >= 0) o_col[node * 128] += acc[r];
+#undef CC_STEP
+    if (ABL == 5 && lane == 0) {
+      const size_t wg = (size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y;
+      for (int q = 0; q < 6; ++q) cc_dbg[(wg * 16 + wave) * 8 + q] = tc[q];
     }
-  };
-
-  // ---- the step pipeline: producers run one step ahead of the consumers
-  int pj = 0, psub = 0;                                    // producer iterator (next step to fill)
-  if (producer && ncell > 0) produce(0, 0, 0);
-  auto advance = [&](int& j, int& sub) {
-    if ((sub + 1) * SUB < s_nrows[j]) ++sub; else { ++j; sub = 0; }
-  };
-  if (ncell > 0) advance(pj, psub);
-  __syncthreads();
-  int buf = 0, cur_cell = -1;
-  for (int j = 0, sub = 0; j < ncell; advance(j, sub)) {
-    if (producer) {
-      if (pj < ncell) produce(pj, psub, buf ^ 1);
-    } else if (has_cols) {
-      if (s_cell[j] != cur_cell) { cur_cell = s_cell[j]; load_b(cur_cell); }
-      consume(buf);
-    }
-    if (pj < ncell) advance(pj, psub);
-    __syncthreads();
-    buf ^= 1;
   }
+  __syncthreads();
+  const unsigned long long tw2 = (ABL == 5) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   // ---- write the tile's partial sums for this cell chunk: partial[chunk][node][column]
   float* dst = partial + ((size_t)blockIdx.y * n + n0) * O;
   const int col0 = blockIdx.z * 128;
   const int n_here = min(TN, n - n0), cols = min(128, O - col0);
-  for (int i = tid; i < n_here * 128; i += 512) {
+  for (int i = tid; i < n_here * 128; i += CC_THREADS) {
     const int nl = i >> 7, c = i & 127;
     if (c < cols) dst[(size_t)nl * O + col0 + c] = out_acc[nl * 128 + c];
+  }
+  if (ABL == 5 && tid == 0) {
+    const size_t wg = (size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y;
+    cc_dbg2[wg * 8 + 0] = tw0; cc_dbg2[wg * 8 + 1] = tw1; cc_dbg2[wg * 8 + 2] = tw2;
+    cc_dbg2[wg * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    cc_dbg2[wg * 8 + 4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
+    cc_dbg2[wg * 8 + 5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+    cc_dbg2[wg * 8 + 6] = (unsigned long long)nsteps;
   }
 }
 
@@ -384,6 +567,14 @@ FusedPlan plan_fused(int n, int n_cells, int O) {
 
 extern "C" {
 
+int nbd_debug_cc_read2(unsigned long long* host_out, int count) {     // TEMPORARY
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cc_dbg2), (size_t)count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+
+int nbd_debug_cc_read(unsigned long long* host_out, int count) {     // TEMPORARY
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cc_dbg), (size_t)count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+
 int nbd_contconv_fused_supported(int in_channels, int out_channels, int n_cells) {
   return in_channels > 0 && in_channels % 4 == 0 && in_channels <= 128 && out_channels > 0 && n_cells > 0 &&
          n_cells <= MAXC;
@@ -408,27 +599,47 @@ static void split_pairs_buffer(void* buf, int n, int64_t edge_capacity, int n_ce
   *pairs = reinterpret_cast<int2*>(p);
 }
 
+int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int* centres, int n, int64_t edge_capacity,
+                                 float radius_sq, int n_res, const int* filter_resolutions, const int* const* cell_maps,
+                                 const int* n_cells, void* const* pair_lists, const size_t* pair_lists_bytes,
+                                 nbd_stream_t stream) {
+  if (n < 0 || edge_capacity < 0 || n_res < 1 || n_res > NBD_CC_MAX_RES) return NBD_E_BADARG;
+  if (!filter_resolutions || !cell_maps || !n_cells || !pair_lists || !pair_lists_bytes) return NBD_E_BADARG;
+  if (n == 0) return 0;
+  if (!pos || !rowptr || !centres) return NBD_E_BADARG;
+  PairJobs jobs;
+  int kc_max = 0;
+  for (int r = 0; r < n_res; ++r) {
+    const int d = filter_resolutions[r], nc = n_cells[r];
+    if (d < 2 || d > 6 || nc <= 0 || nc > MAXC || nc > d * d * d) return NBD_E_BADARG;
+    if (!cell_maps[r] && nc != d * d * d) return NBD_E_BADARG;
+    if (!pair_lists[r] || (reinterpret_cast<uintptr_t>(pair_lists[r]) & 15) != 0) return NBD_E_BADARG;
+    if (pair_lists_bytes[r] < nbd_contconv_pairs_bytes(n, edge_capacity, nc)) return NBD_E_WORKSPACE;
+    PairJob& j = jobs.j[r];
+    j.D = d; j.n_cells = nc; j.cell_map = cell_maps[r];
+    split_pairs_buffer(pair_lists[r], n, edge_capacity, nc, &j.desc, &j.rows, &j.pairs);
+    const int kc = (nc + 3) & ~3;
+    if (kc > kc_max) kc_max = kc;
+  }
+  for (int r = n_res; r < NBD_CC_MAX_RES; ++r) jobs.j[r] = jobs.j[0];
+  const size_t lds = (size_t)TN * kc_max / 2 * 4 + (size_t)TN * kc_max * 4 + (size_t)TN * kc_max;
+  {   // > 64 KiB of dynamic LDS needs the opt-in (a per-function attribute, idempotent)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(contconv_pairs_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    if (e != hipSuccess) return (int)e;
+  }
+  contconv_pairs_kernel<<<dim3(ceil_div(n, TN), n_res), PAIR_THREADS, lds, (hipStream_t)stream>>>(
+      pos, rowptr, centres, n, radius_sq, jobs);
+  return status();
+}
+
 int nbd_contconv_pairs_f32(const float* pos, const int* rowptr, const int* centres, int n, int64_t edge_capacity,
                            int filter_resolution, float radius_sq, const int* cell_map, int n_cells,
                            void* pair_lists, size_t pair_lists_bytes, nbd_stream_t stream) {
-  if (n < 0 || edge_capacity < 0 || filter_resolution < 2 || n_cells <= 0 || n_cells > MAXC) return NBD_E_BADARG;
-  if (n == 0) return 0;
-  if (!pos || !rowptr || !centres || !pair_lists) return NBD_E_BADARG;
-  if ((reinterpret_cast<uintptr_t>(pair_lists) & 15) != 0) return NBD_E_BADARG;
-  if (pair_lists_bytes < nbd_contconv_pairs_bytes(n, edge_capacity, n_cells)) return NBD_E_WORKSPACE;
-  if (!cell_map && n_cells != filter_resolution * filter_resolution * filter_resolution) return NBD_E_BADARG;
-  int2 *desc, *rows, *pairs;
-  split_pairs_buffer(pair_lists, n, edge_capacity, n_cells, &desc, &rows, &pairs);
-  const int kc = (n_cells + 3) & ~3;
-  const size_t lds = (size_t)TN * kc / 2 * 4 + (size_t)TN * kc * 4 + (size_t)TN * kc;
-  {   // > 64 KiB of dynamic LDS needs the opt-in (a per-function attribute, idempotent)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(contconv_pairs_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return (int)e;
-  }
-  contconv_pairs_kernel<<<ceil_div(n, TN), 512, lds, (hipStream_t)stream>>>(
-      pos, rowptr, centres, n, filter_resolution, radius_sq, cell_map, n_cells, desc, rows, pairs);
-  return status();
+  const int* maps[1] = {cell_map};
+  void* lists[1] = {pair_lists};
+  return nbd_contconv_pairs_batch_f32(pos, rowptr, centres, n, edge_capacity, radius_sq, 1, &filter_resolution, maps,
+                                      &n_cells, lists, &pair_lists_bytes, stream);
 }
 
 size_t nbd_contconv_fused_workspace_bytes(int n, int n_cells, int out_channels) {
@@ -439,7 +650,7 @@ size_t nbd_contconv_fused_workspace_bytes(int n, int n_cells, int out_channels) 
 
 size_t nbd_contconv_filter_floats(int in_channels, int out_channels, int n_cells) {
   if (in_channels <= 0 || out_channels <= 0 || n_cells <= 0) return 0;
-  return (size_t)n_cells * ceil_div(out_channels, 32) * ceil_div(in_channels, 8) * 64 * 4;
+  return (size_t)n_cells * ceil_div(out_channels, 16) * ceil_div(in_channels, 16) * 64 * 4;
 }
 
 int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const int* rowptr, int n, int64_t edge_capacity,
@@ -457,16 +668,28 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
   int2 *desc, *rows, *pairs;
   split_pairs_buffer(const_cast<void*>(pair_lists), n, edge_capacity, n_cells, &desc, &rows, &pairs);
   const FusedPlan p = plan_fused(n, n_cells, out_channels);
-  const size_t lds = (size_t)(TN * 128 + 2 * SUB * LDA) * sizeof(float) + 2 * SUB * sizeof(int);
-  {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(contconv_fused_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return (int)e;
-  }
+  const size_t lds = (size_t)((TN + 1) * 128 + NBUF * SUB * LDA) * sizeof(float) + NBUF * SUB * sizeof(int);
   float* partial = static_cast<float*>(workspace);
-  contconv_fused_kernel<<<dim3(p.tiles, p.chunks, p.colgroups), 512, lds, st>>>(
-      feat, ldf, in_channels, rowptr, n, desc, rows, pairs, reinterpret_cast<const f4*>(filters_shuffled), n_cells,
-      ceil_div(in_channels, 8), ceil_div(out_channels, 32), p.cells_per_chunk, out_channels, partial);
+  const char* abl_s = getenv("NBD_CC_ABLATE");        // TEMPORARY measurement switch
+  const int abl = abl_s ? atoi(abl_s) : 0;
+  const dim3 grid(p.tiles, p.chunks, p.colgroups);
+  const int kq_count = ceil_div(in_channels, 16);
+#define CC_LAUNCH(A, K)                                                                                             \
+  do {                                                                                                              \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(contconv_fused_kernel<A, K>),                  \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                     \
+    if (e != hipSuccess) return (int)e;                                                                             \
+    contconv_fused_kernel<A, K><<<grid, CC_THREADS, lds, st>>>(feat, ldf, in_channels, rowptr, n, desc, rows, pairs,       \
+                                                       reinterpret_cast<const f4*>(filters_shuffled), n_cells,     \
+                                                       kq_count, ceil_div(out_channels, 16), p.cells_per_chunk,    \
+                                                       out_channels, partial);                                     \
+  } while (0)
+  if (kq_count <= 2) CC_LAUNCH(0, 2);
+  else if (abl == 1) CC_LAUNCH(1, 8);
+  else if (abl == 2) CC_LAUNCH(2, 8);
+  else if (abl == 5) CC_LAUNCH(5, 8);
+  else CC_LAUNCH(0, 8);
+#undef CC_LAUNCH
   int rc = status();
   if (rc) return rc;
   const size_t total = (size_t)n * out_channels;

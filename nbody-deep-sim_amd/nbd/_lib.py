@@ -118,6 +118,9 @@ SIGNATURES = {
     "nbd_contconv_pairs_bytes": (c_size_t, [c_int, c_int64, c_int]),
     "nbd_contconv_pairs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_int,
                                        c_void_p, c_size_t, c_void_p]),
+    "nbd_contconv_pairs_batch_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_float, c_int, POINTER(c_int),
+                                             POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), POINTER(c_size_t),
+                                             c_void_p]),
     "nbd_contconv_fused_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "nbd_contconv_filter_floats": (c_size_t, [c_int, c_int, c_int]),
     "nbd_contconv_fused_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_int,

@@ -167,16 +167,17 @@ def contconv_fused_supported(i_ch: int, o_ch: int, n_cells: int) -> bool:
 
 def contconv_shuffle_filters(filters: torch.Tensor, cells: torch.Tensor) -> torch.Tensor:
     """filters (D,D,D,I,O) -> the MFMA fragment order nbd_contconv_fused_f32 reads (see include/nbd.h):
-    [cell (the kept ones)][32-column block][8-k block][lane][4], lane = 32 * (k % 8 >= 4) + column % 32,
-    zero padded to I % 8 == 0 and O % 32 == 0. A layout transform of the weights: done once per weight update."""
+    [cell (the kept ones)][16-column block][16-k block][lane][4], lane = 16 * ((k % 16) // 4) + column % 16,
+    element = k % 4, zero padded to I % 16 == 0 and O % 16 == 0. A layout transform of the weights: done once
+    per weight update."""
     d, i_ch, o_ch = filters.shape[0], filters.shape[3], filters.shape[4]
     k = int(cells.numel())
     f = filters.detach().reshape(d * d * d, i_ch, o_ch).index_select(0, cells)
-    ip, op = (i_ch + 7) // 8 * 8, (o_ch + 31) // 32 * 32
+    ip, op = (i_ch + 15) // 16 * 16, (o_ch + 15) // 16 * 16
     if ip != i_ch or op != o_ch:
         f = torch.nn.functional.pad(f, (0, op - o_ch, 0, ip - i_ch))
-    f = f.reshape(k, ip // 8, 2, 4, op // 32, 32)              # [cell][kq][kb][c][cb][n]
-    f = f.permute(0, 4, 1, 2, 5, 3).contiguous()              # [cell][cb][kq][kb][n][c]
+    f = f.reshape(k, ip // 16, 4, 4, op // 16, 16)            # [cell][g][kb][j][cb][n]
+    f = f.permute(0, 4, 1, 2, 5, 3).contiguous()              # [cell][cb][g][kb][n][j]
     return f.reshape(-1)
 
 
@@ -199,6 +200,36 @@ def contconv_pairs(pos, rowptr, centres, edge_capacity: int, d: int, radius_sq: 
                                             int(d), float(radius_sq), _lib.ptr(cell_map), int(n_cells), buf.data_ptr(),
                                             buf.numel(), _lib.current_stream(pos.device)), "nbd_contconv_pairs_f32")
     return buf, int(edge_capacity)
+
+
+def contconv_pairs_batch(pos, rowptr, centres, edge_capacity: int, radius_sq: float, jobs):
+    """Pair lists of several filter resolutions of one graph in ONE launch. jobs: list of (d, cell_map, n_cells);
+    returns a list of (buffer, edge_capacity) in the same order."""
+    import ctypes
+    n = pos.shape[0]
+    if pos.shape != (n, 3) or pos.dtype != torch.float32 or not pos.is_contiguous():
+        raise _lib.NbdError("pos must be contiguous fp32 (n,3)")
+    if rowptr.dtype != torch.int32 or rowptr.numel() != n + 1 or centres.dtype != torch.int32:
+        raise _lib.NbdError("rowptr int32 [n+1] / centres int32 required")
+    edge_capacity = max(int(edge_capacity), centres.numel())
+    L = _lib.lib()
+    k = len(jobs)
+    bufs = []
+    for d, cmap, nc in jobs:
+        if cmap is not None and (cmap.dtype != torch.int32 or cmap.numel() != d * d * d or not cmap.is_cuda):
+            raise _lib.NbdError("cell_map must be an int32 CUDA tensor of d^3 entries")
+        bufs.append(torch.empty(max(L.nbd_contconv_pairs_bytes(n, edge_capacity, int(nc)), 16), dtype=torch.uint8,
+                                device=pos.device))
+    ds = (ctypes.c_int * k)(*[int(j[0]) for j in jobs])
+    maps = (ctypes.c_void_p * k)(*[_lib.ptr(j[1]) for j in jobs])
+    ncs = (ctypes.c_int * k)(*[int(j[2]) for j in jobs])
+    ptrs = (ctypes.c_void_p * k)(*[b.data_ptr() for b in bufs])
+    sizes = (ctypes.c_size_t * k)(*[b.numel() for b in bufs])
+    with _lib.on_device(pos.device):
+        _lib.check(L.nbd_contconv_pairs_batch_f32(pos.data_ptr(), rowptr.data_ptr(), centres.data_ptr(), n, edge_capacity,
+                                                  float(radius_sq), k, ds, maps, ncs, ptrs, sizes,
+                                                  _lib.current_stream(pos.device)), "nbd_contconv_pairs_batch_f32")
+    return [(b, edge_capacity) for b in bufs]
 
 
 def contconv_fused(feat, rowptr, pair_buf, edge_capacity: int, filt_shuffled, n_cells: int, o_ch: int, rowscale=None,

@@ -1,0 +1,70 @@
+"""ContinuousConv layer timings at BASELINE configs[3] (N = 16 384, mean radius-1 degree 32, 128 -> 128 channels,
+D = 6 and D = 4): pair lists, fused block-sparse layer, and the round-1 formulation (dense binned matrix + GEMM)
+on the same graph. HIP events, one JSON line.   python tools/bench_contconv.py [iters]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (os.path.join(ROOT, "nbody-deep-sim_amd"), ROOT):
+    sys.path.insert(0, _p)
+import numpy as np
+import torch
+import contconv
+from nbd import graphops, nnops
+from nbd.plummer import generate_plummer
+
+SCALE = 4.599349753792708
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    n, c = 16384, 128
+    p, v, m = generate_plummer(n, seed=1234)
+    pos = torch.tensor(p * SCALE, dtype=torch.float32, device="cuda")
+    torch.manual_seed(0)
+    feat = torch.randn(n, c, device="cuda")
+    lists = graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32)
+    edges = int(lists.rowptr[-1])
+    out = {"n": n, "edges": edges, "channels": c}
+    for d in (6, 4):
+        layer = contconv.ContinuousConv(c, c, d, radius=1.0, agg="mean").cuda()
+        _, cmap, n_cells = layer.cells()
+        r2 = float(np.float32(1.0))
+        wf, wt = layer.weight_fused(), layer.weight_t()
+        pairs = nnops.contconv_pairs(pos, lists.rowptr, lists.centres, lists.centres.numel(), d, r2, cmap, n_cells)
+        with torch.no_grad():
+            t_pairs = timeit(lambda: nnops.contconv_pairs(pos, lists.rowptr, lists.centres, lists.centres.numel(), d, r2,
+                                                          cmap, n_cells), iters)
+            t_fused = timeit(lambda: layer(pos, feat, lists=lists, act="tanh", wt=wf, pairs=pairs), iters)
+            y_f = layer(pos, feat, lists=lists, act="tanh", wt=wf, pairs=pairs)
+            layer.use_fused = False
+            t_old = timeit(lambda: layer(pos, feat, lists=lists, act="tanh", wt=wt), max(iters // 4, 3))
+            y_o = layer(pos, feat, lists=lists, act="tanh", wt=wt)
+        out[f"D{d}"] = {"cells": n_cells, "pairs_ms": t_pairs, "fused_layer_ms": t_fused, "binned_gemm_layer_ms": t_old,
+                        "fused_vs_binned_max_abs_diff": float((y_f - y_o).abs().max())}
+    jobs = []
+    for d in (6, 4):
+        layer = contconv.ContinuousConv(c, c, d, radius=1.0, agg="mean").cuda()
+        _, cmap, n_cells = layer.cells()
+        jobs.append((d, cmap, n_cells))
+    out["pairs_both_resolutions_one_launch_ms"] = timeit(
+        lambda: nnops.contconv_pairs_batch(pos, lists.rowptr, lists.centres, lists.centres.numel(), 1.0, jobs), iters)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

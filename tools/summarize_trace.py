@@ -3,6 +3,7 @@ in microseconds. The launches of one kernel at different grids (the local and th
 separate.   python tools/summarize_trace.py <..._kernel_trace.csv> [out.json]"""
 import csv
 import json
+import re
 import statistics
 import sys
 from collections import defaultdict
@@ -13,7 +14,8 @@ def main():
     with open(sys.argv[1], newline="") as f:
         for r in csv.DictReader(f):
             name = r.get("Kernel_Name") or r.get("kernel_name")
-            name = name.split("(")[0][-60:]
+            m = re.search(r"(\w+)(<[^(]*>)?\(", name)          # function name + template arguments, no namespaces
+            name = ((m.group(1) + (m.group(2) or "")) if m else name)[:72]
             grid = "x".join(r.get(k, "?") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
             wg = r.get("Workgroup_Size_X", "?")
             dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
@@ -29,7 +31,7 @@ def main():
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(text)
     for o in out[:25]:
-        print(f'{o["kernel"][-48:]:48s} grid {o["grid_threads"]:>14s} n={o["launches"]:5d} mean {o["mean_us"]:9.2f} '
+        print(f'{o["kernel"][:56]:56s} grid {o["grid_threads"]:>14s} n={o["launches"]:5d} mean {o["mean_us"]:9.2f} '
               f'p50 {o["p50_us"]:9.2f} min {o["min_us"]:9.2f} us')
 
 
