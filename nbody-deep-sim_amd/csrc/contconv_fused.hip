@@ -10,21 +10,26 @@
 // dense product `A (N x D^3 I) . F` of round 1 multiplied ~80 % zeros and moved a 1.3 GB A through HBM.
 // Here A never leaves the chip and only touched blocks are multiplied:
 //
-//   nbd_contconv_pairs_f32   per tile of 128 nodes: every (edge, corner) pair {source, weight}, grouped by
-//                            (cell, node) -- a counting sort held in LDS; the packed "rows" (distinct nodes) of
-//                            each (tile, cell) and their pair ranges. ~24 B per pair of index data, once per
-//                            filter resolution and graph.
-//   nbd_contconv_fused_f32   per (tile, chunk of cells): producer waves gather the pairs' feature rows and
-//                            sum them into packed A rows in LDS (32 rows per step, double-buffered);
-//                            consumer waves multiply each step by the cell's I x O filter with fp32 MFMA
-//                            (v_mfma_f32_32x32x2_f32; the filter fragment is held in registers, pre-shuffled
-//                            by the host so that every lane loads it with one dwordx4 per 8 k) and scatter-add
-//                            the 32 x 128 result into a 128-node x 128-column accumulator in LDS.
-//                            Cell chunks of one tile are summed in fixed order by the finishing kernel
-//                            (scale, activation). No float atomics across waves: deterministic.
+//   nbd_contconv_pairs_batch_f32   per (tile of 128 nodes, filter resolution): every (edge, corner) pair
+//                            {source, weight}, grouped by (cell, node) -- a counting sort held in LDS; the packed
+//                            "rows" (distinct nodes) of each (tile, cell) and their pair ranges. ~24 B of index
+//                            data per pair, once per graph; all resolutions of a model in one launch (60 us at the
+//                            published shape for D = 6 and D = 4 together).
+//   nbd_contconv_fused_f32   per (tile, chunk of cells), 16 waves: eight producer waves gather the pairs' feature
+//                            rows and sum them into packed A rows in LDS (32 rows per step, a ring of four
+//                            buffers, two waves per buffer); eight consumer waves multiply each step by 16 columns
+//                            of the cell's I x O filter with fp32 MFMA (v_mfma_f32_16x16x4_f32; the fragment sits in
+//                            registers, pre-shuffled by the host so that every lane loads it with one dwordx4 per 16
+//                            k, the next cell's being fetched meanwhile) and add the 32 x 16 result into a
+//                            128-node x 128-column accumulator in LDS. Producers and consumers meet through LDS
+//                            flags only (no workgroup barrier inside the loop). Cell chunks of one tile are
+//                            summed in fixed order by the finishing kernel (scale, activation). No float atomics:
+//                            deterministic.
+// Measured at the published shape (tools/bench_contconv.py, profiles/r02_contconv_*): layer D = 6 0.52 ms, D = 4
+// 0.35 ms against 1.09 / 0.54 ms for binning + dense GEMM; executed 53.7 GFLOP per step (32-row granularity; the
+// touched blocks alone are 38.1) against 120; the binned matrix: 0 bytes of HBM traffic against 2.7 GB.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "../../include/nbd.h"
 
@@ -272,11 +277,7 @@ constexpr int MAX_STEPS = CHUNK_MAX * (TN / SUB);
   } while (0)
 #define CC_RELEASE_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 
-__device__ unsigned long long cc_dbg[4096 * 16 * 8];
-__device__ unsigned long long cc_dbg2[4096 * 8];      // TEMPORARY: per workgroup {t_start, t_setup, t_loop_end, t_end, hw_id, xcc}     // TEMPORARY: per (workgroup, wave) phase cycle totals (ABL == 5)
-#define CC_T() (ABL == 5 ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
-
-template <int ABL, int KG>
+template <int KG>
 __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
     const float* __restrict__ feat, int ldf, int I, const int* __restrict__ rowptr, int n,
     const int2* __restrict__ desc, const int2* __restrict__ rows, const int2* __restrict__ pairs,
@@ -296,7 +297,6 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
   __shared__ int full[NBUF], done[NBUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned long long tw0 = (ABL == 5) ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const int tile = blockIdx.x, n0 = tile * TN;
   const int k_begin = blockIdx.y * cells_per_chunk, k_end = min(n_cells, k_begin + cells_per_chunk);
   const int e_t = rowptr[n0];
@@ -328,7 +328,6 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
   for (int i = tid; i < (TN + 1) * 128 / 4; i += CC_THREADS) reinterpret_cast<f4*>(out_acc)[i] = f4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   const int nsteps = s_nsteps;
-  const unsigned long long tw1 = (ABL == 5) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   if (wave >= CC_CONSUMERS) {
     const int w4 = (wave - CC_CONSUMERS) & (NBUF - 1);    // ring buffer this wave fills
@@ -356,19 +355,14 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
     };
     int2 rinfo = make_int2(-1, 0);
     if (w4 < nsteps) rinfo = row_records(w4);
-    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0};
     for (int s = w4, use = 0; s < nsteps; s += NBUF, ++use) {
-      const unsigned long long t0 = CC_T();
       const int cnt = max(0, min(HSUB, s_nrows[st_cell[s]] - st_sub[s] * SUB - hf * HSUB));
       const int p_begin = __builtin_amdgcn_readlane(rinfo.y, 0), p_end = __builtin_amdgcn_readlane(rinfo.y, cnt);
-      const unsigned long long t1 = CC_T();
       int2 pr = make_int2(0, 0);
       if (p_begin + lane < p_end) pr = t_pairs[p_begin + lane];      // first 64 pairs
       const int2 rinfo_cur = rinfo;
       if (s + NBUF < nsteps) rinfo = row_records(s + NBUF);          // next step's records: in flight from here on
-      const unsigned long long t2 = CC_T();
       if (use > 0) CC_WAIT(done[w4], >= CC_CONSUMERS * use);         // the consumers are done with this buffer
-      const unsigned long long t3 = CC_T();
       if (lane < HSUB) rowmap[w4 * SUB + hf * HSUB + lane] = lane < cnt ? rinfo_cur.x : TN;     // padding rows -> the dummy row
       int cur = 0;
       int next_begin = __builtin_amdgcn_readlane(rinfo_cur.y, 1);
@@ -389,7 +383,7 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
 #pragma unroll
           for (int u = 0; u < PB; ++u) {
             const char* rowp = fbytes + (unsigned)__builtin_amdgcn_readlane((int)roff, first + u);
-            f[u] = (ABL == 1) ? f2{1.f, 1.f} : *reinterpret_cast<const f2*>(rowp + lane8);
+            f[u] = *reinterpret_cast<const f2*>(rowp + lane8);
           }
         };
         auto sum = [&](const f2* f, int first) {
@@ -418,7 +412,7 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
         }
         for (; i < here; ++i) {                                      // the chunk's last < 16 pairs
           const char* rowp = fbytes + (unsigned)__builtin_amdgcn_readlane((int)roff, i);
-          const f2 f = (ABL == 1) ? f2{1.f, 1.f} : *reinterpret_cast<const f2*>(rowp + lane8);
+          const f2 f = *reinterpret_cast<const f2*>(rowp + lane8);
           if (base + i == next_begin) flush();
           const float w = __int_as_float(__builtin_amdgcn_readlane(pr.y, i));
           acc = __builtin_elementwise_fma(f2{w, w}, f, acc);
@@ -428,14 +422,6 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
       if (cnt > 0) *reinterpret_cast<f2*>(a_dst + cur * LDA + 2 * lane) = live ? acc : f2{0.f, 0.f};
       CC_RELEASE_FENCE();
       if (lane == 0) __hip_atomic_fetch_add(&full[w4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // both halves -> 2 (use + 1)
-      if (ABL == 5) {
-        const unsigned long long t4 = CC_T();
-        tp[0] += t1 - t0; tp[1] += t2 - t1; tp[2] += t3 - t2; tp[3] += t4 - t3; tp[4] += (unsigned long long)(p_end - p_begin); tp[5] += 1;
-      }
-    }
-    if (ABL == 5 && lane == 0) {
-      const size_t wg = (size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y;
-      for (int q = 0; q < 6; ++q) cc_dbg[(wg * 16 + wave) * 8 + q] = tp[q];
     }
   } else {
     // ---------------- consumer: 16 output columns, all steps in order
@@ -450,15 +436,18 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
     const int cb = blockIdx.z * CC_CONSUMERS + cw;         // 16-column block of the output
     const bool has_cols = cb < colblocks;
     f4 bf0[KG], bf1[KG];
+    // always exactly KG loads (clamped index, zeroed afterwards): a counted s_waitcnt vmcnt(KG) is only possible
+    // when the number of younger loads does not depend on the path taken
     auto load_b = [&](f4* dstv, int cell) {
-      const f4* src = filt + (((size_t)cell * colblocks + cb) * kq_count) * 64 + lane;
+      const f4* src = filt + (((size_t)cell * colblocks + min(cb, colblocks - 1)) * kq_count) * 64 + lane;
 #pragma unroll
-      for (int g = 0; g < KG; ++g) dstv[g] = (g < kq_count) ? src[(size_t)g * 64] : f4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < KG; ++g) {
+        const f4 v = src[(size_t)min(g, kq_count - 1) * 64];
+        dstv[g] = (g < kq_count) ? v : f4{0.f, 0.f, 0.f, 0.f};
+      }
     };
-    int cur_j = -1, par = 1;
-    if (has_cols && nsteps > 0) load_b(bf0, s_cell[0]);
+    if (nsteps > 0) load_b(bf0, s_cell[0]);
     float* o_col = out_acc + cw * 16 + (lane & 15);
-    unsigned long long tc[6] = {0, 0, 0, 0, 0, 0};
 #define CC_STEP(BC)                                                                                          \
     {                                                                                                        \
       f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};                                          \
@@ -467,10 +456,8 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
         const f4 a0 = *reinterpret_cast<const f4*>(a_base + g * 16);                                         \
         const f4 a1 = *reinterpret_cast<const f4*>(a_base + 16 * LDA + g * 16);                              \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
-          if (ABL != 2) {                                                                                    \
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], BC[g][j], acc0, 0, 0, 0);                     \
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], BC[g][j], acc1, 0, 0, 0);                     \
-          } else { acc0[j] += a0[j] * BC[g][j]; acc1[j] += a1[j] * BC[g][j]; }                               \
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], BC[g][j], acc0, 0, 0, 0);                       \
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], BC[g][j], acc1, 0, 0, 0);                       \
         }                                                                                                    \
       }                                                                                                      \
       /* C row = 4 (lane >> 4) + reg (+ 16 for the second tile), column = lane & 15 -> node of the tile */  \
@@ -485,36 +472,45 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
       _Pragma("unroll") for (int r = 0; r < 4; ++r) o_col[nd[r] * 128] = old[r] + acc0[r];                   \
       _Pragma("unroll") for (int r = 0; r < 4; ++r) o_col[nd[4 + r] * 128] = old[4 + r] + acc1[r];           \
     }
-    for (int s = 0; s < nsteps; ++s) {
-      const unsigned long long t0 = CC_T();
-      const int b = s & (NBUF - 1), use = s / NBUF;
-      const int j = st_cell[s];
-      if (has_cols && j != cur_j) {                        // new cell: switch to the prefetched set, fetch the next
-        cur_j = j;
-        par ^= 1;
-        if (j + 1 < s_ncell) { if (par) load_b(bf0, s_cell[j + 1]); else load_b(bf1, s_cell[j + 1]); }
-      }
-      const unsigned long long t1 = CC_T();
-      CC_WAIT(full[b], == 2 * (use + 1));
-      const unsigned long long t2 = CC_T();
-      if (has_cols) {
-        if (par) CC_STEP(bf1) else CC_STEP(bf0)
-        if (ABL == 5) {
-          const unsigned long long t4 = CC_T();
-          tc[0] += t1 - t0; tc[1] += t2 - t1; tc[2] += t4 - t2; tc[5] += 1;
-        }
-      } else if (lane == 0) {
-        __hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // Cells two at a time: the even cell multiplies with fragment set 0 while set 1 is fetched for the odd cell
+    // and vice versa. Written out like this (instead of a parity switch inside one loop) the loads of the NEXT
+    // cell are the only ones younger than the current cell's, so the wait before the first MFMA is a counted
+    // vmcnt(KG) and the prefetch really stays in flight (with the switch the compiler had to use vmcnt(0):
+    // every cell change paid the full L2 / Infinity Cache latency).
+    auto cell_steps = [&](int j) { return (s_nrows[j] + SUB - 1) / SUB; };
+#define CC_ONE_STEP(BC)                                                                                      \
+    {                                                                                                        \
+      const int b = s & (NBUF - 1), use = s / NBUF;                                                          \
+      CC_WAIT(full[b], == 2 * (use + 1));                                                                    \
+      if (has_cols) CC_STEP(BC) else if (lane == 0)                                                          \
+        __hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                 \
+      ++s;                                                                                                   \
+    }
+    /* the cell's first step is peeled: its fragment wait then sits in straight-line code behind the prefetch */ \
+
+#define CC_CELL(BC)                                                                                          \
+    {                                                                                                        \
+      const int nsub = cell_steps(j);                                                                        \
+      CC_ONE_STEP(BC)                                                                                        \
+      for (int u = 1; u < nsub; ++u) CC_ONE_STEP(BC)                                                         \
+    }
+    {
+      int s = 0;
+      const int ncell = s_ncell;
+      for (int j = 0; j < ncell;) {
+        load_b(bf1, s_cell[min(j + 1, ncell - 1)]);        // the last cell re-fetches itself: never used
+        CC_CELL(bf0)
+        if (++j >= ncell) break;
+        load_b(bf0, s_cell[min(j + 1, ncell - 1)]);
+        CC_CELL(bf1)
+        ++j;
       }
     }
+#undef CC_CELL
+#undef CC_ONE_STEP
 #undef CC_STEP
-    if (ABL == 5 && lane == 0) {
-      const size_t wg = (size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y;
-      for (int q = 0; q < 6; ++q) cc_dbg[(wg * 16 + wave) * 8 + q] = tc[q];
-    }
   }
   __syncthreads();
-  const unsigned long long tw2 = (ABL == 5) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   // ---- write the tile's partial sums for this cell chunk: partial[chunk][node][column]
   float* dst = partial + ((size_t)blockIdx.y * n + n0) * O;
@@ -523,14 +519,6 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
   for (int i = tid; i < n_here * 128; i += CC_THREADS) {
     const int nl = i >> 7, c = i & 127;
     if (c < cols) dst[(size_t)nl * O + col0 + c] = out_acc[nl * 128 + c];
-  }
-  if (ABL == 5 && tid == 0) {
-    const size_t wg = (size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y;
-    cc_dbg2[wg * 8 + 0] = tw0; cc_dbg2[wg * 8 + 1] = tw1; cc_dbg2[wg * 8 + 2] = tw2;
-    cc_dbg2[wg * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-    cc_dbg2[wg * 8 + 4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID
-    cc_dbg2[wg * 8 + 5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
-    cc_dbg2[wg * 8 + 6] = (unsigned long long)nsteps;
   }
 }
 
@@ -566,14 +554,6 @@ FusedPlan plan_fused(int n, int n_cells, int O) {
 }  // namespace
 
 extern "C" {
-
-int nbd_debug_cc_read2(unsigned long long* host_out, int count) {     // TEMPORARY
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cc_dbg2), (size_t)count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
-}
-
-int nbd_debug_cc_read(unsigned long long* host_out, int count) {     // TEMPORARY
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cc_dbg), (size_t)count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
-}
 
 int nbd_contconv_fused_supported(int in_channels, int out_channels, int n_cells) {
   return in_channels > 0 && in_channels % 4 == 0 && in_channels <= 128 && out_channels > 0 && n_cells > 0 &&
@@ -670,25 +650,19 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
   const FusedPlan p = plan_fused(n, n_cells, out_channels);
   const size_t lds = (size_t)((TN + 1) * 128 + NBUF * SUB * LDA) * sizeof(float) + NBUF * SUB * sizeof(int);
   float* partial = static_cast<float*>(workspace);
-  const char* abl_s = getenv("NBD_CC_ABLATE");        // TEMPORARY measurement switch
-  const int abl = abl_s ? atoi(abl_s) : 0;
   const dim3 grid(p.tiles, p.chunks, p.colgroups);
   const int kq_count = ceil_div(in_channels, 16);
-#define CC_LAUNCH(A, K)                                                                                             \
+#define CC_LAUNCH(K)                                                                                                \
   do {                                                                                                              \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(contconv_fused_kernel<A, K>),                  \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(contconv_fused_kernel<K>),                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                     \
     if (e != hipSuccess) return (int)e;                                                                             \
-    contconv_fused_kernel<A, K><<<grid, CC_THREADS, lds, st>>>(feat, ldf, in_channels, rowptr, n, desc, rows, pairs,       \
-                                                       reinterpret_cast<const f4*>(filters_shuffled), n_cells,     \
-                                                       kq_count, ceil_div(out_channels, 16), p.cells_per_chunk,    \
-                                                       out_channels, partial);                                     \
+    contconv_fused_kernel<K><<<grid, CC_THREADS, lds, st>>>(feat, ldf, in_channels, rowptr, n, desc, rows, pairs,   \
+                                                           reinterpret_cast<const f4*>(filters_shuffled), n_cells, \
+                                                           kq_count, ceil_div(out_channels, 16), p.cells_per_chunk, \
+                                                           out_channels, partial);                                 \
   } while (0)
-  if (kq_count <= 2) CC_LAUNCH(0, 2);
-  else if (abl == 1) CC_LAUNCH(1, 8);
-  else if (abl == 2) CC_LAUNCH(2, 8);
-  else if (abl == 5) CC_LAUNCH(5, 8);
-  else CC_LAUNCH(0, 8);
+  if (kq_count <= 2) CC_LAUNCH(2); else CC_LAUNCH(8);      // K depth: I <= 32 / I <= 128
 #undef CC_LAUNCH
   int rc = status();
   if (rc) return rc;

@@ -14,6 +14,7 @@ the global arrays. See nbd/dist.py and DESIGN.md.
 """
 from __future__ import annotations
 
+import os
 import time
 from dataclasses import dataclass
 
@@ -84,14 +85,17 @@ class BaseSimulator:
         self.process_group = process_group
         self.part = nbd_dist.RangePartition(self.n, world, rank)
         lo, hi = self.part.lo, self.part.hi
-        self.positions = full_pos[lo:hi].clone() if world > 1 else full_pos
-        self.velocities = full_vel[lo:hi].clone() if world > 1 else full_vel
+        # the range-sharded code path: more than one rank, or a one-rank group with NBD_FORCE_SHARDED=1 (rehearsal
+        # of the RCCL calls, the asynchronous gather and the split force on a single GPU)
+        self._sharded = world > 1 or (process_group is not None and os.environ.get("NBD_FORCE_SHARDED") == "1")
+        self.positions = full_pos[lo:hi].clone() if self._sharded else full_pos
+        self.velocities = full_vel[lo:hi].clone() if self._sharded else full_vel
         self.accelerations = None
 
         # scratch owned by the simulator: packed sources (all ranks' bodies), slabs, energy partials
         self._posm = direct.alloc_posm(self.n, self.device)
         self._posm.zero_()
-        if world == 1:
+        if not self._sharded:
             self._ws = direct.step_workspace(max(self.n, 1), self.device)
             self._posm_local, self._mass_local, self._gather = self._posm, self.masses, None
         else:
@@ -102,14 +106,14 @@ class BaseSimulator:
             self._mass_local = self.masses[lo:hi].contiguous()
             self._ws = direct.shard_workspace(self.n, lo, self.part.n_local, self.device) \
                 if self.part.n_local else None
-            self._gather = nbd_dist.RowGather(self.part, 4, torch.float32, self.device, process_group)
+            self._gather = nbd_dist.RowGather(self.part, 4, torch.float32, self.device, process_group, collective=True)
 
         self.accelerations = self.compute_accelerations()
 
     # ------------------------------------------------------------------ force
     def _refresh_sources(self):
         """posm[:n] = {x,y,z,m} of ALL bodies in global order (one all-gather when sharded)."""
-        if self.part.world_size == 1:
+        if not self._sharded:
             direct.pack_posm(self.positions, self.masses, out=self._posm)
         else:
             self._pack_local()
@@ -140,7 +144,7 @@ class BaseSimulator:
         (simulation.py:71-89)."""
         if self.n == 0:
             return torch.zeros((0, 3), dtype=torch.float32, device=self.device)
-        if self.part.world_size == 1:
+        if not self._sharded:
             direct.pack_posm(self.positions, self.masses, out=self._posm)
             return direct.accel(self._posm, self.n, self._posm, self.n, 0, self._eps2, self._g,
                                 workspace=self._ws)
@@ -153,7 +157,7 @@ class BaseSimulator:
         if self.n == 0:
             return 0.0, 0.0
         self._refresh_sources()
-        vel = self.gather("velocities") if self.part.world_size > 1 else self.velocities
+        vel = self.gather("velocities") if self._sharded else self.velocities
         uk = direct.energy(self._posm, vel, self.n, direct.f32(self.softening), self._g)
         u, k = uk.cpu().tolist()
         return u, k
@@ -161,7 +165,7 @@ class BaseSimulator:
     def gather(self, name: str) -> torch.Tensor:
         """Global (n,3) copy of a sharded state array on every rank ('positions', ...)."""
         local = getattr(self, name)
-        if self.part.world_size == 1:
+        if not self._sharded:
             return local
         out = torch.empty((self.n, 3), dtype=torch.float32, device=self.device)
         return nbd_dist.allgather_rows(local, self.part, out, group=self.process_group)
@@ -198,7 +202,7 @@ class BaseSimulator:
                 e1.record()
                 events.append((e0, e1))
                 if self.calc_energy:
-                    if self.part.world_size == 1:
+                    if not self._sharded:
                         # energies of the state AFTER the step (simulation.py:131-133). The leapfrog step
                         # leaves posm = current positions; the Euler step packs before its drift, so repack.
                         if not isinstance(self, LeapFrogSimulator):
@@ -238,7 +242,7 @@ class LeapFrogSimulator(BaseSimulator):
             return
         half = direct.f32(0.5 * self.dt)
         dt = direct.f32(self.dt)
-        if self.part.world_size == 1:
+        if not self._sharded:
             new_acc = torch.empty_like(self.accelerations)
             direct.leapfrog_step(self.positions, self.velocities, self.accelerations, new_acc, self.masses,
                                  half, dt, self._eps2, self._g, self._posm, self._ws)
@@ -258,7 +262,7 @@ class EulerSimulator(BaseSimulator):
         if self.n == 0:
             return
         dt = direct.f32(self.dt)
-        if self.part.world_size == 1:
+        if not self._sharded:
             new_acc = torch.empty_like(self.accelerations)
             direct.euler_step(self.positions, self.velocities, new_acc, self.masses, dt, self._eps2,
                               self._g, self._posm, self._ws)

@@ -47,8 +47,9 @@ class RowGather:
     a scratch array, then one index_select compacts the valid rows into `out`.
     """
 
-    def __init__(self, part: RangePartition, cols: int, dtype, device, group=None):
+    def __init__(self, part: RangePartition, cols: int, dtype, device, group=None, collective: bool = False):
         self.part, self.group = part, group
+        self.collective = collective or part.world_size > 1    # a one-rank group can still go through the collective
         self.send_rows = part.n_local if part.uniform else part.max_count
         self.scratch = self.index = None
         if part.world_size > 1 and not part.uniform:
@@ -62,7 +63,7 @@ class RowGather:
         part = self.part
         if local.shape[0] < self.send_rows:
             raise ValueError(f"local has {local.shape[0]} rows, the exchange sends {self.send_rows}")
-        if part.world_size == 1:
+        if not self.collective:
             out[:part.n].copy_(local[:part.n])
             return None
         dst = out[:part.n] if part.uniform else self.scratch

@@ -501,33 +501,30 @@ def test_tuned_geometries_agree(n_src, n_tgt, gpu_device):
 
 
 @pytest.mark.gpu
-def test_sharded_simulator_single_rank_group_matches_plain(gpu_device, tmp_path):
-    """world_size 1 process group: the sharded code path end to end (async gather handle, split force, fused
-    kick) in this process against the plain simulator."""
+def test_sharded_simulator_single_rank_group_matches_plain(gpu_device, tmp_path, monkeypatch):
+    """A one-rank process group with NBD_FORCE_SHARDED=1: the range-sharded code path end to end in this process
+    (collective all-gather with an async handle, split force, fused kick, energies from gathered state) against
+    the plain simulator."""
     import torch.distributed as dist
     from galaxify import simulation
     from nbd.plummer import generate_plummer
-    init = f"file://{tmp_path}/pg"
-    dist.init_process_group("gloo", init_method=init, rank=0, world_size=1)
+    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1)
     try:
         p, v, m = generate_plummer(1500, seed=3)
         kw = dict(positions=p, velocities=v, masses=m, dt=0.01, calc_energy=False, device="cuda")
         a = simulation.LeapFrogSimulator(**kw)
+        monkeypatch.setenv("NBD_FORCE_SHARDED", "1")
         b = simulation.LeapFrogSimulator(process_group=dist.group.WORLD, **kw)
-        # force the sharded branches on a one-rank partition
-        from nbd import dist as nd, direct
-        b.part = nd.RangePartition(b.n, 1, 0); b.part.world_size = 2; b.part.uniform = True
-        b._posm_local = direct.alloc_posm(b.n, "cuda"); b._posm_local.zero_()
-        b._mass_local = b.masses
-        b._ws = direct.shard_workspace(b.n, 0, b.n, "cuda")
-
-        class _G:                                   # a gather that is a copy (one rank owns everything)
-            def start(self, local, out): out[:b.n].copy_(local[:b.n]); return None
-            def finish(self, h, out): return out
-        b._gather = _G()
+        e = simulation.EulerSimulator(process_group=dist.group.WORLD, **kw)
+        monkeypatch.delenv("NBD_FORCE_SHARDED")
+        assert b._sharded and not a._sharded and b._gather.collective
+        e0 = simulation.EulerSimulator(**kw)
         for _ in range(3):
-            a.step(); b.step()
+            a.step(); b.step(); e.step(); e0.step()
         for key in ("positions", "velocities", "accelerations"):
             assert row_rel(_np(getattr(b, key)), _np(getattr(a, key))) < 2e-6, key
+            assert row_rel(_np(getattr(e, key)), _np(getattr(e0, key))) < 2e-6, key
+        ua, ka = a.compute_energies(); ub, kb = b.compute_energies()
+        assert abs(ua - ub) < 1e-6 * abs(ua) and abs(ka - kb) < 1e-6 * abs(ka)
     finally:
         dist.destroy_process_group()
