@@ -410,6 +410,29 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
 /* scale[i] from the CSR degree d_i: mode 0 = 1/max(d,1), 1 = d, 2 = (d > 0). */
 int nbd_degree_scale_f32(const int* rowptr, int n, int mode, float* scale, nbd_stream_t stream);
 
+/* ------------------------------------------------------------ initial-condition generators on the device
+ * generate_disk / generate_spiral (src/galaxify/galaxies.py:54-192, 195-296) AFTER their random draws, in fp64 as
+ * upstream. The draws stay on the host: they come from NumPy's legacy global stream and must be consumed in the
+ * reference's order for a seed to reproduce its galaxy. generate_disk's O(N^2) enclosed-mass loop (:143-152) is a
+ * radix sort by radius + prefix sum + lower-bound search.
+ *   u_r, u_z, u_phi   device double[n]: the three vector draws of generate_disk in the reference's order --
+ *                     uniform(eps32, 1), uniform(-1, 1), rand()  (:98-112)
+ *   rot3x3            device double[9], row-major: positions/velocities are multiplied as row vectors (v @ rot),
+ *                     rot = Rx^T Ry^T Rz^T of the Euler angles (:160-186)
+ *   offset3_host, initial_vel3_host   HOST double[3] (read at call time)
+ *   pos, vel (n,3) and mass (n) device double outputs; body 0 is the central black hole. */
+size_t nbd_disk_workspace_bytes(int n);
+int nbd_disk_from_draws_f64(const double* u_r, const double* u_z, const double* u_phi, int n, double total_mass,
+                            double radial_scale, double height_scale, double g_const, double black_hole_mass,
+                            int clockwise, const double* rot3x3, const double* offset3_host,
+                            const double* initial_vel3_host, double* pos, double* vel, double* mass, void* workspace,
+                            size_t workspace_bytes, nbd_stream_t stream);
+/* raw: device double[(n-1)*6], per star {gamma radius, rand, normal z, normal v_R, normal v_phi, normal v_z} in the
+ * order the reference draws them (:245-262). */
+int nbd_spiral_from_draws_f64(const double* raw, int n, double total_mass, double radial_scale, double height_scale,
+                              double g_const, double black_hole_mass, int n_arms, double pitch_angle, double arm_strength,
+                              double* pos, double* vel, double* mass, nbd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,12 +2,15 @@
 (src/galaxify/galaxies.py:11-51, 54-67, 195-207) so that `from galaxify import galaxies` keeps
 working when this package replaces the reference's on sys.path (s01-dataset-generation.py:7).
 
-Host-side numpy, float64, one-off per scene: not a kernel. Written to consume NumPy's
-legacy global RNG in exactly the order the reference does, so a given seed yields the same galaxy
-(tests/test_galaxies.py checks this against the golden inputs the real reference generated);
-everything after the draws is vectorised -- the reference's O(N^2) enclosed-mass loop
-(galaxies.py:143-152) becomes a sort + prefix sum, its per-body Python arithmetic (:245-294)
-array expressions.
+Two paths, one random stream. The draws always come from NumPy's legacy global RNG on the host, in exactly
+the order the reference consumes it, so a given seed yields the same galaxy (tests/test_galaxies.py checks this
+against the golden inputs the real reference generated). What follows the draws runs
+  * on the host (default; float64 numpy, the reference's return types): vectorised -- the reference's O(N^2)
+    enclosed-mass loop (galaxies.py:143-152) becomes a sort + prefix sum, its per-body Python arithmetic
+    (:245-294) array expressions;
+  * or on the MI355X with `device="cuda"` (csrc/generators.hip through the C-ABI): the same
+    arithmetic in fp64 kernels, the enclosed mass by radix sort + prefix sum + lower-bound search; returns torch
+    CUDA float64 tensors that the simulators take as they are. Agrees with the host path to fp64 rounding.
 """
 from __future__ import annotations
 
@@ -42,10 +45,13 @@ def _euler_rotation(angle) -> np.ndarray:
 
 def generate_disk(*, n_bodies: int, total_mass: float, radial_scale: float, height_scale: float, g_const: float,
                   black_hole_mass: float, offset=(0, 0, 0), initial_vel=(0, 0, 0), clockwise=True,
-                  angle=(0, 0, 0), seed: int = None):
+                  angle=(0, 0, 0), seed: int = None, device=None):
     """Exponential disc around a central black hole (body 0); returns (positions, velocities, masses)."""
     np.random.seed(seed)
     n = int(n_bodies)
+    if device is not None:
+        return _disk_on_device(n, total_mass, radial_scale, height_scale, g_const, black_hole_mass, offset, initial_vel,
+                               clockwise, angle, device)
     star = np.ones(n, dtype=bool)
     star[0] = False
     # three vector draws, in this order: radius, height, azimuth
@@ -84,10 +90,13 @@ def generate_disk(*, n_bodies: int, total_mass: float, radial_scale: float, heig
 
 def generate_spiral(*, n_bodies: int, total_mass: float, radial_scale: float, height_scale: float, g_const: float,
                     black_hole_mass: float, n_arms: int = 2, pitch_angle: float = -np.pi / 6,
-                    arm_strength: float = 0.3, seed: int = None):
+                    arm_strength: float = 0.3, seed: int = None, device=None):
     """Spiral-perturbed exponential disc around a central black hole (body 0), equal-mass stars."""
     np.random.seed(seed)
     n = int(n_bodies)
+    if device is not None:
+        return _spiral_on_device(n, total_mass, radial_scale, height_scale, g_const, black_hole_mass, n_arms,
+                                 pitch_angle, arm_strength, device)
     m_bh = total_mass * black_hole_mass
     masses = np.empty(n)
     masses[0] = m_bh
@@ -98,13 +107,7 @@ def generate_spiral(*, n_bodies: int, total_mass: float, radial_scale: float, he
     if n <= 1:
         return pos, vel, masses
 
-    # The legacy global RNG has to be consumed star by star (gamma is a rejection sampler, so the number
-    # of underlying draws varies): radius, azimuth, then four unit normals (z, v_R, v_phi, v_z).
-    raw = np.empty((n - 1, 6))
-    for row in raw:
-        row[0] = np.random.gamma(shape=2, scale=radial_scale)
-        row[1] = np.random.rand()
-        row[2:] = (np.random.normal(), np.random.normal(), np.random.normal(), np.random.normal())
+    raw = _spiral_draws(n, radial_scale)
     r, phi = raw[:, 0], 2 * np.pi * raw[:, 1]
     g_z, g_r, g_phi, g_vz = raw[:, 2], raw[:, 3], raw[:, 4], raw[:, 5]
 
@@ -123,3 +126,71 @@ def generate_spiral(*, n_bodies: int, total_mass: float, radial_scale: float, he
     v_z = 0.0 + (0.05 * v_circ) * g_vz
     vel[1:] = np.stack((v_r * cos_a - v_phi * sin_a, v_r * sin_a + v_phi * cos_a, v_z), axis=1)
     return pos, vel, masses
+
+
+def _spiral_draws(n: int, radial_scale: float) -> np.ndarray:
+    """The legacy global RNG has to be consumed star by star (gamma is a rejection sampler, so the number of
+    underlying draws varies): radius, azimuth, then four unit normals (z, v_R, v_phi, v_z) -- galaxies.py:245-262."""
+    raw = np.empty((max(n - 1, 0), 6))
+    for row in raw:
+        row[0] = np.random.gamma(shape=2, scale=radial_scale)
+        row[1] = np.random.rand()
+        row[2:] = (np.random.normal(), np.random.normal(), np.random.normal(), np.random.normal())
+    return raw
+
+
+def _device_lib(device):
+    import torch
+    from nbd import _lib
+    if str(device) not in ("cuda",) and not str(device).startswith("cuda:"):
+        raise ValueError("device debe ser 'cuda' o None")
+    if not torch.cuda.is_available():
+        raise RuntimeError("galaxies(device='cuda'): no GPU visible")
+    return torch, _lib, torch.device(device)
+
+
+def _disk_on_device(n, total_mass, radial_scale, height_scale, g_const, black_hole_mass, offset, initial_vel, clockwise,
+                    angle, device):
+    import ctypes
+    torch, _lib, dev = _device_lib(device)
+    # the three vector draws, in the reference's order (galaxies.py:98-112)
+    u_r = np.random.uniform(low=np.finfo(np.float32).eps, high=1.0, size=n)
+    u_z = np.random.uniform(-1.0, 1.0, size=n)
+    u_phi = np.random.rand(n)
+    d = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
+    u_r_d, u_z_d, u_phi_d, rot_d = d(u_r), d(u_z), d(u_phi), d(_euler_rotation(angle))
+    pos = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    vel = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    mass = torch.empty(n, dtype=torch.float64, device=dev)
+    if n == 0:
+        return pos, vel, mass
+    L = _lib.lib()
+    ws = torch.empty(L.nbd_disk_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    off = (ctypes.c_double * 3)(*[float(t) for t in offset])
+    v0 = (ctypes.c_double * 3)(*[float(t) for t in initial_vel])
+    with _lib.on_device(dev):
+        _lib.check(L.nbd_disk_from_draws_f64(u_r_d.data_ptr(), u_z_d.data_ptr(), u_phi_d.data_ptr(), n, float(total_mass),
+                                             float(radial_scale), float(height_scale), float(g_const),
+                                             float(black_hole_mass), int(bool(clockwise)), rot_d.data_ptr(), off, v0,
+                                             pos.data_ptr(), vel.data_ptr(), mass.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             _lib.current_stream(dev)), "nbd_disk_from_draws_f64")
+    return pos, vel, mass
+
+
+def _spiral_on_device(n, total_mass, radial_scale, height_scale, g_const, black_hole_mass, n_arms, pitch_angle,
+                      arm_strength, device):
+    torch, _lib, dev = _device_lib(device)
+    raw = torch.tensor(_spiral_draws(n, radial_scale), dtype=torch.float64, device=dev)
+    pos = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    vel = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    mass = torch.empty(n, dtype=torch.float64, device=dev)
+    if n == 0:
+        return pos, vel, mass
+    with _lib.on_device(dev):
+        _lib.check(_lib.lib().nbd_spiral_from_draws_f64(raw.data_ptr() if n > 1 else None, n, float(total_mass),
+                                                        float(radial_scale), float(height_scale), float(g_const),
+                                                        float(black_hole_mass), int(n_arms), float(pitch_angle),
+                                                        float(arm_strength), pos.data_ptr(), vel.data_ptr(),
+                                                        mass.data_ptr(), _lib.current_stream(dev)),
+                   "nbd_spiral_from_draws_f64")
+    return pos, vel, mass

@@ -84,6 +84,13 @@ SIGNATURES = {
     "nbd_energy_workspace_bytes": (c_size_t, [c_int]),
     "nbd_energy_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p,
                                c_size_t, c_void_p]),
+    # --- generators on the device (csrc/generators.hip)
+    "nbd_disk_workspace_bytes": (c_size_t, [c_int]),
+    "nbd_disk_from_draws_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_double, c_double,
+                                        c_double, c_int, c_void_p, POINTER(c_double), POINTER(c_double), c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nbd_spiral_from_draws_f64": (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_double, c_double, c_int,
+                                          c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     # --- surrogate models: graph build (csrc/graph.hip)
     "nbd_knn_graph_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_void_p, c_void_p]),

@@ -12,6 +12,7 @@ un-synchronised time.time() would time kernel launches only).
 from __future__ import annotations
 
 import os
+import time
 from glob import glob
 
 import numpy as np
@@ -183,6 +184,8 @@ class Trainer:
         pred = torch.empty((sim_steps, n, 9), dtype=gt.dtype, device=gt.device)
         torch.cat([pos, vel, pred_accs], dim=1, out=pred[0])
         graphed = self._capture_step(pos, vel, m, pred_accs, dt) if (self.use_hip_graph and sim_steps >= self.hip_graph_min_steps) else None
+        torch.cuda.synchronize()
+        t_loop = time.perf_counter()
         for step in range(1, sim_steps):
             if graphed is not None:
                 (pos, vel, pred_accs), ev = timed(lambda: graphed(clone=False))
@@ -190,6 +193,11 @@ class Trainer:
                 (pos, vel, pred_accs), ev = timed(lambda: self.step(pos, vel, m, pred_accs, dt))
             events.append(ev)
             torch.cat([pos, vel, pred_accs], dim=1, out=pred[step])
+        torch.cuda.synchronize()
+        # wall time of the stepping loop alone (launches + GPU, no table building): how far the harness is from the
+        # captured step's own GPU time
+        self.last_rollout_timing = {"steps": sim_steps - 1, "loop_wall_s": time.perf_counter() - t_loop,
+                                    "captured": graphed is not None}
         table = torch.cat([gt, pred], dim=2).cpu().numpy().astype(np.float64)      # ONE device->host copy
         times = np.array([a.elapsed_time(b) * 1e-3 for a, b in events])
         steps = np.repeat(np.arange(sim_steps), n)
