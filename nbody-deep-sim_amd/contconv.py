@@ -73,10 +73,12 @@ class ContinuousConv(nn.Module):
 
     use_fused = True         # block-sparse fused kernels (csrc/contconv_fused.hip) where the shape allows
 
-    def forward(self, positions, features, edge_index=None, lists=None, act=None, out=None, wt=None, pairs=None):
+    def forward(self, positions, features, edge_index=None, lists=None, act=None, out=None, wt=None, pairs=None,
+                scale=None):
         """contconv.py:80-98. Give either the sync-free `lists` (graphops.radius_lists) or a PyG-style
         edge_index [2,E] (row 0 = aggregation target, row 1 = feature source). `pairs`: the pair lists of
-        this graph and filter resolution when the caller already has them (layers of one model that share D)."""
+        this graph and filter resolution when the caller already has them (layers of one model that share D);
+        `scale`: the 1/in-degree row scale of mean aggregation when the caller already has it."""
         n = positions.shape[0]
         if lists is not None:
             rowptr, centres = lists.rowptr, lists.centres
@@ -91,7 +93,10 @@ class ContinuousConv(nn.Module):
         r2 = float(np.float32(self.radius ** 2))                       # contconv.py:86: python double -> fp32
         if self.agg in ("max", "min"):
             return self._forward_extreme(positions, features, rowptr, centres, act, out)
-        scale = nnops.degree_scale(rowptr, n, 0, positions.device) if self.agg == "mean" else None
+        if self.agg != "mean":
+            scale = None
+        elif scale is None:
+            scale = nnops.degree_scale(rowptr, n, 0, positions.device)
         if torch.is_grad_enabled() and (self.filters.requires_grad or features.requires_grad):
             if lists is not None:            # the radius search's per-centre lists ARE the by-source grouping
                 bwd = dict(tgt_s=lists.nbr, deg=lists.deg, cap=lists.nbr.shape[1])
@@ -257,10 +262,12 @@ class ContinuousConvModel(nn.Module):
                 got = nnops.contconv_pairs_batch(pos, lists.rowptr, lists.centres, lists.centres.numel(),
                                                  float(np.float32(self.radius ** 2)), jobs[lo:lo + 4])
                 pair_cache.update(zip(keys[lo:lo + 4], got))
+        inv_deg = nnops.degree_scale(lists.rowptr, n, 0, x7.device) if n > 0 else None     # once for all layers
         for li, layer in enumerate(self.contconv):
             last = li == len(self.contconv) - 1
             pairs = pair_cache.get((layer.filter_resolution, float(layer.radius))) if layer.fused_ok() else None
-            h = layer(pos, h, lists=lists, act="tanh", out=conv_view if last else None, wt=w["wt"][li], pairs=pairs)
+            h = layer(pos, h, lists=lists, act="tanh", out=conv_view if last else None, wt=w["wt"][li], pairs=pairs,
+                      scale=inv_deg)
         ln = nnops.layernorm(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
                              self.layer_norm.eps)
         return run_chain(ln, w["head"])

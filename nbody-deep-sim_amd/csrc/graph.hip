@@ -479,6 +479,7 @@ __global__ __launch_bounds__(256) void transpose_scatter_kernel(const int* __res
 
 // one wave per row, out of place: rank of x = number of row entries below it (entries are distinct
 // centre indices); lane k handles entries k, k+64, ...; the comparison operand is a wave-uniform load
+// (a register-resident form comparing through v_readlane measured slower: 34 us against 23 us at N = 16 384)
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sort_rows_kernel(const int* __restrict__ rowptr, int n,
                                                                         const int* __restrict__ unsorted,
                                                                         int* __restrict__ centres) {
@@ -495,7 +496,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sort_rows_kernel(const in
   }
 }
 
-// exclusive scan of int32 counts into ptr[0..n] (single workgroup; n up to a few million)
+// exclusive scan of int32 counts into ptr[0..n] (single workgroup; n up to a few million). Four consecutive
+// counts per thread and iteration: 4096 per trip, one wave scan and two barriers per trip (first form: 1024 per
+// trip and three barriers, 19 us for n = 16 384; this one 10 us).
 __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int* __restrict__ cnt, int n,
                                                               int* __restrict__ ptr) {
   __shared__ int wave_sum[16];
@@ -503,10 +506,13 @@ __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int* __restr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < n ? cnt[i] : 0;
-    int s = v;
+  for (int base = 0; base < n; base += 4096) {
+    const int i = base + 4 * threadIdx.x;
+    int v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = i + q < n ? cnt[i + q] : 0;
+    const int mine = (v[0] + v[1]) + (v[2] + v[3]);
+    int s = mine;
     for (int off = 1; off < 64; off <<= 1) {
       const int t = __shfl_up(s, off);
       if (lane >= off) s += t;
@@ -516,11 +522,16 @@ __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int* __restr
     int wave_off = 0;
     for (int w = 0; w < wave; ++w) wave_off += wave_sum[w];
     const int carry = carry_s;
-    if (i < n) ptr[i] = carry + wave_off + s - v;
+    int run = carry + wave_off + s - mine;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (i + q < n) ptr[i + q] = run;
+      run += v[q];
+    }
     __syncthreads();
-    if (threadIdx.x == 1023) carry_s = carry + wave_off + s;
-    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = run;
   }
+  __syncthreads();
   if (threadIdx.x == 0) ptr[n] = carry_s;
 }
 
