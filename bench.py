@@ -263,7 +263,9 @@ def main():
             "n_particles": n_total, "particles_per_gpu": n_loc, "g_const": 1.0, "softening": 0.1, "dt": 0.01,
             "seed": args.seed, "pairs_per_step": pairs_per_step,
             "parallelism": "single GPU" if world == 1 else
-                           f"range partition x{world}, one RCCL all-gather of float4[{n_loc}] per rank per step",
+                           f"range partition x{world}, one all-gather of float4[{n_loc}] per rank per step "
+                           f"(backend {dist.get_backend() if group is not None else 'none'}: nccl = RCCL over xGMI), "
+                           f"overlapped with the own-bodies force block",
             "launch_plan": plan,
         },
         "roofline": {

@@ -50,15 +50,25 @@ def test_host_only_queries():
     assert b"workspace" in L.nbd_strerror(-2)
     g, s, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert L.nbd_accel_plan(65536, 65536, g, s, c) == 0
-    # 512 target groups x 16 slabs = 8192 workgroups (4 residency rounds of 8 per CU), 16 chunks per wave
+    # 512 target groups x 16 slabs = 8192 workgroups (6.4 residency rounds of 5 per CU), 16 chunks per wave
     assert (g.value, s.value, c.value) == (512, 16, 16)
     assert L.nbd_accel_plan(0, 5, None, None, None) == -1
     assert L.nbd_step_workspace_bytes(65536) == 16 * 65536 * 12
-    for n_src, n_tgt in [(3, 3), (1000, 1000), (65536, 8192), (524288, 65536), (100, 7)]:
+    for n_src, n_tgt in [(3, 3), (1000, 1000), (65536, 8192), (524288, 65536), (100, 7), (65536, 16384), (8192, 8192)]:
         assert L.nbd_accel_plan(n_src, n_tgt, g, s, c) == 0
         chunks = (n_src + 63) // 64
         assert s.value * 4 * c.value >= chunks          # every chunk is covered
+        assert 1 <= s.value <= 64 and (c.value - 1) * s.value * 4 < chunks      # ... and no wave is given more than its share
         assert g.value * 128 >= n_tgt
+    # the range-sharded split: one of 8 ranks at N = 65 536 (own block + remote block), ragged shards, a lone rank
+    a, b, cc, d = (ctypes.c_int() for _ in range(4))
+    assert L.nbd_shard_plan(65536, 3 * 8192, 8192, a, b, cc, d) == 0
+    assert a.value * 4 * b.value >= 128 and cc.value * 4 * d.value >= 896 and 16 <= cc.value <= 64
+    assert L.nbd_shard_workspace_bytes(65536, 3 * 8192, 8192) == (a.value + cc.value) * 8192 * 12
+    assert L.nbd_shard_plan(1000, 0, 1000, a, b, cc, d) == 0 and cc.value == 0          # nothing remote
+    assert L.nbd_shard_plan(1000, 990, 20, a, b, cc, d) == -1                           # range outside the system
+    assert L.nbd_contconv_fused_supported(128, 128, 160) == 1 and L.nbd_contconv_fused_supported(70, 40, 27) == 0
+    assert L.nbd_contconv_fused_supported(128, 128, 216) == 0                            # pair-list LDS tables: <= 160 cells
 
 
 def test_bad_arguments_are_rejected_without_touching_the_gpu():
