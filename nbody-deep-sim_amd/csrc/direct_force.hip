@@ -410,6 +410,11 @@ AccelPlan plan_chunks(int n_chunks, int n_tgt) {
   const int pref = ceil_div(8192, p.groups), cap_pref = n_chunks / (16 * kWaves);
   if ((pref < cap_pref ? pref : cap_pref) * p.groups >= 10 * kCUs) {
     slabs = pref < cap_pref ? pref : cap_pref;
+    // accuracy: a wave adds its sources in one sequential fp32 chain, so very large systems get enough slabs to keep
+    // a chain <= 64 chunks (4096 sources): at N = 524 288 two slabs (65 536-source chains) measured 3e-6 per-row
+    // against fp64, 32 slabs 1e-6; the extra slab traffic is < 0.1 % of such a step
+    const int min_slabs = ceil_div(n_chunks, kWaves * 64);
+    if (slabs < min_slabs) slabs = min_slabs;
   } else {
     slabs = 1;
     double best = plan_cost(p.groups, n_chunks, 1);

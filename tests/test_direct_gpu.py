@@ -528,3 +528,42 @@ def test_sharded_simulator_single_rank_group_matches_plain(gpu_device, tmp_path,
         assert abs(ua - ub) < 1e-6 * abs(ua) and abs(ka - kb) < 1e-6 * abs(ka)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_config5_size_on_one_gpu_properties_and_rank_split(gpu_device):
+    """BASELINE configs[4]: 524 288 bodies (the 8-GPU shape) on ONE GPU. (a) Newton's third law on the full force,
+    (b) 32 sampled rows against an fp64 direct sum, (c) what rank 3 of 8 computes -- own block + remote block over
+    the gathered array, nbd_shard_force_* at n_local = 65 536, lo = 196 608 -- equals its rows of the one-launch
+    force."""
+    from nbd import direct
+    from nbd.plummer import generate_plummer
+    n = 524288
+    p, v, m = generate_plummer(n, seed=1234)
+    pos = torch.tensor(p, dtype=torch.float32, device="cuda")
+    mass = torch.tensor(m, dtype=torch.float32, device="cuda")
+    posm = direct.pack_posm(pos, mass)
+    eps2, g = direct.f32(0.1 ** 2), 1.0
+    acc = direct.accel(posm, n, posm, n, 0, eps2, g)
+    assert torch.isfinite(acc).all()
+    a64, m64 = acc.double(), mass.double()
+    net = (m64[:, None] * a64).sum(0).norm() / (m64[:, None] * a64).norm(dim=1).sum()
+    assert float(net) < 2e-6                                                       # sum_i m_i a_i = 0
+    rows = np.random.default_rng(0).choice(n, 32, replace=False)
+    p64, m64n = p.astype(np.float32).astype(np.float64), m.astype(np.float32).astype(np.float64)
+    ref = np.empty((32, 3))
+    for k, i in enumerate(rows):
+        d = p64 - p64[i]
+        w = m64n * (np.einsum("ij,ij->i", d, d) + float(np.float32(0.01))) ** -1.5
+        w[i] = 0.0
+        ref[k] = (d * w[:, None]).sum(0)
+    assert row_rel(_np(acc[torch.tensor(rows, device="cuda")]), ref) < 3e-6
+    lo, n_loc = 3 * 65536, 65536
+    posm_local = direct.pack_posm(pos[lo:lo + n_loc].contiguous(), mass[lo:lo + n_loc].contiguous())
+    ws = direct.shard_workspace(n, lo, n_loc, "cuda")
+    acc_r = torch.empty((n_loc, 3), device="cuda")
+    direct.shard_force_local(posm_local, n_loc, n, lo, eps2, ws)
+    direct.shard_force_remote(posm, n, posm_local, n_loc, lo, eps2, g, acc_r, None, 0.0, ws)
+    assert row_rel(_np(acc_r), _np(acc[lo:lo + n_loc])) < 2e-6
+    plan = direct.shard_plan(n, lo, n_loc)
+    assert plan["slabs_local"] >= 1 and plan["slabs_remote"] >= 1
