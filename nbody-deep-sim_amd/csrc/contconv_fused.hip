@@ -410,12 +410,24 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
             if (!more) break;
           }
         }
-        for (; i < here; ++i) {                                      // the chunk's last < 16 pairs
-          const char* rowp = fbytes + (unsigned)__builtin_amdgcn_readlane((int)roff, i);
-          const f2 f = *reinterpret_cast<const f2*>(rowp + lane8);
-          if (base + i == next_begin) flush();
-          const float w = __int_as_float(__builtin_amdgcn_readlane(pr.y, i));
-          acc = __builtin_elementwise_fma(f2{w, w}, f, acc);
+        if (i < here) {
+          // the chunk's last < 16 pairs as ONE masked batch (indices clamped, all loads issued together): one at a
+          // time they ran with a single row in flight -- and half-steps with fewer than 16 pairs, a large share of
+          // all steps, were gathered entirely that way (measured 300-400 cycles per pair)
+          const int rem = here - i;
+#pragma unroll
+          for (int u = 0; u < PB; ++u) {
+            const char* rowp = fbytes + (unsigned)__builtin_amdgcn_readlane((int)roff, i + min(u, rem - 1));
+            fa[u] = *reinterpret_cast<const f2*>(rowp + lane8);
+          }
+#pragma unroll
+          for (int u = 0; u < PB; ++u) {
+            if (u < rem) {                                           // wave-uniform
+              if (base + i + u == next_begin) flush();
+              const float w = __int_as_float(__builtin_amdgcn_readlane(pr.y, i + u));
+              acc = __builtin_elementwise_fma(f2{w, w}, fa[u], acc);
+            }
+          }
         }
         pr = pr_next;
       }
