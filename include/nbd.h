@@ -116,6 +116,11 @@ int nbd_kick_f32(float* vel, const float* acc, int n, float c, nbd_stream_t stre
 /* x += c * v   (simulation.py:187). */
 int nbd_drift_f32(float* pos, const float* vel, int n, float c, nbd_stream_t stream);
 
+/* out[0..3n) = pos, out[3n..6n) = vel, out[6n..9n) = acc: the per-step state clones of BaseSimulator.run
+ * (simulation.py:135-139) as one launch, so that a chunk of steps can be captured into a hipGraph with its
+ * snapshots going to a device ring (one device->host copy per chunk instead of three per step). */
+int nbd_snapshot_f32(const float* pos, const float* vel, const float* acc, int n, float* out, nbd_stream_t stream);
+
 /* Bytes of scratch the fused step entry points need (always >= one slab). */
 size_t nbd_step_workspace_bytes(int n);
 

@@ -252,6 +252,15 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, si
   if (i < n) p[i] = 0.f;
 }
 
+// state snapshot of one step into a device ring slot: out = [pos | vel | acc], each (n,3) -- BaseSimulator.run's
+// per-step clones (simulation.py:135-139) as ONE launch that a captured chunk of steps can contain
+__global__ __launch_bounds__(256) void snapshot_kernel(const float* __restrict__ pos, const float* __restrict__ vel,
+                                                       const float* __restrict__ acc, int n3, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n3) return;
+  out[i] = pos[i]; out[n3 + i] = vel[i]; out[2 * n3 + i] = acc[i];
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                    float c, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -676,6 +685,13 @@ int nbd_drift_f32(float* pos, const float* vel, int n, float c, nbd_stream_t str
   if (n < 0 || (n > 0 && (!pos || !vel))) return NBD_E_BADARG;
   if (n == 0) return 0;
   axpy_kernel<<<ceil_div(3 * n, 256), 256, 0, (hipStream_t)stream>>>(pos, vel, c, 3 * n);
+  return launch_status();
+}
+
+int nbd_snapshot_f32(const float* pos, const float* vel, const float* acc, int n, float* out, nbd_stream_t stream) {
+  if (n < 0 || (n > 0 && (!pos || !vel || !acc || !out))) return NBD_E_BADARG;
+  if (n == 0) return 0;
+  snapshot_kernel<<<ceil_div(3 * n, 256), 256, 0, (hipStream_t)stream>>>(pos, vel, acc, 3 * n, out);
   return launch_status();
 }
 

@@ -179,6 +179,12 @@ class BaseSimulator:
         states = []
         if steps <= 0:
             return states
+        if self._graph_run_ok(steps):
+            return self._run_graphed(steps)
+        return self._run_eager(steps, 0)
+
+    def _run_eager(self, steps: int, first_index: int) -> list[SimulationState]:
+        states = []
         n_loc = self.part.n_local
         per_step = 3 * n_loc * 3 * 4
         chunk = max(1, min(max(steps, 32), (64 << 20) // max(per_step, 1)))
@@ -225,9 +231,103 @@ class BaseSimulator:
                 u, k = (uk[s][0], uk[s][1]) if self.calc_energy else (None, None)
                 states.append(SimulationState(
                     positions=host[s, 0], velocities=host[s, 1],
-                    accelerations=host[s, 2], step=done + s,
+                    accelerations=host[s, 2], step=first_index + done + s,
                     step_time=events[s][0].elapsed_time(events[s][1]) * 1e-3, u_energy=u, k_energy=k))
             done += m
+        return states
+
+    # ------------------------------------------------------------------ run(): captured chunks for small systems
+    # Below ~16 k bodies a step is a handful of microseconds of GPU work and run() is bound by its per-step host
+    # work (events, seven ctypes launches, three staged copies, a state object): 110-280 us per step wall for 15-25 us
+    # of GPU time at the reference's dataset sizes (100-2000 bodies x 1000 steps, s01-dataset-generation.py:192-214).
+    # Those systems run in CHUNKS captured into a hipGraph: per step the integrator's launches, the energy launches
+    # and ONE snapshot launch into a device ring; per chunk one replay, one sync, one device->host copy. Same
+    # kernels in the same order as step(): bit-identical states (tested).
+    GRAPH_RUN_MAX_BODIES = 16384
+    GRAPH_RUN_CHUNK = 32
+
+    def _graph_run_ok(self, steps: int) -> bool:
+        return (not self._sharded and 0 < self.n <= self.GRAPH_RUN_MAX_BODIES and steps >= 8 and
+                type(self).step in (LeapFrogSimulator.step, EulerSimulator.step) and
+                os.environ.get("NBD_RUN_GRAPH", "1") != "0")
+
+    def _step_in_place(self, acc):
+        """One integrator step on (positions, velocities, acc) without rebinding anything (capturable)."""
+        dt = direct.f32(self.dt)
+        if isinstance(self, LeapFrogSimulator):
+            direct.leapfrog_step(self.positions, self.velocities, acc, acc, self.masses, direct.f32(0.5 * self.dt), dt,
+                                 self._eps2, self._g, self._posm, self._ws)
+        else:
+            direct.euler_step(self.positions, self.velocities, acc, self.masses, dt, self._eps2, self._g, self._posm,
+                              self._ws)
+
+    def _chunk_graph(self, m: int):
+        """(graph, ring, uk) for a chunk of m steps; captured once per m and kept."""
+        cache = self.__dict__.setdefault("_run_graphs", {})
+        # a graph bakes in buffer addresses and scalar arguments: anything the caller may have changed is in the key
+        key = (m, self.positions.data_ptr(), self.velocities.data_ptr(), self.masses.data_ptr(), float(self.dt),
+               bool(self.calc_energy))
+        if key in cache:
+            return cache[key]
+        if len(cache) > 8:
+            cache.clear()
+        n, dev = self.n, self.device
+        if getattr(self, "_acc_g", None) is None:
+            self._acc_g = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            self._energy_ws = direct.alloc_bytes(_lib.lib().nbd_energy_workspace_bytes(n), dev)
+        ring = torch.empty((m, 3, n, 3), dtype=torch.float32, device=dev)
+        uk = torch.zeros((m, 2), dtype=torch.float64, device=dev)
+        soft = direct.f32(self.softening)
+        leap = isinstance(self, LeapFrogSimulator)
+
+        def body(count=m):
+            for s_ in range(count):
+                self._step_in_place(self._acc_g)
+                if self.calc_energy:
+                    if not leap:     # the Euler step packs before its drift: energies need the moved positions
+                        direct.pack_posm(self.positions, self.masses, out=self._posm)
+                    direct.energy(self._posm, self.velocities, n, soft, self._g, out_uk=uk[s_], workspace=self._energy_ws)
+                direct.snapshot(self.positions, self.velocities, self._acc_g, ring[s_])
+        # capture on a side stream; the state is saved and restored around the (executed) warm-up pass
+        keep = (self.positions.clone(), self.velocities.clone(), self._acc_g.clone())
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            body(1)                                          # every kernel of a step once (lazy initialisations)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.positions.copy_(keep[0]); self.velocities.copy_(keep[1]); self._acc_g.copy_(keep[2])
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        self.positions.copy_(keep[0]); self.velocities.copy_(keep[1]); self._acc_g.copy_(keep[2])
+        cache[key] = (graph, ring, uk)
+        return cache[key]
+
+    def _run_graphed(self, steps: int) -> list[SimulationState]:
+        n, dev = self.n, self.device
+        states, done = [], 0
+        first = True
+        while steps - done >= 8:                             # chunks of 32, then of 8; the last < 8 steps run eagerly
+            m = self.GRAPH_RUN_CHUNK if steps - done >= self.GRAPH_RUN_CHUNK else 8
+            graph, ring, uk = self._chunk_graph(m)          # (capture leaves the state untouched)
+            if first:                                        # a caller's handle on the old accelerations stays valid
+                self._acc_g.copy_(self.accelerations)
+                first = False
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            graph.replay()
+            e1.record()
+            host = ring.cpu()                                # one device->host copy per chunk (synchronises)
+            uk_h = uk.cpu().tolist() if self.calc_energy else None
+            t_step = e0.elapsed_time(e1) * 1e-3 / m          # GPU time of the chunk, spread over its steps
+            for s_ in range(m):
+                u, k = (uk_h[s_][0], uk_h[s_][1]) if self.calc_energy else (None, None)
+                states.append(SimulationState(step=done + s_, step_time=t_step, positions=host[s_, 0],
+                                              velocities=host[s_, 1], accelerations=host[s_, 2], u_energy=u, k_energy=k))
+            done += m
+        self.accelerations = self._acc_g.clone()             # rebound, as step() does (simulation.py:168)
+        if done < steps:
+            states += self._run_eager(steps - done, done)
         return states
 
     def step(self):

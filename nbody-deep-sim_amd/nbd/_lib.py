@@ -72,6 +72,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p]),
     "nbd_kick_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "nbd_drift_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "nbd_snapshot_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "nbd_step_workspace_bytes": (c_size_t, [c_int]),
     "nbd_leapfrog_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                       c_float, c_float, c_float, c_float, c_void_p, c_void_p,

@@ -184,6 +184,15 @@ def drift(pos, vel, c: float) -> None:
                                             _lib.current_stream(pos.device)), "nbd_drift_f32")
 
 
+def snapshot(pos, vel, acc, out) -> None:
+    """out (3, n, 3) = [pos, vel, acc]: one launch (a slot of run()'s device ring)."""
+    n = pos.shape[0]
+    _chk(pos, (n, 3), "pos"); _chk(vel, (n, 3), "vel"); _chk(acc, (n, 3), "acc"); _chk(out, (3, n, 3), "out")
+    with _lib.on_device(pos.device):
+        _lib.check(_lib.lib().nbd_snapshot_f32(pos.data_ptr(), vel.data_ptr(), acc.data_ptr(), n, out.data_ptr(),
+                                               _lib.current_stream(pos.device)), "nbd_snapshot_f32")
+
+
 def leapfrog_step(pos, vel, acc_in, acc_out, mass, dt_half: float, dt: float, softening_sq: float,
                   g_const: float, posm, workspace, ev_begin=None, ev_end=None) -> None:
     """One fused step; ev_begin/ev_end: optional torch.cuda.Event (already recorded once, so the

@@ -567,3 +567,45 @@ def test_config5_size_on_one_gpu_properties_and_rank_split(gpu_device):
     assert row_rel(_np(acc_r), _np(acc[lo:lo + n_loc])) < 2e-6
     plan = direct.shard_plan(n, lo, n_loc)
     assert plan["slabs_local"] >= 1 and plan["slabs_remote"] >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls,n,steps,energy", [("LeapFrogSimulator", 300, 45, True), ("EulerSimulator", 129, 40, True),
+                                                ("LeapFrogSimulator", 1024, 33, False), ("LeapFrogSimulator", 2, 9, True)])
+def test_run_in_captured_chunks_equals_eager_run(cls, n, steps, energy, gpu_device, monkeypatch):
+    """run() on launch-bound systems replays hipGraph chunks (step + energies + one snapshot launch per step, one
+    copy per chunk): every SimulationState, the final device state and the bookkeeping (accelerations rebound,
+    earlier handles untouched, a second run() and step() continuing from it) must equal the eager run() bit for bit."""
+    from galaxify import galaxies
+    p, v, m = galaxies.generate_spiral(n_bodies=n, total_mass=1.0, radial_scale=3.0, height_scale=0.3, g_const=4.5e-6,
+                                       black_hole_mass=0.01, seed=5)
+    g = dict(pos=p, vel=v, mass=m, g_const=4.5e-6, softening=0.05, dt=1e-4)
+    a = _mk(cls, g, calc_energy=energy)
+    b = _mk(cls, g, calc_energy=energy)
+    assert a._graph_run_ok(steps)
+    acc_before = a.accelerations
+    acc_before_copy = acc_before.clone()
+    sa = a.run(steps)
+    monkeypatch.setenv("NBD_RUN_GRAPH", "0")
+    assert not b._graph_run_ok(steps)
+    sb = b.run(steps)
+    monkeypatch.delenv("NBD_RUN_GRAPH")
+    assert len(sa) == len(sb) == steps
+    for x, y in zip(sa, sb):
+        assert x.step == y.step and x.step_time > 0
+        assert torch.equal(x.positions, y.positions) and torch.equal(x.velocities, y.velocities)
+        assert torch.equal(x.accelerations, y.accelerations)
+        assert (x.u_energy, x.k_energy) == (y.u_energy, y.k_energy)
+        assert (x.u_energy is not None) == energy
+    for key in ("positions", "velocities", "accelerations"):
+        assert torch.equal(getattr(a, key), getattr(b, key)), key
+    assert torch.equal(acc_before, acc_before_copy) and a.accelerations.data_ptr() != acc_before.data_ptr()
+    # continue: a second (cached-graph) run and a plain step
+    a.dt = 2e-4; b.dt = 2e-4                              # a changed dt must not replay the old graph
+    sa2 = a.run(10); sb2 = [None] * 10
+    monkeypatch.setenv("NBD_RUN_GRAPH", "0")
+    sb2 = b.run(10)
+    monkeypatch.delenv("NBD_RUN_GRAPH")
+    assert torch.equal(sa2[-1].positions, sb2[-1].positions) and torch.equal(sa2[-1].accelerations, sb2[-1].accelerations)
+    a.step(); b.step()
+    assert torch.equal(a.positions, b.positions) and torch.equal(a.velocities, b.velocities)
