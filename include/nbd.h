@@ -438,6 +438,24 @@ int nbd_spiral_from_draws_f64(const double* raw, int n, double total_mass, doubl
                               double g_const, double black_hole_mass, int n_arms, double pitch_angle, double arm_strength,
                               double* pos, double* vel, double* mass, nbd_stream_t stream);
 
+/* ------------------------------------------------------------ dataset CSV rows (host code, no device work)
+ * The reference writes one row per particle per state with csv.DictWriter (src/s01-dataset-generation.py:218-241);
+ * the nine state columns are numpy.float32 scalars, which the csv module prints with str(): the shortest decimal
+ * that reads back as the same fp32, positional for 1e-4 <= |x| < 1e16, d.ddde-XX otherwise.
+ *   nbd_format_f32        that string for one value into out24 (>= 24 bytes, not NUL-terminated); returns its length
+ *   nbd_format_f32_array  n values into fixed slots of `slot` (>= 24) bytes each, NUL-padded (a numpy 'S<slot>' array)
+ *   nbd_csv_format_state  the n rows of one state:  prefix + mass_i + ",x,y,z,vx,vy,vz,ax,ay,az" + suffix, where
+ *                         prefix = "scene,scene_type,step,step_time," and suffix = ",u,k\r\n" are the per-state
+ *                         constants the caller printed, mass_i = mass_chars[mass_off[i] .. mass_off[i+1]) the per-body
+ *                         float64 strings (printed once per scene), pos / vel / acc HOST (n,3) fp32. Returns the bytes
+ *                         written, or -1 on a bad argument / cap < nbd_csv_state_bound(...). */
+int nbd_format_f32(float x, char* out24);
+int nbd_format_f32_array(const float* x, int64_t n, char* out, int slot);
+size_t nbd_csv_state_bound(int n, size_t prefix_len, size_t mass_chars, size_t suffix_len);
+int64_t nbd_csv_format_state(char* out, size_t cap, const char* prefix, size_t prefix_len, const char* mass_chars,
+                             const int32_t* mass_off, const float* pos, const float* vel, const float* acc, int n,
+                             const char* suffix, size_t suffix_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,12 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nbd_spiral_from_draws_f64": (c_int, [c_void_p, c_int, c_double, c_double, c_double, c_double, c_double, c_int,
                                           c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    # --- dataset CSV rows, host code (csrc/csv_format.hip)
+    "nbd_format_f32": (c_int, [c_float, c_void_p]),
+    "nbd_format_f32_array": (c_int, [c_void_p, c_int64, c_void_p, c_int]),
+    "nbd_csv_state_bound": (c_size_t, [c_int, c_size_t, c_size_t, c_size_t]),
+    "nbd_csv_format_state": (c_int64, [c_void_p, c_size_t, c_char_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int, c_char_p, c_size_t]),
     # --- surrogate models: graph build (csrc/graph.hip)
     "nbd_knn_graph_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_void_p, c_void_p]),

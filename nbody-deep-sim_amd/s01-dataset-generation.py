@@ -2,21 +2,24 @@
 """Dataset-generation CLI with the reference's flags and CSV wire format
 (src/s01-dataset-generation.py:12-91 flags, :93-104 cartesian product over list-valued flags,
 :108-125 columns, :218-241 one row per particle per step), running the simulation on the MI355X
-through galaxify.simulation. Rows are formatted array-wise (the reference builds one dict per
-particle per step). Extension: --sim-type plummer (the reference has disk | spiral only).
+through galaxify.simulation. Rows are formatted state by state in native code (the reference builds one
+dict per particle per step and hands it to csv.DictWriter). Extension: --sim-type plummer (the reference has disk | spiral only).
 
   python s01-dataset-generation.py --integrator leapfrog --n-bodies 3 25 50 --sim-type spiral \\
          --steps 1000 --seed 7 --output data/train/output_file_1.csv
 """
 import argparse
+import ctypes
 import itertools
 import os
 import sys
 
 import numpy as np
+import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from galaxify import galaxies, simulation  # noqa: E402
+from nbd import _lib  # noqa: E402
 from nbd.plummer import generate_plummer  # noqa: E402
 
 FIELDNAMES = ["scene", "scene_type", "step", "step_time", "mass", "x", "y", "z", "vx", "vy", "vz",
@@ -24,22 +27,34 @@ FIELDNAMES = ["scene", "scene_type", "step", "step_time", "mass", "x", "y", "z",
 
 
 def write_states(f, scene_id, scene_type, states, masses):
-    """Append the rows of one scene: for every state, for every particle, the 16 columns above, each
-    value printed as Python's csv module prints it (str() of the fp32 / float64 / float value)."""
-    m = np.asarray(masses).astype(str)
-    n = m.shape[0]
+    """Append the rows of one scene to the binary file `f`: for every state, for every particle, the 16 columns
+    above, each value printed as Python's csv module prints it (str() of the fp32 / float64 / float value). The
+    per-state constants and the float64 masses are printed here, once; the nine fp32 columns of every row by
+    nbd_csv_format_state (csrc/csv_format.hip), which reproduces str(np.float32(x)) digit for digit."""
+    L = _lib.lib()
+    m = [s.encode() for s in np.asarray(masses).astype(str).tolist()]
+    n = len(m)
+    if n == 0:
+        return
+    mass_chars = b"".join(m)
+    mass_off = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum([len(s) for s in m], out=mass_off[1:])
+    buf, cap = None, 0
     for st in states:
-        cols = [np.full(n, str(scene_id)), np.full(n, scene_type), np.full(n, str(st.step)),
-                np.full(n, str(st.step_time)), m]
-        for t in (st.positions, st.velocities, st.accelerations):
-            a = t.cpu().numpy()
-            cols += [a[:, 0].astype(str), a[:, 1].astype(str), a[:, 2].astype(str)]
-        cols += [np.full(n, "" if st.u_energy is None else str(st.u_energy)),
-                 np.full(n, "" if st.k_energy is None else str(st.k_energy))]
-        lines = cols[0]
-        for c in cols[1:]:
-            lines = np.char.add(np.char.add(lines, ","), c)
-        f.write("\r\n".join(lines.tolist()) + "\r\n")          # csv.writer's default line terminator
+        prefix = f"{scene_id},{scene_type},{st.step},{st.step_time},".encode()
+        suffix = (f",{'' if st.u_energy is None else st.u_energy},{'' if st.k_energy is None else st.k_energy}"
+                  "\r\n").encode()                                     # csv.writer's default line terminator
+        need = L.nbd_csv_state_bound(n, len(prefix), len(mass_chars), len(suffix))
+        if need > cap:
+            buf, cap = ctypes.create_string_buffer(need), need
+        p, v, a = (t.cpu().contiguous() for t in (st.positions, st.velocities, st.accelerations))
+        if not (p.dtype == v.dtype == a.dtype == torch.float32 and p.shape == v.shape == a.shape == (n, 3)):
+            raise ValueError("write_states: estados (n,3) float32 esperados")
+        wrote = L.nbd_csv_format_state(buf, cap, prefix, len(prefix), mass_chars, mass_off.ctypes.data, p.data_ptr(),
+                                       v.data_ptr(), a.data_ptr(), n, suffix, len(suffix))
+        if wrote < 0:
+            raise _lib.NbdError("nbd_csv_format_state: argumentos rechazados")
+        f.write(memoryview(buf)[:wrote])
 
 
 def build_parser():
@@ -83,8 +98,8 @@ def main(argv=None):
     combos = list(itertools.product(*(params[k] for k in keys)))
     print(f"Generando {len(combos)} escenarios -> {args.output}")
     cls = simulation.EulerSimulator if args.integrator == "euler" else simulation.LeapFrogSimulator
-    with open(args.output, "w", newline="") as f:
-        f.write(",".join(FIELDNAMES) + "\r\n")
+    with open(args.output, "wb") as f:
+        f.write((",".join(FIELDNAMES) + "\r\n").encode())
         for scene_id, combo in enumerate(combos):
             c = dict(zip(keys, combo))
             pos, vel, masses = initial_conditions(c)

@@ -842,3 +842,37 @@ def test_captured_gnn_step_equals_eager_for_small_systems(n, gpu_device):
         p, v, a = tr.step(p, v, m1, a, 0.01)
         gp, gv, ga = adv()
         assert torch.equal(gp, p) and torch.equal(gv, v) and torch.equal(ga, a), (n, i)
+
+
+@pytest.mark.parametrize("k", [3, 0])
+def test_dataset_graphs_equal_the_per_group_construction(k, tmp_path, gpu_device):
+    """datautils.ParticleGraphDataset builds all graphs from one sort, one upload and one batched kNN launch. Against
+    the reference's construction spelled out (datautils.py:23-48: pandas groupby (scene, step), per-group tensors,
+    per-graph kNN) on a CSV whose rows are interleaved across scenes / steps, with ragged graph sizes including
+    graphs of one and two nodes: same graphs in the same order, same node order, same edges."""
+    import pandas as pd
+    from datautils import ParticleGraphDataset
+    from nbd import graphops
+    rng = np.random.default_rng(21)
+    rows = []
+    for scene, n in ((2, 5), (0, 1), (1, 9), (3, 2)):
+        mass = (rng.random(n) + 0.5).astype(np.float32)
+        for step in (1, 0, 2):
+            block = rng.standard_normal((n, 9)).astype(np.float32)
+            rows += [[scene, step, mass[i]] + list(block[i]) for i in range(n)]
+    rows = np.array(rows, dtype=np.float64)[rng.permutation(len(rows))]            # file order != group order
+    path = str(tmp_path / "mixed.csv")
+    _write_toy_csv(path, rows)
+    ds = ParticleGraphDataset(path, k=k, device="cuda")
+    df = pd.read_csv(path)
+    groups = list(df.groupby(["scene", "step"]))
+    assert len(ds) == len(groups) == 12
+    for g, ((scene, step), grp) in zip(ds.graphs, groups):
+        x = torch.tensor(grp[["x", "y", "z", "vx", "vy", "vz", "mass"]].values, dtype=torch.float)
+        y = torch.tensor(grp[["ax", "ay", "az"]].values, dtype=torch.float)
+        assert torch.equal(g.x.cpu(), x) and torch.equal(g.y.cpu(), y)
+        assert g.scene.tolist() == [scene] * len(grp) and g.step.tolist() == [step] * len(grp)
+        assert g.scene.dtype == g.step.dtype == torch.int64 and g.edge_index.dtype == torch.int64
+        want = graphops.knn_graph(x[:, :3].cuda().contiguous(), k=k, loop=False) if k > 0 else \
+            torch.zeros((2, 0), dtype=torch.int64, device="cuda")
+        assert torch.equal(g.edge_index, want) and g.edge_index.is_contiguous()
