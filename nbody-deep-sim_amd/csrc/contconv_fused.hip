@@ -11,13 +11,14 @@
 // Here A never leaves the chip and only touched blocks are multiplied:
 //
 //   nbd_contconv_pairs_batch_f32   per (tile of 128 nodes, filter resolution): every (edge, corner) pair
-//                            {source, weight}, grouped by (cell, node) -- a counting sort held in LDS; the packed
-//                            "rows" (distinct nodes) of each (tile, cell) and their pair ranges. ~24 B of index
-//                            data per pair, once per graph; all resolutions of a model in one launch (60 us at the
+//                            source and weight (two arrays), grouped by (cell, node) -- a counting sort held in LDS;
+//                            the packed "rows" (distinct nodes) of each (tile, cell) and their pair ranges. ~24 B of
+//                            index data per pair, once per graph; all resolutions of a model in one launch (60 us at the
 //                            published shape for D = 6 and D = 4 together).
 //   nbd_contconv_fused_f32   per (tile, chunk of cells), 16 waves: eight producer waves gather the pairs' feature
-//                            rows and sum them into packed A rows in LDS (32 rows per step, a ring of four
-//                            buffers, two waves per buffer); eight consumer waves multiply each step by 16 columns
+//                            rows (pair records by scalar loads, rows by buffer loads with the row offset in an
+//                            SGPR: no vector-ALU work per gathered row but the weighted add) and sum them into
+//                            packed A rows in LDS (32 rows per step, a ring of four buffers, two waves per buffer); eight consumer waves multiply each step by 16 columns
 //                            of the cell's I x O filter with fp32 MFMA (v_mfma_f32_16x16x4_f32; the fragment sits in
 //                            registers, pre-shuffled by the host so that every lane loads it with one dwordx4 per 16
 //                            k, the next cell's being fetched meanwhile) and add the 32 x 16 result into a
@@ -25,8 +26,8 @@
 //                            flags only (no workgroup barrier inside the loop). Cell chunks of one tile are
 //                            summed in fixed order by the finishing kernel (scale, activation). No float atomics:
 //                            deterministic.
-// Measured at the published shape (tools/bench_contconv.py, profiles/r02_contconv_*): layer D = 6 0.52 ms, D = 4
-// 0.35 ms against 1.09 / 0.54 ms for binning + dense GEMM; executed 53.7 GFLOP per step (32-row granularity; the
+// Measured at the published shape (tools/bench_contconv.py, profiles/r02_contconv_*): layer D = 6 0.47 ms, D = 4
+// 0.32 ms against 1.09 / 0.54 ms for binning + dense GEMM; executed 53.7 GFLOP per step (32-row granularity; the
 // touched blocks alone are 38.1) against 120; the binned matrix: 0 bytes of HBM traffic against 2.7 GB.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,6 +37,7 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef int i8v __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -112,7 +114,9 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 struct PairJob {
   int D, n_cells;
   const int* cell_map;
-  int2 *desc, *rows, *pairs;
+  int2 *desc, *rows;
+  int* pair_src;        // [8 * edge_capacity] source node of every (edge, corner) pair ...
+  float* pair_w;        // ... and its window * trilinear weight (two arrays: the fused kernel reads them with scalar loads)
 };
 struct PairJobs { PairJob j[NBD_CC_MAX_RES]; };
 
@@ -126,7 +130,8 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   const int D = job.D, n_cells = job.n_cells;
   int2* __restrict__ desc = job.desc;
   int2* __restrict__ rows = job.rows;
-  int2* __restrict__ pairs = job.pairs;
+  int* __restrict__ psrc = job.pair_src;
+  float* __restrict__ pwgt = job.pair_w;
   const int kc = (n_cells + 3) & ~3;                       // padded cell count (even: two u16 per word)
   unsigned* cnt32 = smem;                                   // [TN][kc/2]
   unsigned* pwithin = cnt32 + TN * kc / 2;                  // [TN][kc]
@@ -241,7 +246,8 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
         if (k < 0) continue;
         const unsigned old = atomicSub(&cnt32[(nl * kc + k) >> 1], 1u << (16 * (k & 1)));
         const int slot = (int)((old >> (16 * (k & 1))) & 0xffffu) - 1;
-        pairs[pair_base + cell_pairbase[k] + pwithin[nl * kc + k] + slot] = make_int2(c_cur, __float_as_int(w));
+        const size_t at = (size_t)pair_base + cell_pairbase[k] + pwithin[nl * kc + k] + slot;
+        psrc[at] = c_cur; pwgt[at] = w;
       }
     }
   }
@@ -258,6 +264,20 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
 // hidden behind three other steps, and the consumers never wait for each other: every wave owns its 32
 // output columns of the LDS accumulator. (First version: one s_barrier per step, 7 us per step against
 // 1.8 us of MFMA.)
+#if defined(NBD_CC_ABL) && NBD_CC_ABL == 3
+#define CC_MFMA(acc, a, b) acc[0] += a * b;
+#else
+#define CC_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+#endif
+#ifndef NBD_CC_SLEEP
+#define NBD_CC_SLEEP 4             // s_sleep between two polls of a flag (x64 cycles); 0 / 1 / 4 measured 0.479 / 0.492 / 0.474 ms (D = 6)
+#endif
+#ifndef NBD_CC_XCD_MAP
+#define NBD_CC_XCD_MAP 0
+#endif
+#ifndef NBD_CC_PRODUCER_PRIO
+#define NBD_CC_PRODUCER_PRIO 2
+#endif
 constexpr int NBUF = 4;
 constexpr int CC_CONSUMERS = 8;                  // consumer waves (16 output columns each)
 constexpr int CC_PRODUCERS = 2 * NBUF;           // producer waves: two per ring buffer, 16 packed rows each
@@ -272,17 +292,32 @@ constexpr int MAX_STEPS = CHUNK_MAX * (TN / SUB);
 #define CC_WAIT(flag, cond)                                                                                  \
   do {                                                                                                       \
     while (!(__hip_atomic_load(&(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) cond))               \
-      __builtin_amdgcn_s_sleep(1);                                                                           \
+      __builtin_amdgcn_s_sleep(NBD_CC_SLEEP);                                                                \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");                                          \
   } while (0)
 #define CC_RELEASE_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 
+#ifdef NBD_CC_TRACE
+__device__ long long* g_cc_trace = nullptr;
+#endif
+
+// Build-time probes (tools/build_contconv_trace.sh, tools/contconv_trace.py): -DNBD_CC_TRACE stamps every workgroup
+// (s_memrealtime) and accumulates the time waves spend on the LDS flags; -DNBD_CC_ABL = 1 / 2 / 3 are timing-only
+// ablations (one cell's filters / feature rows from a 64 KiB table / no MFMA). None of it is in the product build.
+#ifndef NBD_CC_TRACE
+#define DBG_T(x)
+#define DBG_ACC(x)
+#define DBG_LAT(x, j)
+#define DBG_W(x)
+#define DBG_PH(i, x)
+#endif
 template <int KG>
 __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
     const float* __restrict__ feat, int ldf, int I, const int* __restrict__ rowptr, int n,
-    const int2* __restrict__ desc, const int2* __restrict__ rows, const int2* __restrict__ pairs,
-    const f4* __restrict__ filt, int n_cells, int kq_count, int colblocks, int cells_per_chunk, int O,
-    float* __restrict__ partial) {
+    const int2* __restrict__ desc, const int2* __restrict__ rows, const int* __restrict__ pair_src,
+    const float* __restrict__ pair_w,
+    const f4* __restrict__ filt, int n_cells, int kq_count, int colblocks, int cells_per_chunk, int n_tiles,
+    int n_chunks, int O, float* __restrict__ partial) {
   // f4-typed so that the dynamic region starts 16-byte aligned behind the static __shared__ variables: declared
   // as float[] it began at an 8-byte offset and EVERY ds_read_b128 / ds_write_b64 below took the unaligned path
   // (SQ_LDS_UNALIGNED_STALL = 85 % of all LDS cycles, LDS array 69 % busy, MFMA pipe 27 %)
@@ -297,11 +332,38 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
   __shared__ int full[NBUF], done[NBUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x, n0 = tile * TN;
-  const int k_begin = blockIdx.y * cells_per_chunk, k_end = min(n_cells, k_begin + cells_per_chunk);
+#ifdef NBD_CC_TRACE
+  __shared__ long long s_dbg_wait[16];
+  long long dbg_wait = 0;
+#define DBG_T(x) const long long x = __builtin_amdgcn_s_memrealtime();
+#define DBG_ACC(x) dbg_wait += __builtin_amdgcn_s_memrealtime() - x;
+#define DBG_W(x) const long long x##_w = dbg_wait;
+  long long dbg_ph[3] = {0, 0, 0}; const long long l2 = 0; (void)l2;
+#define DBG_PH(i, x) dbg_ph[i] += __builtin_amdgcn_s_memrealtime() - x;
+  long long dbg_lat = 0; int dbg_nlat = 0;
+#define DBG_LAT(x, j) if ((j) == 0) { dbg_lat += __builtin_amdgcn_s_memrealtime() - x - (dbg_wait - x##_w); ++dbg_nlat; }
+  __shared__ int s_dbg_pairs;
+  const long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) s_dbg_pairs = 0;
+#endif
+  // Workgroup -> (tile, cell chunk), tile fastest. Measured and rejected (NBD_CC_XCD_MAP=1): chunk = index mod 8, which
+  // pins every chunk -- and its 1.3 MB slice of the filter matrix -- to ONE XCD (workgroups go to the XCDs round-robin
+  // by index: confirmed with the probes, 1024 of 1024). The filters then sit in that XCD's L2, but nothing got
+  // faster per workgroup (the kernel is not waiting on those loads) while the chunks of the central cells, now all on
+  // two XCDs, stretched the launch from 0.50 to 0.65 ms.
+  int tile, chunk;
+  if (NBD_CC_XCD_MAP && (n_chunks & 7) == 0) {
+    const int k = blockIdx.x >> 3;
+    tile = k % n_tiles; chunk = (blockIdx.x & 7) + 8 * (k / n_tiles);
+  } else {
+    tile = blockIdx.x % n_tiles; chunk = blockIdx.x / n_tiles;
+  }
+  const int n0 = tile * TN;
+  const int k_begin = chunk * cells_per_chunk, k_end = min(n_cells, k_begin + cells_per_chunk);
   const int e_t = rowptr[n0];
   const int2* t_rows = rows + (size_t)8 * e_t + tile;
-  const int2* t_pairs = pairs + (size_t)8 * e_t;
+  const int* t_src = pair_src + (size_t)8 * e_t;
+  const float* t_w = pair_w + (size_t)8 * e_t;
 
   // non-empty cells of this chunk, compacted, and the step table (wave 0; cells_per_chunk <= 64)
   if (wave == 0) {
@@ -340,30 +402,52 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
     // (the gather wants tens of KiB outstanding per CU: MI355X_MICROARCH.md "Indexed rows"), and the wave's next
     // step's row records are fetched while this one is summed. (First form: 64-bit index math, a predicate
     // around every load and a clamp per pair -- 25+ instructions per pair, 5.7 us per step.)
-    constexpr int PB = 16;
+    constexpr int PB = 8, NBF = 4;                        // rows per batch, batches in flight per wave
+    // The producers are the YOUNGER waves of their SIMDs (waves 8-15 behind the consumers' 0-7): at equal priority
+    // the issue arbiter serves age first, and the consumers' back-to-back MFMAs left a producer one instruction
+    // slot in ~70 (in-kernel stamps: 2.1 us to ISSUE a batch of 16 row loads, 1.4 us to sum it -- the same with the
+    // rows coming from a 64 KiB table as from the 8 MB one, i.e. not a memory effect). Their stream is sparse (about
+    // ten instructions per gathered row), so raised priority costs the consumers little.
+    __builtin_amdgcn_s_setprio(NBD_CC_PRODUCER_PRIO);
     float* a_dst = a_buf + (w4 * SUB + hf * HSUB) * LDA;
     const bool live = 2 * lane < I;
     const unsigned lane8 = (unsigned)min(2 * lane, I - 2) * 4u;      // clamped: every lane reads inside the row
-    const char* fbytes = reinterpret_cast<const char*>(feat);
     const unsigned ldb = (unsigned)ldf * 4u;
-    auto row_records = [&](int s) {
-      const int j = st_cell[s];
-      const int cnt = max(0, min(HSUB, s_nrows[j] - st_sub[s] * SUB - hf * HSUB));      // this half's rows (may be 0)
-      int2 r = make_int2(-1, 0);
-      if (lane <= cnt && cnt > 0) r = t_rows[s_rowbeg[j] + st_sub[s] * SUB + hf * HSUB + lane];   // row `cnt` = the next row (or the sentinel)
-      return r;
+    // this half's rows of step s (clamped to the last step: ONE load whatever s, so that hipcc can count its
+    // s_waitcnt vmcnt); lane `cnt` holds the row behind the last one (or the tile's sentinel): its first pair ends the step
+    auto step_cnt = [&](int s) { return max(0, min(HSUB, s_nrows[st_cell[s]] - st_sub[s] * SUB - hf * HSUB)); };
+    auto row_records = [&](int s_want) {
+      const int s = min(s_want, nsteps - 1), j = st_cell[s], cnt = step_cnt(s);
+      const int2 v = t_rows[s_rowbeg[j] + st_sub[s] * SUB + (cnt > 0 ? hf * HSUB + min(lane, cnt) : 0)];
+      return (lane <= cnt && cnt > 0) ? v : make_int2(-1, 0);
     };
-    int2 rinfo = make_int2(-1, 0);
-    if (w4 < nsteps) rinfo = row_records(w4);
+    // The feature matrix through a buffer descriptor: a row is fetched by `buffer_load_dwordx2 v, v_lane, s[rsrc], s_row offen`
+    // with the row's byte offset in an SGPR -- and the pair records {source, weight} are read with SCALAR loads
+    // (uniform addresses), so gathering a row costs the vector ALU nothing and summing it one v_pk_fma_f32 with the
+    // weight as a scalar operand. The fp32 MFMAs of the consumer waves keep the SIMDs' vector issue busy: in-kernel
+    // stamps showed a producer getting one VALU slot per ~35 cycles (1.5-2 us to ISSUE 16 row loads when each cost a
+    // v_readlane + a 64-bit VALU add; the same from a 64 KiB table as from the 8 MB one, so not a memory effect).
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feat), 0, (int)min((size_t)0x7fffffff, ((size_t)(n - 1) * ldf + I) * 4), 0x00020000);
+    int2 rinfo = make_int2(-1, 0), rinfo_n = make_int2(-1, 0);
+    if (nsteps > 0) { rinfo = row_records(w4); rinfo_n = row_records(w4 + NBUF); }
     for (int s = w4, use = 0; s < nsteps; s += NBUF, ++use) {
-      const int cnt = max(0, min(HSUB, s_nrows[st_cell[s]] - st_sub[s] * SUB - hf * HSUB));
+      const int cnt = step_cnt(s);
       const int p_begin = __builtin_amdgcn_readlane(rinfo.y, 0), p_end = __builtin_amdgcn_readlane(rinfo.y, cnt);
-      int2 pr = make_int2(0, 0);
-      if (p_begin + lane < p_end) pr = t_pairs[p_begin + lane];      // first 64 pairs
+#ifdef NBD_CC_TRACE
+      if (lane == 0) atomicAdd(&s_dbg_pairs, p_end - p_begin);
+#endif
       const int2 rinfo_cur = rinfo;
-      if (s + NBUF < nsteps) rinfo = row_records(s + NBUF);          // next step's records: in flight from here on
-      if (use > 0) CC_WAIT(done[w4], >= CC_CONSUMERS * use);         // the consumers are done with this buffer
-      if (lane < HSUB) rowmap[w4 * SUB + hf * HSUB + lane] = lane < cnt ? rinfo_cur.x : TN;     // padding rows -> the dummy row
+      rinfo = rinfo_n;
+      // the ring buffer is claimed only when the first feature rows are already on their way
+      bool claimed = false;
+      auto claim = [&]() {
+        if (!claimed) {
+          DBG_T(p0) if (use > 0) CC_WAIT(done[w4], >= CC_CONSUMERS * use);   // the consumers are done with this buffer
+          DBG_ACC(p0)
+          if (lane < HSUB) rowmap[w4 * SUB + hf * HSUB + lane] = lane < cnt ? rinfo_cur.x : TN;   // padding rows -> the dummy row
+          claimed = true;
+        }
+      };
       int cur = 0;
       int next_begin = __builtin_amdgcn_readlane(rinfo_cur.y, 1);
       f2 acc = {0.f, 0.f};
@@ -373,64 +457,93 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
         ++cur;
         next_begin = __builtin_amdgcn_readlane(rinfo_cur.y, cur + 1);
       };
-      for (int base = p_begin; base < p_end; base += 64) {
-        int2 pr_next = make_int2(0, 0);
-        if (base + 64 + lane < p_end) pr_next = t_pairs[base + 64 + lane];
-        const int here = min(64, p_end - base);
-        const unsigned roff = (unsigned)pr.x * ldb;                  // byte offset of each pair's feature row
-        f2 fa[PB], fb[PB];
-        auto issue = [&](f2* f, int first) {
-#pragma unroll
+      // The step-half's pairs as one stream of 16-row batches, two in flight. EVERY stage issues exactly 16 row loads
+      // (past the end: re-reads of the last pair's row, L1 hits), and the row records of the step after next ONE:
+      // only then can hipcc count its s_waitcnt vmcnt() and let batch j be summed while batch j + 1 is in flight
+      // (with `if (more) issue(...)` the merged paths made it assume no younger loads: summing row u of one batch
+      // waited for row u of the NEXT batch -- vmcnt(15..0) behind a conditional block of 16 loads in the ISA).
+      const int np = p_end - p_begin, nb = (np + PB - 1) / PB;
+      if (nb > 0) {
+        // NBF batches of PB rows in flight. A batch's pair records sit in SGPRs, fetched by scalar loads one stage
+        // before they are needed: its PB sources (for the row loads) NBF - 1 stages before its PB weights (for the
+        // sum), two register sets each, alternating. Inline asm: hipcc selects scalar loads only for memory it can
+        // prove unclobbered, and the LDS fences of the flag protocol defeat that proof (it fell back to vector
+        // loads + a v_readfirstlane waterfall per row).
+        f2 fbuf[NBF][PB];
+        i8v srcA, srcB, wgtA, wgtB;
+        auto req_src = [&](i8v& src, int j) {                        // batches past the end: no request, row 0 is gathered
+          if (j < nb) asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(src) : "s"(t_src + p_begin + PB * j) : "memory");
+        };
+        auto req_wgt = [&](i8v& wgt, int j) {
+          if (j < nb) asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(wgt) : "s"(t_w + p_begin + PB * j) : "memory");
+        };
+        auto landed = [&](i8v& a, i8v& b, i8v& c, i8v& d) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
+        };
+        auto issue = [&](f2* f, const i8v& src, int j) {
+          const int valid = np - PB * j;                             // records past the step's last pair: gather row 0 of
+#pragma unroll                                                       // the batch again instead of whatever follows
           for (int u = 0; u < PB; ++u) {
-            const char* rowp = fbytes + (unsigned)__builtin_amdgcn_readlane((int)roff, first + u);
-            f[u] = *reinterpret_cast<const f2*>(rowp + lane8);
+            const int sidx = u < valid ? src[u] : (valid > 0 ? src[0] : 0);     // nothing left at all: row 0, a hot line
+#if defined(NBD_CC_ABL) && NBD_CC_ABL == 2
+            const unsigned ro = (unsigned)(sidx & 127) * ldb;
+#else
+            const unsigned ro = (unsigned)sidx * ldb;
+#endif
+            f[u] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(frs, (int)lane8, (int)ro, 0));
           }
         };
-        auto sum = [&](const f2* f, int first) {
+        auto sum = [&](const f2* f, const i8v& wgt, int j) {
+          const int valid = min(PB, np - PB * j), q0 = p_begin + PB * j;
+          if (valid == PB) {
 #pragma unroll
-          for (int u = 0; u < PB; ++u) {
-            if (base + first + u == next_begin) flush();             // wave-uniform
-            const float w = __int_as_float(__builtin_amdgcn_readlane(pr.y, first + u));
-            acc = __builtin_elementwise_fma(f2{w, w}, f[u], acc);
-          }
-        };
-        int i = 0;
-        if (here >= PB) {
-          issue(fa, 0);
-          for (;;) {
-            bool more = i + 2 * PB <= here;
-            if (more) issue(fb, i + PB);
-            sum(fa, i);
-            i += PB;
-            if (!more) break;
-            more = i + 2 * PB <= here;
-            if (more) issue(fa, i + PB);
-            sum(fb, i);
-            i += PB;
-            if (!more) break;
-          }
-        }
-        if (i < here) {
-          // the chunk's last < 16 pairs as ONE masked batch (indices clamped, all loads issued together): one at a
-          // time they ran with a single row in flight -- and half-steps with fewer than 16 pairs, a large share of
-          // all steps, were gathered entirely that way (measured 300-400 cycles per pair)
-          const int rem = here - i;
+            for (int u = 0; u < PB; ++u) {
+              if (q0 + u == next_begin) flush();                     // wave-uniform
+              const float w = __int_as_float(wgt[u]);
+              acc = __builtin_elementwise_fma(f2{w, w}, f[u], acc);
+            }
+          } else {
 #pragma unroll
-          for (int u = 0; u < PB; ++u) {
-            const char* rowp = fbytes + (unsigned)__builtin_amdgcn_readlane((int)roff, i + min(u, rem - 1));
-            fa[u] = *reinterpret_cast<const f2*>(rowp + lane8);
-          }
-#pragma unroll
-          for (int u = 0; u < PB; ++u) {
-            if (u < rem) {                                           // wave-uniform
-              if (base + i + u == next_begin) flush();
-              const float w = __int_as_float(__builtin_amdgcn_readlane(pr.y, i + u));
-              acc = __builtin_elementwise_fma(f2{w, w}, fa[u], acc);
+            for (int u = 0; u < PB; ++u) {
+              if (u < valid) {                                       // wave-uniform
+                if (q0 + u == next_begin) flush();
+                const float w = __int_as_float(wgt[u]);
+                acc = __builtin_elementwise_fma(f2{w, w}, f[u], acc);
+              }
             }
           }
+        };
+        static_assert(NBF == 4, "the stage rotation below is written out for four batches in flight");
+        DBG_T(l0) DBG_W(l0)
+        req_src(srcA, 0); req_src(srcB, 1);
+        landed(srcA, srcB, wgtA, wgtB);
+        issue(fbuf[0], srcA, 0); issue(fbuf[1], srcB, 1);
+        req_src(srcA, 2); req_src(srcB, 3); req_wgt(wgtA, 0);
+        rinfo_n = row_records(s + 2 * NBUF);
+        landed(srcA, srcB, wgtA, wgtB);
+        issue(fbuf[2], srcA, 2);
+        DBG_PH(0, l0)
+        claim();
+        DBG_T(l1)
+        // stage K: rows of batch j + K + 3 on their way, next records requested, batch j + K summed meanwhile
+#define CC_STAGE(K, SRC_CUR, SRC_OTHER, WGT_CUR, WGT_OTHER)                                                   \
+        landed(srcA, srcB, wgtA, wgtB);                                                                      \
+        issue(fbuf[(K + NBF - 1) % NBF], SRC_CUR, j + K + NBF - 1);                                          \
+        req_src(SRC_OTHER, j + K + NBF); req_wgt(WGT_OTHER, j + K + 1);                                      \
+        sum(fbuf[K], WGT_CUR, j + K);                                                                        \
+        if (j + K + 1 >= nb) break;
+        for (int j = 0;; j += NBF) {
+          CC_STAGE(0, srcB, srcA, wgtA, wgtB)
+          if (j == 0) { DBG_PH(1, l1) DBG_LAT(l0, j) }
+          CC_STAGE(1, srcA, srcB, wgtB, wgtA)
+          CC_STAGE(2, srcB, srcA, wgtA, wgtB)
+          CC_STAGE(3, srcA, srcB, wgtB, wgtA)
         }
-        pr = pr_next;
+#undef CC_STAGE
+      } else {
+        rinfo_n = row_records(s + 2 * NBUF);
       }
+      claim();
       if (cnt > 0) *reinterpret_cast<f2*>(a_dst + cur * LDA + 2 * lane) = live ? acc : f2{0.f, 0.f};
       CC_RELEASE_FENCE();
       if (lane == 0) __hip_atomic_fetch_add(&full[w4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // both halves -> 2 (use + 1)
@@ -451,6 +564,9 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
     // always exactly KG loads (clamped index, zeroed afterwards): a counted s_waitcnt vmcnt(KG) is only possible
     // when the number of younger loads does not depend on the path taken
     auto load_b = [&](f4* dstv, int cell) {
+#if defined(NBD_CC_ABL) && NBD_CC_ABL == 1
+      cell = 0;
+#endif
       const f4* src = filt + (((size_t)cell * colblocks + min(cb, colblocks - 1)) * kq_count) * 64 + lane;
 #pragma unroll
       for (int g = 0; g < KG; ++g) {
@@ -468,8 +584,7 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
         const f4 a0 = *reinterpret_cast<const f4*>(a_base + g * 16);                                         \
         const f4 a1 = *reinterpret_cast<const f4*>(a_base + 16 * LDA + g * 16);                              \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], BC[g][j], acc0, 0, 0, 0);                       \
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], BC[g][j], acc1, 0, 0, 0);                       \
+          CC_MFMA(acc0, a0[j], BC[g][j]) CC_MFMA(acc1, a1[j], BC[g][j])                                      \
         }                                                                                                    \
       }                                                                                                      \
       /* C row = 4 (lane >> 4) + reg (+ 16 for the second tile), column = lane & 15 -> node of the tile */  \
@@ -493,7 +608,7 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
 #define CC_ONE_STEP(BC)                                                                                      \
     {                                                                                                        \
       const int b = s & (NBUF - 1), use = s / NBUF;                                                          \
-      CC_WAIT(full[b], == 2 * (use + 1));                                                                    \
+      DBG_T(c0) CC_WAIT(full[b], == 2 * (use + 1)); DBG_ACC(c0)                                              \
       if (has_cols) CC_STEP(BC) else if (lane == 0)                                                          \
         __hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                 \
       ++s;                                                                                                   \
@@ -522,16 +637,32 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
 #undef CC_ONE_STEP
 #undef CC_STEP
   }
+#ifdef NBD_CC_TRACE
+  if (lane == 0) s_dbg_wait[wave] = wave == 9 ? dbg_lat : (wave == 13 ? dbg_nlat : (wave == 10 ? dbg_ph[0] : (wave == 11 ? dbg_ph[1] : (wave == 14 ? dbg_ph[2] : (wave == 15 ? dbg_nlat : dbg_wait)))));
+#endif
   __syncthreads();
+#ifdef NBD_CC_TRACE
+  const long long dbg_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- write the tile's partial sums for this cell chunk: partial[chunk][node][column]
-  float* dst = partial + ((size_t)blockIdx.y * n + n0) * O;
+  float* dst = partial + ((size_t)chunk * n + n0) * O;
   const int col0 = blockIdx.z * 128;
   const int n_here = min(TN, n - n0), cols = min(128, O - col0);
   for (int i = tid; i < n_here * 128; i += CC_THREADS) {
     const int nl = i >> 7, c = i & 127;
     if (c < cols) dst[(size_t)nl * O + col0 + c] = out_acc[nl * 128 + c];
   }
+#ifdef NBD_CC_TRACE
+  __syncthreads();
+  if (tid == 0 && g_cc_trace) {
+    long long* t = g_cc_trace + (size_t)blockIdx.x * 16;
+    t[6] = s_dbg_wait[0]; t[7] = s_dbg_wait[4]; t[8] = s_dbg_wait[8]; t[9] = s_dbg_wait[12];
+    t[10] = s_dbg_wait[9]; t[11] = s_dbg_wait[13]; t[12] = s_dbg_wait[10]; t[13] = s_dbg_wait[11]; t[14] = s_dbg_wait[14]; t[15] = s_dbg_wait[15];
+    t[0] = dbg_t0; t[1] = dbg_t1; t[2] = __builtin_amdgcn_s_memrealtime(); t[3] = nsteps; t[4] = s_dbg_pairs;
+    t[5] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+  }
+#endif
 }
 
 // out = act(scale * sum of the chunk partials), fixed chunk order
@@ -567,6 +698,10 @@ FusedPlan plan_fused(int n, int n_cells, int O) {
 
 extern "C" {
 
+#ifdef NBD_CC_TRACE
+int nbd_debug_cc_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cc_trace), &buf, sizeof(buf)); }
+#endif
+
 int nbd_contconv_fused_supported(int in_channels, int out_channels, int n_cells) {
   return in_channels > 0 && in_channels % 4 == 0 && in_channels <= 128 && out_channels > 0 && n_cells > 0 &&
          n_cells <= MAXC;
@@ -577,18 +712,21 @@ size_t nbd_contconv_pairs_bytes(int n, int64_t edge_capacity, int n_cells) {
   const size_t tiles = (size_t)ceil_div(n, TN);
   const size_t desc = tiles * n_cells * sizeof(int2);
   const size_t rows = ((size_t)8 * edge_capacity + tiles) * sizeof(int2);
-  const size_t pairs = (size_t)8 * edge_capacity * sizeof(int2);
+  const size_t pairs = 2 * (((size_t)8 * edge_capacity * sizeof(int) + 255) & ~(size_t)255);   // sources, weights
   return ((desc + 255) & ~(size_t)255) + ((rows + 255) & ~(size_t)255) + pairs + 256;
 }
 
-static void split_pairs_buffer(void* buf, int n, int64_t edge_capacity, int n_cells, int2** desc, int2** rows, int2** pairs) {
+static void split_pairs_buffer(void* buf, int n, int64_t edge_capacity, int n_cells, int2** desc, int2** rows, int** pair_src,
+                               float** pair_w) {
   const size_t tiles = (size_t)ceil_div(n, TN);
   char* p = static_cast<char*>(buf);
   *desc = reinterpret_cast<int2*>(p);
   p += (tiles * n_cells * sizeof(int2) + 255) & ~(size_t)255;
   *rows = reinterpret_cast<int2*>(p);
   p += (((size_t)8 * edge_capacity + tiles) * sizeof(int2) + 255) & ~(size_t)255;
-  *pairs = reinterpret_cast<int2*>(p);
+  *pair_src = reinterpret_cast<int*>(p);
+  p += ((size_t)8 * edge_capacity * sizeof(int) + 255) & ~(size_t)255;
+  *pair_w = reinterpret_cast<float*>(p);
 }
 
 int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int* centres, int n, int64_t edge_capacity,
@@ -609,7 +747,7 @@ int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int*
     if (pair_lists_bytes[r] < nbd_contconv_pairs_bytes(n, edge_capacity, nc)) return NBD_E_WORKSPACE;
     PairJob& j = jobs.j[r];
     j.D = d; j.n_cells = nc; j.cell_map = cell_maps[r];
-    split_pairs_buffer(pair_lists[r], n, edge_capacity, nc, &j.desc, &j.rows, &j.pairs);
+    split_pairs_buffer(pair_lists[r], n, edge_capacity, nc, &j.desc, &j.rows, &j.pair_src, &j.pair_w);
     const int kc = (nc + 3) & ~3;
     if (kc > kc_max) kc_max = kc;
   }
@@ -657,22 +795,24 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
   if ((reinterpret_cast<uintptr_t>(feat) & 7) || (reinterpret_cast<uintptr_t>(filters_shuffled) & 15)) return NBD_E_BADARG;
   if (!workspace || workspace_bytes < nbd_contconv_fused_workspace_bytes(n, n_cells, out_channels)) return NBD_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int2 *desc, *rows, *pairs;
-  split_pairs_buffer(const_cast<void*>(pair_lists), n, edge_capacity, n_cells, &desc, &rows, &pairs);
+  int2 *desc, *rows;
+  int* pair_src;
+  float* pair_w;
+  split_pairs_buffer(const_cast<void*>(pair_lists), n, edge_capacity, n_cells, &desc, &rows, &pair_src, &pair_w);
   const FusedPlan p = plan_fused(n, n_cells, out_channels);
   const size_t lds = (size_t)((TN + 1) * 128 + NBUF * SUB * LDA) * sizeof(float) + NBUF * SUB * sizeof(int);
   float* partial = static_cast<float*>(workspace);
-  const dim3 grid(p.tiles, p.chunks, p.colgroups);
+  const dim3 grid(p.tiles * p.chunks, 1, p.colgroups);
   const int kq_count = ceil_div(in_channels, 16);
 #define CC_LAUNCH(K)                                                                                                \
   do {                                                                                                              \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(contconv_fused_kernel<K>),                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                     \
     if (e != hipSuccess) return (int)e;                                                                             \
-    contconv_fused_kernel<K><<<grid, CC_THREADS, lds, st>>>(feat, ldf, in_channels, rowptr, n, desc, rows, pairs,   \
+    contconv_fused_kernel<K><<<grid, CC_THREADS, lds, st>>>(feat, ldf, in_channels, rowptr, n, desc, rows, pair_src, pair_w, \
                                                            reinterpret_cast<const f4*>(filters_shuffled), n_cells, \
                                                            kq_count, ceil_div(out_channels, 16), p.cells_per_chunk, \
-                                                           out_channels, partial);                                 \
+                                                           p.tiles, p.chunks, out_channels, partial);              \
   } while (0)
   if (kq_count <= 2) CC_LAUNCH(2); else CC_LAUNCH(8);      // K depth: I <= 32 / I <= 128
 #undef CC_LAUNCH
