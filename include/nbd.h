@@ -313,6 +313,8 @@ typedef struct nbd_gnn_layer_args {
   float ln_eps;
   float* out;
   int ldout;
+  float* kick_vel;        /* FINAL_HEAD only, or NULL: vel[n][ep_out] += kick_c * out_i, the second half-kick of  */
+  float kick_c;           /* Trainer.step (trainer.py:225) in the layer's epilogue (multiply, then add)           */
 } nbd_gnn_layer_args;
 int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream);
 

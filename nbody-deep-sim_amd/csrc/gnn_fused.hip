@@ -249,7 +249,14 @@ __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer
 #pragma unroll
           for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; if (h < H) part = __builtin_fmaf(zy[r], wrow[E + h], part); }
           part = wave_sum(part);
-          if (lane == 0) a.out[(size_t)node * a.ldout + d] = part + a.b_ep[d];
+          if (lane == 0) {
+            const float o_d = part + a.b_ep[d];
+            a.out[(size_t)node * a.ldout + d] = o_d;
+            if (a.kick_vel) {                              // v += c * a, rounded as the separate kick kernel rounds it
+              float* v = a.kick_vel + (size_t)node * a.ep_out + d;
+              *v = __fadd_rn(*v, __fmul_rn(a.kick_c, o_d));
+            }
+          }
         }
       }
     }
@@ -272,6 +279,7 @@ int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
   if (!a.src && (a.rowptr || a.fixed_k > 0)) return NBD_E_BADARG;
   if (a.pq) { if (a.ldpq < 2 * a.h) return NBD_E_BADARG; }
   else { if (!a.x || !a.wpq || !a.bpq || a.f <= 0 || a.ldx < a.f) return NBD_E_BADARG; if (a.f > kFMax) return NBD_E_UNSUPPORTED; }
+  if (a.kick_vel && a.epilogue != NBD_GNN_FINAL_HEAD) return NBD_E_BADARG;
   int n_ep = 0;
   switch (a.epilogue) {
     case NBD_GNN_WRITE_X: if (a.ldout < a.h) return NBD_E_BADARG; break;

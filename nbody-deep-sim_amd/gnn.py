@@ -316,10 +316,13 @@ class GraphModel(torch.nn.Module):
                     out = hint
                 else:
                     out = torch.empty((n, head[0][0].shape[0]), dtype=torch.float32, device=dev)
+                kick = getattr(self, "_kick_hint", None)      # (vel, c): the caller's half-kick, done in the epilogue
+                kw_k = dict(kick_vel=kick[0], kick_c=kick[1]) if kick is not None else {}
                 ok = nnops.gnn_layer(epilogue="final_head", w_ep=head[0][0], b_ep=head[0][1],
                                      ep_out=head[0][0].shape[0], enc=enc, e=e, ln_g=ln_g, ln_b=ln_b,
-                                     ln_eps=self.layer_norm.eps, out=out, **kw)
+                                     ln_eps=self.layer_norm.eps, out=out, **kw_k, **kw)
                 self._fused_out = out
+                self._kick_done = kick is not None
             else:
                 z = torch.empty((n, e + h), dtype=torch.float32, device=dev)
                 ok = nnops.gnn_layer(epilogue="final_ln", enc=enc, e=e, ln_g=ln_g, ln_b=ln_b,
@@ -353,11 +356,21 @@ class GraphModel(torch.nn.Module):
             pred = self._forward_inference(x_in.to(torch.float32), ei, max(min(k, pos.shape[0] - 1), 0))
         return pred
 
-    def _predict_posm(self, posm, pos, k=50, out=None):
+    def _predict_posm(self, posm, pos, k=50, out=None, kick=None):
         """predict() for callers that already hold the packed rows {x, y, z, mass} the kick-drift kernel writes
         (Trainer's captured rollout step): with input_dim == 4 that IS the model input [pos | mass]
-        (gnn.py:131-132), so nothing is concatenated. Same graph, same kernels, same values as predict()."""
+        (gnn.py:131-132), so nothing is concatenated. Same graph, same kernels, same values as predict().
+        kick = (vel, c): apply vel += c * prediction in the last layer's epilogue when the fused path runs with a
+        single-Linear head; `self._kick_done` tells the caller whether it did (otherwise the caller kicks)."""
         self.eval()
+        self._kick_done = False
+        self._kick_hint = kick
+        try:
+            return self._predict_posm_impl(posm, pos, k, out)
+        finally:
+            self._kick_hint = None
+
+    def _predict_posm_impl(self, posm, pos, k, out):
         with torch.no_grad():
             n = pos.shape[0]
             kk = max(min(k, n - 1), 0)

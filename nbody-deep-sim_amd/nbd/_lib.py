@@ -45,7 +45,7 @@ class GnnLayerArgs(ctypes.Structure):
                 ("h", c_int), ("aggr", c_int), ("w2t", c_void_p), ("b2", c_void_p),
                 ("epilogue", c_int), ("w_ep", c_void_p), ("b_ep", c_void_p), ("ep_out", c_int),
                 ("enc", c_void_p), ("ldenc", c_int), ("e", c_int), ("ln_g", c_void_p), ("ln_b", c_void_p),
-                ("ln_eps", c_float), ("out", c_void_p), ("ldout", c_int)]
+                ("ln_eps", c_float), ("out", c_void_p), ("ldout", c_int), ("kick_vel", c_void_p), ("kick_c", c_float)]
 
 
 # name -> (restype, argtypes); mirrors include/nbd.h one to one (tests check the two agree)

@@ -269,9 +269,10 @@ EPILOGUE = {"write_x": 0, "next_pq": 1, "final_head": 2, "final_ln": 3, "next_pq
 
 
 def gnn_layer(*, n, h, aggr, rowptr, src, fixed_k, w2t, b2, epilogue, out, pq=None, x=None, f=0, wpq=None, bpq=None,
-              w_ep=None, b_ep=None, ep_out=0, enc=None, e=0, ln_g=None, ln_b=None, ln_eps=1e-5):
+              w_ep=None, b_ep=None, ep_out=0, enc=None, e=0, ln_g=None, ln_b=None, ln_eps=1e-5, kick_vel=None, kick_c=0.0):
     """One fused EdgeConv layer (nbd_gnn_layer_f32). Returns False (nothing launched) when the shape is
-    outside what the fused kernel supports, so the caller can take the general multi-kernel path."""
+    outside what the fused kernel supports, so the caller can take the general multi-kernel path.
+    kick_vel (n, ep_out), final_head only: vel += kick_c * out in the epilogue (Trainer.step's second half-kick)."""
     a = _lib.GnnLayerArgs()
     dev = out.device
     kp = 64 * ((h + 63) // 64)
@@ -294,6 +295,11 @@ def gnn_layer(*, n, h, aggr, rowptr, src, fixed_k, w2t, b2, epilogue, out, pq=No
     a.enc, a.ldenc, a.e = _lib.ptr(enc), (_mat(enc, "enc") if enc is not None else 0), e
     a.ln_g, a.ln_b, a.ln_eps = _lib.ptr(ln_g), _lib.ptr(ln_b), float(ln_eps)
     a.out, a.ldout = out.data_ptr(), _mat(out, "out")
+    if kick_vel is not None:
+        if epilogue != "final_head" or kick_vel.shape != (n, ep_out) or kick_vel.dtype != torch.float32 or \
+                not kick_vel.is_contiguous() or kick_vel.device != dev:
+            raise _lib.NbdError("gnn_layer: kick_vel must be a contiguous fp32 (n, ep_out) tensor on the layer's device")
+        a.kick_vel, a.kick_c = kick_vel.data_ptr(), float(kick_c)
     with _lib.on_device(dev):
         _lib.check(_lib.lib().nbd_gnn_layer_f32(ctypes.byref(a), _lib.current_stream(dev)), "nbd_gnn_layer_f32")
     return True

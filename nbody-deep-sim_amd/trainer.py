@@ -127,11 +127,14 @@ class Trainer:
                 # copy-backs of step() would be five more launches per replay)
                 if packed:
                     direct.kick_drift(s_pos, s_vel, s_acc, m_flat, half, full, posm=posm)
-                    o_acc = self.model._predict_posm(posm, s_pos, out=s_acc)   # s_acc is consumed by kick_drift above
+                    # the second half-kick rides in the last layer's epilogue when the model's fused path allows it
+                    o_acc = self.model._predict_posm(posm, s_pos, out=s_acc, kick=(s_vel, half))   # s_acc is consumed by kick_drift above
+                    if not getattr(self.model, "_kick_done", False):
+                        direct.kick(s_vel, o_acc, half)
                 else:
                     direct.kick_drift(s_pos, s_vel, s_acc, None, half, full)
                     o_acc = self.model.predict(s_pos, torch.cat([s_vel, m], dim=-1))
-                direct.kick(s_vel, o_acc, half)
+                    direct.kick(s_vel, o_acc, half)
                 if o_acc.data_ptr() != s_acc.data_ptr():
                     s_acc.copy_(o_acc)
         except Exception as exc:                          # pragma: no cover - depends on runtime support
