@@ -492,6 +492,9 @@ int launch_linear(const float* X, int ldx, const float* W, int ldw, const float*
   if (m > 64) {          // 64 x 128 block tile: waves 2 x 2, strips of 32 x 64
     dim3 grid(ceil_div(n, 64), ceil_div(m, 128));
     linear_kernel<2, 2, 2, VEC><<<grid, 256, 0, st>>>(X, ldx, W, ldw, b, rs, brs, act, Y, ldy, n, m, K);
+  } else if (m > 32 && ceil_div(n, 128) < 512) {   // 64 x 64 (waves 2 x 2, strips of 32 x 32): a skinny product on few
+    dim3 grid(ceil_div(n, 64), ceil_div(m, 64));    // rows leaves half the CUs idle with 128-row tiles (n = 16 384: 128 workgroups)
+    linear_kernel<2, 2, 1, VEC><<<grid, 256, 0, st>>>(X, ldx, W, ldw, b, rs, brs, act, Y, ldy, n, m, K);
   } else if (m > 32) {   // 128 x 64: waves 4 x 1, strips of 32 x 64
     dim3 grid(ceil_div(n, 128), ceil_div(m, 64));
     linear_kernel<4, 1, 2, VEC><<<grid, 256, 0, st>>>(X, ldx, W, ldw, b, rs, brs, act, Y, ldy, n, m, K);
