@@ -489,10 +489,13 @@ __global__ __launch_bounds__(256) void degree_scale_kernel(const int* __restrict
 template <bool VEC>
 int launch_linear(const float* X, int ldx, const float* W, int ldw, const float* b, const float* rs,
                   const float* brs, int act, float* Y, int ldy, int n, int m, int K, hipStream_t st) {
-  if (m > 64) {          // 64 x 128 block tile: waves 2 x 2, strips of 32 x 64
+  if (m > 64 && ceil_div(n, 64) * ceil_div(m, 128) < 512) {   // 32 x 128 (waves 1 x 4): twice the workgroups when rows are few
+    dim3 grid(ceil_div(n, 32), ceil_div(m, 128));
+    linear_kernel<1, 4, 1, VEC><<<grid, 256, 0, st>>>(X, ldx, W, ldw, b, rs, brs, act, Y, ldy, n, m, K);
+  } else if (m > 64) {   // 64 x 128 block tile: waves 2 x 2, strips of 32 x 64
     dim3 grid(ceil_div(n, 64), ceil_div(m, 128));
     linear_kernel<2, 2, 2, VEC><<<grid, 256, 0, st>>>(X, ldx, W, ldw, b, rs, brs, act, Y, ldy, n, m, K);
-  } else if (m > 32 && ceil_div(n, 128) < 512) {   // 64 x 64 (waves 2 x 2, strips of 32 x 32): a skinny product on few
+  } else if (ceil_div(n, 128) < 512) {   // 64 x 64 (waves 2 x 2, strips of 32 x 32): a skinny product on few
     dim3 grid(ceil_div(n, 64), ceil_div(m, 64));    // rows leaves half the CUs idle with 128-row tiles (n = 16 384: 128 workgroups)
     linear_kernel<2, 2, 1, VEC><<<grid, 256, 0, st>>>(X, ldx, W, ldw, b, rs, brs, act, Y, ldy, n, m, K);
   } else if (m > 32) {   // 128 x 64: waves 4 x 1, strips of 32 x 64
