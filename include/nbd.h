@@ -179,6 +179,21 @@ int nbd_knn_graph_hint_f32(const float* pos, int n, int k, int loop, const int* 
                            const int64_t* out_off, int64_t num_edges, int64_t* edge_index, const int64_t* hint,
                            nbd_stream_t stream);
 
+/* The radius search of a ROLLOUT (Trainer.evaluate_rollout calls the model once per step on a configuration that
+ * has barely moved): same outputs as nbd_radius_search_f32 (no batch segments), exactly, but the O(n^2) scan runs only
+ * when some body has moved more than sqrt(moved_sq) since the cached candidate lists were built -- lists of the first
+ * wide_cap indices within sqrt(wide_radius_sq) of every centre, kept in `state` together with the reference
+ * positions. Every call: one check launch, the (self-skipping) rebuild launches, one re-test launch (one wave per
+ * centre over its cached list; a centre whose truncated list holds fewer than max_num_neighbors current hits scans
+ * on behind the list). Exact as long as moved <= (wide_radius - radius) / 2; callers leave a margin (graphops.py uses
+ * 0.45). state: nbd_radius_cached_state_bytes bytes, 64-byte aligned, ZEROED before its first use and kept by the
+ * caller between calls; workspace: nbd_radius_cached_workspace_bytes (scratch). indeg as in nbd_radius_search_f32. */
+size_t nbd_radius_cached_state_bytes(int n, int wide_cap);
+size_t nbd_radius_cached_workspace_bytes(int n, int wide_cap);
+int nbd_radius_cached_search_f32(const float* pos, int n, float radius_sq, float wide_radius_sq, float moved_sq, int loop,
+                                 int max_num_neighbors, int wide_cap, void* state, size_t state_bytes, int* nbr, int* deg,
+                                 int* last, int* indeg, void* workspace, size_t workspace_bytes, nbd_stream_t stream);
+
 /* radius_graph(pos, r, batch, loop, max_num_neighbors) -- contconv.py:225 -- in padded (ELL) form:
  * nbr[i][0..deg[i]) = the first max_num_neighbors indices j (ascending) with d2 < radius_sq
  * (strict), j == i iff loop; last[i] = the largest listed j (-1 if none). No host sync needed. */

@@ -218,6 +218,8 @@ class ContinuousConvModel(nn.Module):
         else:
             self.output = nn.Linear(out_dim, out_channels)
         self._cache = _WeightCache(self)
+        self._radius_cache = None
+        self.use_radius_cache = True
         self.to(device)
 
     def _build_weights(self):
@@ -239,7 +241,8 @@ class ContinuousConvModel(nn.Module):
         x = x.to(torch.float32).contiguous()
         pos = x[:, :3].contiguous()
         lists = graphops.radius_lists(pos, self.radius, getattr(data, "batch", None), loop=self.self_loops,
-                                      max_num_neighbors=self.max_num_neighbors)
+                                      max_num_neighbors=self.max_num_neighbors,
+                                      cache=getattr(data, "_radius_cache", None))      # predict(): a rollout's search
         c = self.continuous_conv_dim
         enc_dim = self.in_channels if w["enc"] is None else c
         cat_buf = torch.empty((n, enc_dim + c), dtype=torch.float32, device=x7.device)
@@ -278,7 +281,14 @@ class ContinuousConvModel(nn.Module):
         from nbd.data import Data
         self.eval()
         with torch.no_grad():
-            return self.forward(Data(x=torch.cat((pos, feat), dim=-1), batch=None))
+            # predict() is the rollout entry point (Trainer.step): consecutive calls see almost the same configuration,
+            # so the radius search re-tests cached candidate lists and runs its O(n^2) scan only when a body has moved
+            # far enough to matter (graphops.RadiusCache; the result is exact either way)
+            if getattr(self, "_radius_cache", None) is None:
+                self._radius_cache = graphops.RadiusCache()
+            data = Data(x=torch.cat((pos, feat), dim=-1), batch=None)
+            data._radius_cache = self._radius_cache if self.use_radius_cache else None
+            return self.forward(data)
 
     def eval_graph_batch(self, data):
         self.eval()

@@ -319,8 +319,9 @@ template <bool BATCH>
 __global__ __launch_bounds__(256) void radius_stream_kernel(
     const float* __restrict__ pos, int n, float r2, int loop, int cap, const int* __restrict__ seg_lo,
     const int* __restrict__ seg_hi, int n_slices, int slice_len, int* __restrict__ tmp_list,
-    int* __restrict__ tmp_cnt) {
+    int* __restrict__ tmp_cnt, const int* __restrict__ run_flag) {
   typedef float f4 __attribute__((ext_vector_type(4)));
+  if (run_flag && *run_flag == 0) return;                  // cached search (below): this launch is only needed on a rebuild
   typedef float f2 __attribute__((ext_vector_type(2)));
   __shared__ f4 stage[kWavesPerBlock][64];
   const int w = wave_id(), lane = threadIdx.x & 63;
@@ -406,7 +407,9 @@ __global__ __launch_bounds__(256) void radius_stream_kernel(
 // comes from the slice whose range holds t.
 __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_merge_kernel(
     const int* __restrict__ tmp_list, const int* __restrict__ tmp_cnt, int n, int n_slices, int cap,
-    int* __restrict__ nbr, int* __restrict__ deg, int* __restrict__ last, int* __restrict__ indeg) {
+    int* __restrict__ nbr, int* __restrict__ deg, int* __restrict__ last, int* __restrict__ indeg,
+    const int* __restrict__ run_flag) {
+  if (run_flag && *run_flag == 0) return;
   const int i = blockIdx.x * kWavesPerBlock + wave_id();
   if (i >= n) return;
   const int lane = threadIdx.x & 63;
@@ -431,6 +434,90 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_merge_kernel(
     if (t == d - 1) last[i] = j;
   }
   if (lane == 0) { deg[i] = d; if (d == 0) last[i] = -1; }
+}
+
+// ---- radius search for a ROLLOUT: consecutive calls see almost the same configuration, so the O(N^2) scan is
+// replaced by a re-test of a cached candidate list. The cache is the same search run once with a larger radius
+// r + skin and a larger cap W ("wide" lists: the first W indices within r + skin of each centre at the reference
+// positions `ref`, self included). As long as no body has moved more than 0.45 skin from `ref`, a body outside a
+// centre's wide list is still farther than r, so the first `cap` hits in ascending index are found inside the
+// list -- unless the list was truncated at W and holds fewer than `cap` current hits, in which case the wave
+// continues with a plain scan behind the list's last index. The result is exactly that of nbd_radius_search_f32.
+//   radius_disp_kernel      ONE workgroup: flags[0] = rebuild needed (never built, or some |pos - ref| too large)
+//   stream + merge (above)  the wide lists; they return at once unless flags[0]
+//   radius_snapshot_kernel  ref = pos, flags[1] = built; only when flags[0]
+//   radius_refresh_kernel   one wave per centre: the wide list re-tested against r
+__global__ __launch_bounds__(1024) void radius_disp_kernel(const float* __restrict__ pos, const float* __restrict__ ref,
+                                                           int n, float thr2, int* __restrict__ flags) {
+  __shared__ int any;
+  if (threadIdx.x == 0) any = flags[1] == 0 || flags[2] != n;     // never built, or built for another n
+  __syncthreads();
+  if (!any) {
+    bool moved = false;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      const float dx = pos[3 * i] - ref[3 * i], dy = pos[3 * i + 1] - ref[3 * i + 1], dz = pos[3 * i + 2] - ref[3 * i + 2];
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      moved |= !(d2 <= thr2);                                      // NaN counts as moved
+    }
+    if (moved) any = 1;                                            // benign race: every writer stores 1
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) flags[0] = any;
+}
+
+__global__ __launch_bounds__(256) void radius_snapshot_kernel(const float* __restrict__ pos, float* __restrict__ ref, int n,
+                                                              int* __restrict__ flags) {
+  if (flags[0] == 0) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 3 * n) ref[i] = pos[i];
+  if (i == 0) { flags[1] = 1; flags[2] = n; }
+}
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void radius_refresh_kernel(
+    const float* __restrict__ pos, int n, float r2, int loop, int cap, const int* __restrict__ wnbr,
+    const int* __restrict__ wdeg, int wcap, int* __restrict__ nbr, int* __restrict__ deg, int* __restrict__ last,
+    int* __restrict__ indeg) {
+  const int i = blockIdx.x * kWavesPerBlock + wave_id();
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+  const int wd = wdeg[i];
+  int hits = 0, last_j = -1;
+  auto take = [&](int j, bool ok) {                               // append the wave's hits in lane (= index) order
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+    const int slot = hits + __popcll(m & ((1ull << lane) - 1ull));
+    if (ok && slot < cap) {
+      nbr[(size_t)i * cap + slot] = j;
+      if (indeg) atomicAdd(&indeg[j], 1);
+    }
+    const int total = hits + __popcll(m);
+    if (total > hits) {                                            // the last LISTED hit so far
+      const int want = min(total, cap) - 1;                        // its slot
+      const bool mine = ok && slot == want;
+      const unsigned long long mm = __builtin_amdgcn_ballot_w64(mine);
+      if (mm) last_j = __shfl(j, (int)__builtin_ctzll(mm));
+    }
+    hits = total;
+  };
+  for (int base = 0; base < wd && hits < cap; base += 64) {
+    const int t = base + lane;
+    int j = -1;
+    bool ok = false;
+    if (t < wd) {
+      j = wnbr[(size_t)i * wcap + t];
+      ok = dist2(pos, j, xi, yi, zi) < r2 && (loop || j != i);
+    }
+    take(j, ok);
+  }
+  if (hits < cap && wd >= wcap) {                                  // truncated list, not enough hits inside: scan on
+    const int from = wnbr[(size_t)i * wcap + wcap - 1] + 1;
+    for (int base = from; base < n && hits < cap; base += 64) {
+      const int j = base + lane;
+      const bool ok = j < n && dist2(pos, j, xi, yi, zi) < r2 && (loop || j != i);
+      take(j, ok);
+    }
+  }
+  if (lane == 0) { deg[i] = min(hits, cap); last[i] = last_j; }
 }
 
 // ---- transpose of the capped lists: for node j, the centres c (ascending) whose list contains j.
@@ -692,14 +779,56 @@ int nbd_radius_search_ws_f32(const float* pos, int n, float radius_sq, int loop,
   const int waves = ceil_div(n, 128) * p.slices;
   if (seg_lo)
     radius_stream_kernel<true><<<ceil_div(waves, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
-        pos, n, radius_sq, loop, max_num_neighbors, seg_lo, seg_hi, p.slices, p.slice_len, tmp_list, tmp_cnt);
+        pos, n, radius_sq, loop, max_num_neighbors, seg_lo, seg_hi, p.slices, p.slice_len, tmp_list, tmp_cnt, nullptr);
   else
     radius_stream_kernel<false><<<ceil_div(waves, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
-        pos, n, radius_sq, loop, max_num_neighbors, seg_lo, seg_hi, p.slices, p.slice_len, tmp_list, tmp_cnt);
+        pos, n, radius_sq, loop, max_num_neighbors, seg_lo, seg_hi, p.slices, p.slice_len, tmp_list, tmp_cnt, nullptr);
   int rc = status();
   if (rc) return rc;
   radius_merge_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
-      tmp_list, tmp_cnt, n, p.slices, max_num_neighbors, nbr, deg, last, indeg);
+      tmp_list, tmp_cnt, n, p.slices, max_num_neighbors, nbr, deg, last, indeg, nullptr);
+  return status();
+}
+
+size_t nbd_radius_cached_state_bytes(int n, int wide_cap) {
+  if (n <= 0 || wide_cap <= 0) return 0;
+  return 64 + ((size_t)3 * n * sizeof(float) + 63) / 64 * 64 + (size_t)2 * n * sizeof(int) + (size_t)n * wide_cap * sizeof(int);
+}
+
+size_t nbd_radius_cached_workspace_bytes(int n, int wide_cap) { return nbd_radius_search_workspace_bytes(n, wide_cap); }
+
+int nbd_radius_cached_search_f32(const float* pos, int n, float radius_sq, float wide_radius_sq, float moved_sq, int loop,
+                                 int max_num_neighbors, int wide_cap, void* state, size_t state_bytes, int* nbr, int* deg,
+                                 int* last, int* indeg, void* workspace, size_t workspace_bytes, nbd_stream_t stream) {
+  if (n < 0 || max_num_neighbors <= 0 || wide_cap < max_num_neighbors || !(wide_radius_sq >= radius_sq) || !(moved_sq >= 0.f))
+    return NBD_E_BADARG;
+  if (n == 0) return 0;
+  if (!pos || !state || !nbr || !deg || !last || (reinterpret_cast<uintptr_t>(state) & 63) != 0) return NBD_E_BADARG;
+  if (state_bytes < nbd_radius_cached_state_bytes(n, wide_cap)) return NBD_E_WORKSPACE;
+  const RadiusPlan p = plan_radius(n, wide_cap);
+  if (!workspace || workspace_bytes < p.ws) return NBD_E_WORKSPACE;
+  if ((long long)p.slices * n * wide_cap > 0x7fffffffLL * 2) return NBD_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  char* sp = static_cast<char*>(state);
+  int* flags = reinterpret_cast<int*>(sp);                         // [0] rebuild now, [1] built, [2] n of the build
+  float* ref = reinterpret_cast<float*>(sp + 64);
+  int* wdeg = reinterpret_cast<int*>(sp + 64 + ((size_t)3 * n * sizeof(float) + 63) / 64 * 64);
+  int* wlast = wdeg + n;
+  int* wnbr = wlast + n;
+  int* tmp_list = static_cast<int*>(workspace);
+  int* tmp_cnt = tmp_list + (size_t)p.slices * n * wide_cap;
+  radius_disp_kernel<<<1, 1024, 0, st>>>(pos, ref, n, moved_sq, flags);
+  const int waves = ceil_div(n, 128) * p.slices;
+  radius_stream_kernel<false><<<ceil_div(waves, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
+      pos, n, wide_radius_sq, 1, wide_cap, nullptr, nullptr, p.slices, p.slice_len, tmp_list, tmp_cnt, flags);
+  radius_merge_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
+      tmp_list, tmp_cnt, n, p.slices, wide_cap, wnbr, wdeg, wlast, nullptr, flags);
+  radius_snapshot_kernel<<<ceil_div(3 * n, 256), 256, 0, st>>>(pos, ref, n, flags);
+  int rc = status();
+  if (rc) return rc;
+  if (indeg) zero_i32_kernel<<<ceil_div(n, 256), 256, 0, st>>>(indeg, n);
+  radius_refresh_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
+      pos, n, radius_sq, loop, max_num_neighbors, wnbr, wdeg, wide_cap, nbr, deg, last, indeg);
   return status();
 }
 

@@ -112,8 +112,29 @@ def radius_r2(r: float) -> float:
     return float(np.float32(r32 * r32))
 
 
+class RadiusCache:
+    """State of nbd_radius_cached_search_f32 for ONE sequence of similar configurations (a rollout): candidate lists
+    of the first `wide_cap` indices within r + skin of every centre and the positions they were built at. The search
+    result does not depend on it (it is exact either way); it only decides how often the O(n^2) scan runs."""
+    SKIN = 0.05          # in units of r
+    MARGIN = 0.45        # rebuild when a body has moved MARGIN * skin (0.5 would be the exact bound)
+
+    def __init__(self, wide_cap: int = 128):
+        self.wide_cap, self.key, self.state, self.ws = int(wide_cap), None, None, None
+
+    def buffers(self, n, r, cap, dev):
+        L = _lib.lib()
+        wide = max(self.wide_cap, 4 * cap)
+        key = (n, float(r), cap, wide, str(dev))
+        if key != self.key:
+            self.state = torch.zeros(L.nbd_radius_cached_state_bytes(n, wide), dtype=torch.uint8, device=dev)
+            self.ws = torch.empty(max(L.nbd_radius_cached_workspace_bytes(n, wide), 1), dtype=torch.uint8, device=dev)
+            self.key = key
+        return wide, self.state, self.ws
+
+
 def radius_lists(pos: torch.Tensor, r: float, batch=None, loop: bool = False, max_num_neighbors: int = 32,
-                 transpose: bool = True, scan_transpose: bool = False) -> RadiusLists:
+                 transpose: bool = True, scan_transpose: bool = False, cache: RadiusCache | None = None) -> RadiusLists:
     n = pos.shape[0]
     _chk(pos, (n, 3), "pos")
     dev = pos.device
@@ -131,8 +152,20 @@ def radius_lists(pos: torch.Tensor, r: float, batch=None, loop: bool = False, ma
     stream_ok = 0 < need <= (1 << 29)
     ws = torch.empty(need if stream_ok else 1, dtype=torch.uint8, device=dev)
 
+    use_cache = cache is not None and batch is None and cap > 0 and n > 0 and stream_ok
+
     def search(indeg_ptr):
-        if stream_ok:
+        if use_cache:
+            wide, state, cws = cache.buffers(n, r, cap, dev)
+            skin = np.float32(RadiusCache.SKIN) * np.float32(r)
+            rw = np.float32(r) + skin
+            moved = np.float32(RadiusCache.MARGIN) * skin
+            _lib.check(L.nbd_radius_cached_search_f32(pos.data_ptr(), n, r2, float(np.float32(rw * rw)),
+                                                      float(np.float32(moved * moved)), int(loop), cap, wide,
+                                                      state.data_ptr(), state.numel(), nbr.data_ptr(), deg.data_ptr(),
+                                                      last.data_ptr(), indeg_ptr, cws.data_ptr(), cws.numel(), st),
+                       "nbd_radius_cached_search_f32")
+        elif stream_ok:
             _lib.check(L.nbd_radius_search_ws_f32(pos.data_ptr(), n, r2, int(loop), cap, _lib.ptr(lo), _lib.ptr(hi),
                                                   nbr.data_ptr(), deg.data_ptr(), last.data_ptr(), indeg_ptr,
                                                   ws.data_ptr(), need, st), "nbd_radius_search_ws_f32")

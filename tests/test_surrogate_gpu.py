@@ -876,3 +876,81 @@ def test_dataset_graphs_equal_the_per_group_construction(k, tmp_path, gpu_device
         want = graphops.knn_graph(x[:, :3].cuda().contiguous(), k=k, loop=False) if k > 0 else \
             torch.zeros((2, 0), dtype=torch.int64, device="cuda")
         assert torch.equal(g.edge_index, want) and g.edge_index.is_contiguous()
+
+
+@pytest.mark.parametrize("n,cap,loop,wide_cap", [(3000, 32, True, 128), (500, 8, False, 32), (40, 32, True, 128),
+                                                  (2500, 16, True, 64)])
+def test_cached_radius_search_is_exact_over_a_rollout(n, cap, loop, wide_cap, gpu_device):
+    """nbd_radius_cached_search_f32 (the rollout form of the radius search: cached candidate lists within r + skin,
+    re-tested every call, rebuilt when a body has moved too far) against the plain search on the same positions, step
+    after step: small drifts (lists reused), then a few bodies jumping across the system (forced rebuild), with a
+    dense clump whose truncated candidate lists exercise the scan-on path. Every output identical: lists, degrees,
+    last index, and the transposed CSR."""
+    from nbd import graphops
+    rng = np.random.default_rng(n + cap)
+    p = rng.standard_normal((n, 3)).astype(np.float32) * 2.0
+    p[: n // 5] = p[: n // 5] * 0.05 + np.float32(0.3)                    # a clump: hundreds of bodies within r
+    pos = torch.tensor(p, device="cuda")
+    cache = graphops.RadiusCache(wide_cap=wide_cap)
+    r = 0.7
+    for step in range(14):
+        got = graphops.radius_lists(pos, r, None, loop=loop, max_num_neighbors=cap, cache=cache)
+        want = graphops.radius_lists(pos, r, None, loop=loop, max_num_neighbors=cap)
+        assert torch.equal(got.deg, want.deg), step
+        assert torch.equal(got.last, want.last), step
+        mask = torch.arange(cap, device="cuda")[None, :] < want.deg[:, None]
+        assert torch.equal(got.nbr[mask], want.nbr[mask]), step
+        assert torch.equal(got.rowptr, want.rowptr), step
+        e = int(want.rowptr[-1])
+        assert torch.equal(got.centres[:e], want.centres[:e]), step
+        if step % 5 == 4:                                                  # a few bodies jump: the cache must rebuild
+            idx = torch.tensor(rng.choice(n, 3, replace=False), device="cuda")
+            pos[idx] = torch.tensor(rng.standard_normal((3, 3)).astype(np.float32), device="cuda")
+        else:                                                              # a rollout step's drift: far below the skin
+            pos = pos + torch.tensor(rng.standard_normal((n, 3)).astype(np.float32) * 2e-4, device="cuda")
+    # the very same configuration again (nothing moved): still exact, and a model's predict() goes through the cache
+    got = graphops.radius_lists(pos, r, None, loop=loop, max_num_neighbors=cap, cache=cache)
+    want = graphops.radius_lists(pos, r, None, loop=loop, max_num_neighbors=cap)
+    assert torch.equal(got.deg, want.deg) and torch.equal(got.rowptr, want.rowptr)
+
+
+def test_contconv_predict_with_and_without_the_radius_cache(gpu_device):
+    """ContinuousConvModel.predict over a short drifting sequence: the cached radius search changes nothing."""
+    import contconv
+    torch.manual_seed(3)
+    model = contconv.ContinuousConvModel(in_channels=4, continuous_conv_dim=32, continuous_conv_layers=2,
+                                         filter_resolution=[4, 3], radius=0.8, device="cuda").cuda().eval()
+    pos, vel, m = _plummer_pos(900, 4)
+    pos, vel, m = pos.cuda(), vel.cuda(), m.cuda()
+    feat = torch.cat([vel, m[:, None] * 900], 1)
+    for step in range(6):
+        model.use_radius_cache = True
+        a = model.predict(pos, feat)
+        model.use_radius_cache = False
+        b = model.predict(pos, feat)
+        assert torch.equal(a, b), step
+        pos = pos + 1e-3 * vel
+
+
+def test_cached_radius_search_scans_on_behind_a_truncated_list(gpu_device):
+    """A centre whose cached candidate list is truncated AND holds fewer current hits than the cap: its first
+    wide_cap candidates by index all sit in the shell between r and r + skin, its real neighbours have higher indices.
+    The re-test must continue with a plain scan behind the list's last index."""
+    from nbd import graphops
+    rng = np.random.default_rng(9)
+    n, r, cap = 400, 0.7, 16
+    skin = graphops.RadiusCache.SKIN * r
+    d = rng.standard_normal((n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    p = np.zeros((n, 3), dtype=np.float32)
+    p[:200] = (d[:200] * (r + 0.5 * skin)).astype(np.float32)            # shell bodies: in the wide lists, not within r
+    p[200:399] = (d[200:399] * rng.uniform(0.05, 0.6, (199, 1))).astype(np.float32)
+    pos = torch.tensor(p, device="cuda")                                   # body 399 sits at the origin
+    cache = graphops.RadiusCache(wide_cap=64)
+    for step in range(3):
+        got = graphops.radius_lists(pos, r, None, loop=False, max_num_neighbors=cap, cache=cache)
+        want = graphops.radius_lists(pos, r, None, loop=False, max_num_neighbors=cap)
+        assert int(want.deg[399]) == cap and int(want.nbr[399, 0]) >= 200
+        mask = torch.arange(cap, device="cuda")[None, :] < want.deg[:, None]
+        assert torch.equal(got.deg, want.deg) and torch.equal(got.last, want.last) and torch.equal(got.nbr[mask], want.nbr[mask])
+        assert torch.equal(got.rowptr, want.rowptr)
+        pos = pos + torch.tensor(rng.standard_normal((n, 3)).astype(np.float32) * 1e-4, device="cuda")
