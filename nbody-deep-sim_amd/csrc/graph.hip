@@ -443,26 +443,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_merge_kernel(
 // centre's wide list is still farther than r, so the first `cap` hits in ascending index are found inside the
 // list -- unless the list was truncated at W and holds fewer than `cap` current hits, in which case the wave
 // continues with a plain scan behind the list's last index. The result is exactly that of nbd_radius_search_f32.
-//   radius_disp_kernel      ONE workgroup: flags[0] = rebuild needed (never built, or some |pos - ref| too large)
+//   radius_disp_kernel      flags[0] = rebuild needed (never built, or some |pos - ref| too large)
 //   stream + merge (above)  the wide lists; they return at once unless flags[0]
 //   radius_snapshot_kernel  ref = pos, flags[1] = built; only when flags[0]
 //   radius_refresh_kernel   one wave per centre: the wide list re-tested against r
-__global__ __launch_bounds__(1024) void radius_disp_kernel(const float* __restrict__ pos, const float* __restrict__ ref,
-                                                           int n, float thr2, int* __restrict__ flags) {
-  __shared__ int any;
-  if (threadIdx.x == 0) any = flags[1] == 0 || flags[2] != n;     // never built, or built for another n
-  __syncthreads();
-  if (!any) {
-    bool moved = false;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-      const float dx = pos[3 * i] - ref[3 * i], dy = pos[3 * i + 1] - ref[3 * i + 1], dz = pos[3 * i + 2] - ref[3 * i + 2];
-      const float d2 = (dx * dx + dy * dy) + dz * dz;
-      moved |= !(d2 <= thr2);                                      // NaN counts as moved
-    }
-    if (moved) any = 1;                                            // benign race: every writer stores 1
+__global__ __launch_bounds__(256) void radius_disp_kernel(const float* __restrict__ pos, const float* __restrict__ ref,
+                                                          int n, float thr2, int* __restrict__ flags,
+                                                          int* __restrict__ indeg) {
+  {   // the in-degree counters the refresh kernel adds into: zeroed here, one launch less
+    const int z = blockIdx.x * 256 + threadIdx.x;
+    if (indeg && z < n) indeg[z] = 0;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) flags[0] = any;
+  // flags[0] was cleared by the previous call's refresh kernel (or is zero in a fresh state): every thread that finds
+  // a reason to rebuild stores 1 (benign race). A state never built / built for another n has no valid `ref`.
+  if (flags[1] == 0 || flags[2] != n) { if (threadIdx.x == 0) flags[0] = 1; return; }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float dx = pos[3 * i] - ref[3 * i], dy = pos[3 * i + 1] - ref[3 * i + 1], dz = pos[3 * i + 2] - ref[3 * i + 2];
+  const float d2 = (dx * dx + dy * dy) + dz * dz;
+  if (!(d2 <= thr2)) flags[0] = 1;                                 // NaN counts as moved
 }
 
 __global__ __launch_bounds__(256) void radius_snapshot_kernel(const float* __restrict__ pos, float* __restrict__ ref, int n,
@@ -476,7 +475,8 @@ __global__ __launch_bounds__(256) void radius_snapshot_kernel(const float* __res
 __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_refresh_kernel(
     const float* __restrict__ pos, int n, float r2, int loop, int cap, const int* __restrict__ wnbr,
     const int* __restrict__ wdeg, int wcap, int* __restrict__ nbr, int* __restrict__ deg, int* __restrict__ last,
-    int* __restrict__ indeg) {
+    int* __restrict__ indeg, int* __restrict__ flags) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) flags[0] = 0;          // consumed by the launches before this one
   const int i = blockIdx.x * kWavesPerBlock + wave_id();
   if (i >= n) return;
   const int lane = threadIdx.x & 63;
@@ -817,7 +817,7 @@ int nbd_radius_cached_search_f32(const float* pos, int n, float radius_sq, float
   int* wnbr = wlast + n;
   int* tmp_list = static_cast<int*>(workspace);
   int* tmp_cnt = tmp_list + (size_t)p.slices * n * wide_cap;
-  radius_disp_kernel<<<1, 1024, 0, st>>>(pos, ref, n, moved_sq, flags);
+  radius_disp_kernel<<<ceil_div(n, 256), 256, 0, st>>>(pos, ref, n, moved_sq, flags, indeg);
   const int waves = ceil_div(n, 128) * p.slices;
   radius_stream_kernel<false><<<ceil_div(waves, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
       pos, n, wide_radius_sq, 1, wide_cap, nullptr, nullptr, p.slices, p.slice_len, tmp_list, tmp_cnt, flags);
@@ -826,9 +826,8 @@ int nbd_radius_cached_search_f32(const float* pos, int n, float radius_sq, float
   radius_snapshot_kernel<<<ceil_div(3 * n, 256), 256, 0, st>>>(pos, ref, n, flags);
   int rc = status();
   if (rc) return rc;
-  if (indeg) zero_i32_kernel<<<ceil_div(n, 256), 256, 0, st>>>(indeg, n);
   radius_refresh_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
-      pos, n, radius_sq, loop, max_num_neighbors, wnbr, wdeg, wide_cap, nbr, deg, last, indeg);
+      pos, n, radius_sq, loop, max_num_neighbors, wnbr, wdeg, wide_cap, nbr, deg, last, indeg, flags);
   return status();
 }
 
