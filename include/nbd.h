@@ -194,6 +194,13 @@ int nbd_radius_cached_search_f32(const float* pos, int n, float radius_sq, float
                                  int max_num_neighbors, int wide_cap, void* state, size_t state_bytes, int* nbr, int* deg,
                                  int* last, int* indeg, void* workspace, size_t workspace_bytes, nbd_stream_t stream);
 
+/* The transposed lists (rows = neighbour j, entries = the centres that list j, ascending) straight from the cache of
+ * the nbd_radius_cached_search_f32 call that produced `last` on the SAME positions: rowptr = exclusive scan of that
+ * call's indeg. Same result as nbd_radius_transpose_lists, without scatter, atomics or per-row sort. */
+int nbd_radius_cached_transpose_f32(const float* pos, int n, float radius_sq, int loop, int wide_cap, const void* state,
+                                    size_t state_bytes, const int* last, const int* rowptr, int* centres,
+                                    nbd_stream_t stream);
+
 /* radius_graph(pos, r, batch, loop, max_num_neighbors) -- contconv.py:225 -- in padded (ELL) form:
  * nbr[i][0..deg[i]) = the first max_num_neighbors indices j (ascending) with d2 < radius_sq
  * (strict), j == i iff loop; last[i] = the largest listed j (-1 if none). No host sync needed. */

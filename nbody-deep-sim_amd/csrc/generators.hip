@@ -131,9 +131,9 @@ __global__ __launch_bounds__(256) void spiral_kernel(const double* __restrict__ 
 
 size_t cub_temp_bytes(int n) {
   size_t a = 0, b = 0;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const double*)nullptr, (double*)nullptr, (const double*)nullptr,
-                                     (double*)nullptr, n);
-  hipcub::DeviceScan::InclusiveSum(nullptr, b, (const double*)nullptr, (double*)nullptr, n);
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const double*)nullptr, (double*)nullptr, (const double*)nullptr,
+                                           (double*)nullptr, n);      // size queries: nothing runs, nothing can fail
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, (const double*)nullptr, (double*)nullptr, n);
   return ((a > b ? a : b) + 255) & ~(size_t)255;
 }
 

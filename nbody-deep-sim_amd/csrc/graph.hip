@@ -520,6 +520,44 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_refresh_kernel(
   if (lane == 0) { deg[i] = min(hits, cap); last[i] = last_j; }
 }
 
+// The transposed lists from the same cache: "c lists j" <=> d2(c, j) < r2, (loop or c != j) and j <= last[c] (a list
+// is the first `cap` hits in ascending index), and the distance is symmetric, so every centre that can list j is in
+// j's own candidate list -- or, if that list is truncated, behind its last index. One wave per node walks its
+// candidates in ascending index and writes the row in order: no scatter, no atomics, no per-row sort.
+__global__ __launch_bounds__(64 * kWavesPerBlock) void radius_transpose_cached_kernel(
+    const float* __restrict__ pos, int n, float r2, int loop, const int* __restrict__ wnbr, const int* __restrict__ wdeg,
+    int wcap, const int* __restrict__ last, const int* __restrict__ rowptr, int* __restrict__ centres) {
+  const int j = blockIdx.x * kWavesPerBlock + wave_id();
+  if (j >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float xj = pos[3 * j], yj = pos[3 * j + 1], zj = pos[3 * j + 2];
+  const int wd = wdeg[j];
+  int* row = centres + rowptr[j];
+  int cnt = 0;
+  auto take = [&](int c, bool ok) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+    if (ok) row[cnt + __popcll(m & ((1ull << lane) - 1ull))] = c;
+    cnt += __popcll(m);
+  };
+  for (int base = 0; base < wd; base += 64) {
+    const int t = base + lane;
+    int c = -1;
+    bool ok = false;
+    if (t < wd) {
+      c = wnbr[(size_t)j * wcap + t];
+      ok = dist2(pos, c, xj, yj, zj) < r2 && (loop || c != j) && j <= last[c];
+    }
+    take(c, ok);
+  }
+  if (wd >= wcap) {
+    for (int base = wnbr[(size_t)j * wcap + wcap - 1] + 1; base < n; base += 64) {
+      const int c = base + lane;
+      const bool ok = c < n && dist2(pos, c, xj, yj, zj) < r2 && (loop || c != j) && j <= last[c];
+      take(c, ok);
+    }
+  }
+}
+
 // ---- transpose of the capped lists: for node j, the centres c (ascending) whose list contains j.
 // "c lists j"  <=>  d2(c,j) < r2, (loop or c != j), same segment, and j <= last[c]  (lists are the
 // first `cap` hits in ascending index, so membership is a comparison, not a search).
@@ -828,6 +866,21 @@ int nbd_radius_cached_search_f32(const float* pos, int n, float radius_sq, float
   if (rc) return rc;
   radius_refresh_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
       pos, n, radius_sq, loop, max_num_neighbors, wnbr, wdeg, wide_cap, nbr, deg, last, indeg, flags);
+  return status();
+}
+
+int nbd_radius_cached_transpose_f32(const float* pos, int n, float radius_sq, int loop, int wide_cap, const void* state,
+                                    size_t state_bytes, const int* last, const int* rowptr, int* centres,
+                                    nbd_stream_t stream) {
+  if (n < 0 || wide_cap <= 0) return NBD_E_BADARG;
+  if (n == 0) return 0;
+  if (!pos || !state || !last || !rowptr || !centres || (reinterpret_cast<uintptr_t>(state) & 63) != 0) return NBD_E_BADARG;
+  if (state_bytes < nbd_radius_cached_state_bytes(n, wide_cap)) return NBD_E_WORKSPACE;
+  const char* sp = static_cast<const char*>(state);
+  const int* wdeg = reinterpret_cast<const int*>(sp + 64 + ((size_t)3 * n * sizeof(float) + 63) / 64 * 64);
+  const int* wnbr = wdeg + 2 * (size_t)n;
+  radius_transpose_cached_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, (hipStream_t)stream>>>(
+      pos, n, radius_sq, loop, wnbr, wdeg, wide_cap, last, rowptr, centres);
   return status();
 }
 

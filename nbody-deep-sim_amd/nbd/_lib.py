@@ -107,6 +107,8 @@ SIGNATURES = {
     "nbd_radius_cached_workspace_bytes": (c_size_t, [c_int, c_int]),
     "nbd_radius_cached_search_f32": (c_int, [c_void_p, c_int, c_float, c_float, c_float, c_int, c_int, c_int, c_void_p,
                                              c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nbd_radius_cached_transpose_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p,
+                                                c_void_p, c_void_p, c_void_p]),
     "nbd_radius_search_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "nbd_radius_search_workspace_bytes": (c_size_t, [c_int, c_int]),

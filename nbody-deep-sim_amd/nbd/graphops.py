@@ -182,7 +182,12 @@ def radius_lists(pos: torch.Tensor, r: float, batch=None, loop: bool = False, ma
             centres = torch.empty(max(n * cap, 1), dtype=torch.int32, device=dev)   # E <= n*cap: no sync needed
             search(indeg.data_ptr())
             _lib.check(L.nbd_exclusive_scan_i32(indeg.data_ptr(), n, rowptr.data_ptr(), st), "exclusive_scan")
-            if scan_transpose:      # O(N^2) scanning transpose (kept as the independent cross-check)
+            if use_cache and not scan_transpose:   # rows straight from the candidate lists, already in order
+                wide, state, _ = cache.buffers(n, r, cap, dev)
+                _lib.check(L.nbd_radius_cached_transpose_f32(pos.data_ptr(), n, r2, int(loop), wide, state.data_ptr(),
+                                                             state.numel(), last.data_ptr(), rowptr.data_ptr(),
+                                                             centres.data_ptr(), st), "nbd_radius_cached_transpose_f32")
+            elif scan_transpose:    # O(N^2) scanning transpose (kept as the independent cross-check)
                 _lib.check(L.nbd_radius_transpose_fill_f32(pos.data_ptr(), n, r2, int(loop), _lib.ptr(lo), _lib.ptr(hi),
                                                            last.data_ptr(), rowptr.data_ptr(), centres.data_ptr(), st),
                            "radius_transpose_fill")
