@@ -153,6 +153,8 @@ def radius_lists(pos: torch.Tensor, r: float, batch=None, loop: bool = False, ma
     ws = torch.empty(need if stream_ok else 1, dtype=torch.uint8, device=dev)
 
     use_cache = cache is not None and batch is None and cap > 0 and n > 0 and stream_ok
+    if use_cache:       # the rebuild's slice lists grow with the wide cap: keep them under 1 GiB or search plainly
+        use_cache = L.nbd_radius_cached_workspace_bytes(n, max(cache.wide_cap, 4 * cap)) <= (1 << 30)
 
     def search(indeg_ptr):
         if use_cache:
