@@ -954,3 +954,29 @@ def test_cached_radius_search_scans_on_behind_a_truncated_list(gpu_device):
         assert torch.equal(got.deg, want.deg) and torch.equal(got.last, want.last) and torch.equal(got.nbr[mask], want.nbr[mask])
         assert torch.equal(got.rowptr, want.rowptr)
         pos = pos + torch.tensor(rng.standard_normal((n, 3)).astype(np.float32) * 1e-4, device="cuda")
+
+
+def test_cached_radius_search_over_a_real_trajectory(gpu_device):
+    """600 leapfrog steps of a 4096-body Plummer sphere (the HIP integrator, dt = 0.01: bodies cross the skin many
+    times, so the cache rebuilds repeatedly at its own pace): cached and plain radius search agree at every step,
+    lists and transposed lists alike."""
+    from galaxify import simulation
+    from nbd import graphops
+    from nbd.plummer import generate_plummer
+    n = 4096
+    p, v, m = generate_plummer(n, seed=8)
+    sim = simulation.LeapFrogSimulator(positions=p * 3.0, velocities=v, masses=m, g_const=1.0, softening=0.1, dt=0.01,
+                                       calc_energy=False, device="cuda")
+    cache = graphops.RadiusCache()
+    arange = torch.arange(32, device="cuda")[None, :]
+    for step in range(600):
+        sim.step()
+        pos = sim.positions
+        got = graphops.radius_lists(pos, 1.0, None, loop=True, max_num_neighbors=32, cache=cache)
+        if step % 3 == 0:
+            want = graphops.radius_lists(pos, 1.0, None, loop=True, max_num_neighbors=32)
+            mask = arange < want.deg[:, None]
+            e = int(want.rowptr[-1])
+            ok = (torch.equal(got.deg, want.deg) and torch.equal(got.last, want.last) and torch.equal(got.nbr[mask], want.nbr[mask])
+                  and torch.equal(got.rowptr, want.rowptr) and torch.equal(got.centres[:e], want.centres[:e]))
+            assert ok, step
