@@ -70,6 +70,12 @@ __device__ __forceinline__ void matvec(const float (&in)[RIN], const float* __re
 
 namespace {
 
+#ifdef NBD_GNN_TRACE
+__device__ long long* g_gnn_trace = nullptr;
+#define GT(i) if (lane == 0 && g_gnn_trace) g_gnn_trace[((size_t)blockIdx.x * WPB + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define GT(i)
+#endif
 template <int R, int FM, int WPB>      // FM: on-the-fly feature count the loops are unrolled for (4 or kFMax); WPB: waves (= nodes in flight) per workgroup
 __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer_args a) {
   extern __shared__ float smem[];
@@ -81,9 +87,11 @@ __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_ep = (a.epilogue == NBD_GNN_NEXT_PQ || folded) ? a.ep_out : 0;
+  GT(0)
   for (int idx = threadIdx.x; !folded && idx < KP * H; idx += 64 * WPB) w2t[idx] = idx < H * H ? a.w2t[idx] : 0.f;
   for (int idx = threadIdx.x; idx < KP * n_ep; idx += 64 * WPB) ept[idx] = idx < H * n_ep ? a.w_ep[idx] : 0.f;
   __syncthreads();
+  GT(1)
 
   // on-the-fly P/Q weights of this lane's channels (first layer, F <= 8)
   float wp[R][FM], wq[R][FM], bp[R];
@@ -171,6 +179,7 @@ __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer
         }
       }
     }
+    GT(2)
     if (a.aggr == 1) {
       const float inv = 1.0f / (float)max(deg, 1);
 #pragma unroll
@@ -187,6 +196,7 @@ __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer
       matvec<R, 2 * R>(s, ept, n_ep, lane, o);
 #pragma unroll
       for (int r = 0; r < 2 * R; ++r) { const int c = r * 64 + lane; if (c < n_ep) a.out[(size_t)node * a.ldout + c] = o[r]; }
+      GT(3)
       continue;
     }
     float y[R];
@@ -241,16 +251,30 @@ __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer
 #pragma unroll
         for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; if (h < H) a.out[(size_t)node * a.ldout + E + h] = zy[r]; }
       } else {  // FINAL_HEAD: out[d] = sum_c z[c] Wh[d][c] + bh[d]
-        for (int d = 0; d < a.ep_out; ++d) {
-          const float* wrow = a.w_ep + (size_t)d * C;
-          float part = 0.f;
+        // all heads at once: their weight rows are fetched together and their wave sums advance in lock step (same
+        // arithmetic, same order per head; measured: no change on the captured step -- the ~7 us this kernel spends
+        // behind its edge loop, in-kernel stamps with -DNBD_GNN_TRACE, are not the head's)
+        float part[kMaxOut];
 #pragma unroll
-          for (int r = 0; r < kMaxZR; ++r) { const int c = r * 64 + lane; if (c < E) part = __builtin_fmaf(ze[r], wrow[c], part); }
+        for (int d = 0; d < kMaxOut; ++d) {
+          part[d] = 0.f;
+          if (d < a.ep_out) {                                 // wave-uniform
+            const float* wrow = a.w_ep + (size_t)d * C;
 #pragma unroll
-          for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; if (h < H) part = __builtin_fmaf(zy[r], wrow[E + h], part); }
-          part = wave_sum(part);
-          if (lane == 0) {
-            const float o_d = part + a.b_ep[d];
+            for (int r = 0; r < kMaxZR; ++r) { const int c = r * 64 + lane; if (c < E) part[d] = __builtin_fmaf(ze[r], wrow[c], part[d]); }
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; if (h < H) part[d] = __builtin_fmaf(zy[r], wrow[E + h], part[d]); }
+          }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+          for (int d = 0; d < kMaxOut; ++d)
+            if (d < a.ep_out) part[d] += __shfl_xor(part[d], off);
+        }
+#pragma unroll
+        for (int d = 0; d < kMaxOut; ++d) {
+          if (d < a.ep_out && lane == 0) {
+            const float o_d = part[d] + a.b_ep[d];
             a.out[(size_t)node * a.ldout + d] = o_d;
             if (a.kick_vel) {                              // v += c * a, rounded as the separate kick kernel rounds it
               float* v = a.kick_vel + (size_t)node * a.ep_out + d;
@@ -268,6 +292,10 @@ inline int status() { hipError_t e = hipGetLastError(); return e == hipSuccess ?
 }  // namespace
 
 extern "C" {
+
+#ifdef NBD_GNN_TRACE
+int nbd_debug_gnn_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gnn_trace), &buf, sizeof(buf)); }
+#endif
 
 int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
   if (!args) return NBD_E_BADARG;
