@@ -47,7 +47,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // y[out] += sum_k in_k * Wt[k][out]  (in: lane = k over RIN registers, zero beyond K; Wt rows are
-// zero-padded to 64*RIN in LDS, so the trip count is a compile-time constant and the loop unrolls)
+// zero-padded to 64*RIN in LDS, so the trip count is a compile-time constant and the loop unrolls).
+// The LDS reads carry no per-lane predicate: with `if (o < n_out)` around them hipcc emitted, per k, a branch, the
+// ds_read, an s_waitcnt lgkmcnt(0) and the fma -- 64 serialised LDS latencies, 4.0 us of an 18.7 us layer kernel
+// (in-kernel stamps); unpredicated, eight reads are in flight per wait.
 template <int RIN, int ROUT>
 __device__ __forceinline__ void matvec(const float (&in)[RIN], const float* __restrict__ wt, int n_out, int lane,
                                        float (&out)[ROUT]) {
@@ -58,10 +61,8 @@ __device__ __forceinline__ void matvec(const float (&in)[RIN], const float* __re
       const float v = lane_bcast(in[r], l);
       const float* row = wt + (r * 64 + l) * n_out;
 #pragma unroll
-      for (int ro = 0; ro < ROUT; ++ro) {
-        const int o = ro * 64 + lane;
-        if (o < n_out) out[ro] = __builtin_fmaf(v, row[o], out[ro]);
-      }
+      for (int ro = 0; ro < ROUT; ++ro)       // lanes past n_out re-read the row's last entry (their result is never stored):
+        out[ro] = __builtin_fmaf(v, row[min(ro * 64 + lane, n_out - 1)], out[ro]);   // a guard here cost one LDS latency per k
     }
   }
 }
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer
 #pragma unroll
     for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; y[r] = h < H ? beta * a.b2[h] : 0.f; }
     matvec<R, R>(s, w2t, H, lane, y);
+    GT(4)
 
     if (a.epilogue == NBD_GNN_WRITE_X) {
 #pragma unroll
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer
         const int h = r * 64 + lane;
         zy[r] = h < H ? (y[r] - mean) * rstd * a.ln_g[E + h] + a.ln_b[E + h] : 0.f;
       }
+      GT(5)
       if (a.epilogue == NBD_GNN_FINAL_LN) {
 #pragma unroll
         for (int r = 0; r < kMaxZR; ++r) { const int c = r * 64 + lane; if (c < E) a.out[(size_t)node * a.ldout + c] = ze[r]; }
@@ -252,8 +255,8 @@ __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer
         for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; if (h < H) a.out[(size_t)node * a.ldout + E + h] = zy[r]; }
       } else {  // FINAL_HEAD: out[d] = sum_c z[c] Wh[d][c] + bh[d]
         // all heads at once: their weight rows are fetched together and their wave sums advance in lock step (same
-        // arithmetic, same order per head; measured: no change on the captured step -- the ~7 us this kernel spends
-        // behind its edge loop, in-kernel stamps with -DNBD_GNN_TRACE, are not the head's)
+        // arithmetic, same order per head; measured: no change on the captured step). Un-predicating the LayerNorm /
+        // head loads as well (clamped indices) was WORSE: hipcc hoisted them all, 128 VGPRs + scratch, step 66 -> 82 us.
         float part[kMaxOut];
 #pragma unroll
         for (int d = 0; d < kMaxOut; ++d) {
@@ -283,6 +286,7 @@ __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer
           }
         }
       }
+      GT(6)
     }
   }
 }

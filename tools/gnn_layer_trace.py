@@ -29,7 +29,10 @@ t0 = t[:, 0].min()
 out = {"waves": int(len(t)), "start_us_p50_max": [float(np.percentile((t[:,0]-t0)/100,50)), float(((t[:,0]-t0)/100).max())],
        "staging_us_mean": float(((t[:,1]-t[:,0])/100).mean()), "edges_us_mean": float(((t[:,2]-t[:,1])/100).mean()),
        "edges_done_at_us_p50_max": [float(np.percentile((t[:,2]-t0)/100,50)), float(((t[:,2]-t0)/100).max())]}
-fin = t[:, 3] != 0
+if (t[:, 6] != 0).any():
+    out["matvec_us_mean"] = float(((t[:,4]-t[:,2])/100).mean()); out["layernorm_us_mean"] = float(((t[:,5]-t[:,4])/100).mean())
+    out["head_us_mean"] = float(((t[:,6]-t[:,5])/100).mean()); out["end_at_us_p50_max"] = [float(np.percentile((t[:,6]-t0)/100,50)), float(((t[:,6]-t0)/100).max())]
+fin = np.zeros(len(t), dtype=bool)
 if fin.any():
     out["matvec_us_mean_folded_layers"] = float(((t[fin,3]-t[fin,2])/100).mean())
 print(json.dumps(out))
