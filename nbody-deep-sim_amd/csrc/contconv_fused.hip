@@ -683,8 +683,10 @@ FusedPlan plan_fused(int n, int n_cells, int O) {
   FusedPlan p;
   p.tiles = ceil_div(n, TN);
   p.colgroups = ceil_div(O, 128);
-  // ~4 workgroups per CU over the launch so that tiles of different density balance; <= 64 cells per chunk
-  int chunks = ceil_div(1024, p.tiles * p.colgroups);
+  // ~2 workgroups per CU over the launch (a workgroup carries ~10 us of fixed cost: fill, drain, 64 KiB of partial
+  // sums; measured at N = 16 384, D = 6 / 4: 3 / 4 / 5 / 6 / 8 / 12 / 16 chunks 0.512 / 0.465 / 0.495 / 0.480 /
+  // 0.485 / 0.497 / 0.510 and 0.372 / 0.315 / 0.319 / 0.319 / 0.317 / 0.329 / 0.347 ms); <= 64 cells per chunk
+  int chunks = ceil_div(512, p.tiles * p.colgroups);
   if (chunks > 16) chunks = 16;                      // bounds the partial-sum traffic of small problems
   if (chunks > n_cells) chunks = n_cells;
   if (chunks < ceil_div(n_cells, CHUNK_MAX)) chunks = ceil_div(n_cells, CHUNK_MAX);
