@@ -76,11 +76,14 @@ __device__ __forceinline__ Geo edge_geo(const float* __restrict__ pos, int c, fl
 __device__ __forceinline__ int corner_cell(const Geo& g, int corner, int D, const int* __restrict__ cell_map, float* w) {
   const int ax = corner & 1, ay = (corner >> 1) & 1, az = corner >> 2;
   const int cx = g.ix + ax, cy = g.iy + ay, cz = g.iz + az;
-  if (cx < 0 || cx >= D || cy < 0 || cy >= D || cz < 0 || cz >= D) return -1;
-  const int cell = (cz * D + cy) * D + cx;                           // filters[z][y][x] (contconv.py:62-75)
+  // branch-free (the map is read at a clamped index whatever the corner): eight of these run back to back per edge,
+  // and an early return made every map read wait for the previous corner's
+  const bool in = (unsigned)cx < (unsigned)D && (unsigned)cy < (unsigned)D && (unsigned)cz < (unsigned)D;
+  const int cell = in ? (cz * D + cy) * D + cx : 0;                  // filters[z][y][x] (contconv.py:62-75)
   const float wxy = (ax ? g.tx : 1.0f - g.tx) * (ay ? g.ty : 1.0f - g.ty);
   *w = wxy * ((az ? g.tz : 1.0f - g.tz) * g.window);
-  return cell_map ? cell_map[cell] : cell;
+  const int k = cell_map ? cell_map[cell] : cell;
+  return in ? k : -1;
 }
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
@@ -120,6 +123,12 @@ struct PairJob {
 };
 struct PairJobs { PairJob j[NBD_CC_MAX_RES]; };
 
+#ifdef NBD_PAIRS_TRACE
+__device__ long long* g_pairs_trace = nullptr;
+#define PT(i) if (threadIdx.x == 0 && g_pairs_trace) g_pairs_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define PT(i)
+#endif
 constexpr int PAIR_THREADS = 1024;
 constexpr int SEG = 16, NSEG = TN / SEG;                   // node segments of the two-level scan
 __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
@@ -145,6 +154,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   const int tile = blockIdx.x, n0 = tile * TN, n_here = min(TN, n - n0);
   const float half = (float)(D - 1) / 2.0f;
 
+  PT(0)
   if (tid <= TN) rp[tid] = rowptr[min(n0 + tid, n)];
   if (tid < D * D * D) cmap[tid] = job.cell_map ? job.cell_map[tid] : tid;
   if (tid == 0) next_node = 0;
@@ -153,6 +163,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   const int e_t = rp[0], e_end = rp[n_here];
   const size_t row_base = (size_t)8 * e_t + tile, pair_base = (size_t)8 * e_t;
 
+  PT(1)
   // ---- A: counts (lane = edge)
   for (int e = e_t + tid; e < e_end; e += PAIR_THREADS) {
     int lo = 0, hi = n_here;                               // largest nl with rp[nl] <= e
@@ -169,6 +180,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   }
   __syncthreads();
 
+  PT(2)
   // ---- B: per cell, prefix over the nodes of the tile, in 16-node segments
   const unsigned short* cnt16 = reinterpret_cast<const unsigned short*>(cnt32);
   for (int w = tid; w < NSEG * n_cells; w += PAIR_THREADS) {
@@ -191,6 +203,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   }
   __syncthreads();
 
+  PT(3)
   // ---- B2: prefix over cells (one wave; cells in chunks of 64 with a running carry)
   if (wave == 0) {
     int row_carry = 0, pair_carry = 0;
@@ -210,6 +223,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   }
   __syncthreads();
 
+  PT(4)
   // ---- B3: row records (wave = nodes, lanes = cells: no division)
   for (int nl = wave; nl < n_here; nl += PAIR_THREADS / 64)
     for (int k = lane; k < n_cells; k += 64)
@@ -217,6 +231,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
         rows[row_base + cell_rowbase[k] + rowidx[nl * kc + k]] = make_int2(nl, cell_pairbase[k] + (int)pwithin[nl * kc + k]);
   __syncthreads();          // B3 reads the counters that C counts down
 
+  PT(5)
   // ---- C: place the pairs (counters count down: slot = old - 1). A half-wave takes the next node from the
   // counter; its 32 lanes walk the node's edges in order.
   const int hl = lane & 31;
@@ -239,18 +254,33 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
       const float src[3] = {sx, sy, sz};
       const Geo g = edge_geo(src, 0, xn, yn, zn, r2max, half);
       if (g.window == 0.f) continue;
+      // the eight counters are decremented by eight UNCONDITIONAL returning atomics issued together (a corner that
+      // falls outside subtracts 0 from cell 0's word), then the eight stores: with `if (k < 0) continue` in front of
+      // each, every corner paid its own LDS round trip -- this phase was 43 of the densest tile's 74 us
+      int kk[8];
+      float ww[8];
+      unsigned old[8];
+#pragma unroll
+      for (int corner = 0; corner < 8; ++corner) kk[corner] = corner_cell(g, corner, D, cmap, &ww[corner]);
 #pragma unroll
       for (int corner = 0; corner < 8; ++corner) {
-        float w;
-        const int k = corner_cell(g, corner, D, cmap, &w);
+        const int k = max(kk[corner], 0);
+        old[corner] = atomicSub(&cnt32[(nl * kc + k) >> 1], kk[corner] >= 0 ? 1u << (16 * (k & 1)) : 0u);
+      }
+#pragma unroll
+      for (int corner = 0; corner < 8; ++corner) {
+        const int k = kk[corner];
         if (k < 0) continue;
-        const unsigned old = atomicSub(&cnt32[(nl * kc + k) >> 1], 1u << (16 * (k & 1)));
-        const int slot = (int)((old >> (16 * (k & 1))) & 0xffffu) - 1;
+        const int slot = (int)((old[corner] >> (16 * (k & 1))) & 0xffffu) - 1;
         const size_t at = (size_t)pair_base + cell_pairbase[k] + pwithin[nl * kc + k] + slot;
-        psrc[at] = c_cur; pwgt[at] = w;
+        psrc[at] = c_cur; pwgt[at] = ww[corner];
       }
     }
   }
+#ifdef NBD_PAIRS_TRACE
+  __syncthreads();
+  PT(6)
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------- fused conv
@@ -702,6 +732,10 @@ extern "C" {
 
 #ifdef NBD_CC_TRACE
 int nbd_debug_cc_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cc_trace), &buf, sizeof(buf)); }
+#endif
+
+#ifdef NBD_PAIRS_TRACE
+int nbd_debug_pairs_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pairs_trace), &buf, sizeof(buf)); }
 #endif
 
 int nbd_contconv_fused_supported(int in_channels, int out_channels, int n_cells) {
