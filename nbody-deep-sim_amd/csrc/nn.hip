@@ -329,6 +329,34 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   if (i >= n) return;
   const int lane = threadIdx.x & 63;
   const float* x = X + (size_t)i * ldx;
+  if (C <= 256) {
+    // the row in registers: four loads issued together (clamped index, masked value) instead of three passes of
+    // dependent loads over the same row (13.6 -> see tools/ubench_mlp.py); same sums in the same order
+    float xv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int c = r * 64 + lane; const float t = x[min(c, C - 1)]; xv[r] = c < C ? t : 0.f; }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s += xv[r];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float d = xv[r] - mean; v += (r * 64 + lane < C) ? d * d : 0.f; }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const float rstd = 1.0f / sqrtf(v / (float)C + eps);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = r * 64 + lane;
+      if (c < C) {
+        float y = (xv[r] - mean) * rstd;
+        if (gamma) y = y * gamma[c];
+        if (beta) y = y + beta[c];
+        Y[(size_t)i * ldy + c] = y;
+      }
+    }
+    return;
+  }
   float s = 0.f;
   for (int c = lane; c < C; c += 64) s += x[c];
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
