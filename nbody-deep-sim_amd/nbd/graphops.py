@@ -119,7 +119,7 @@ class RadiusCache:
     SKIN = 0.05          # in units of r
     MARGIN = 0.45        # rebuild when a body has moved MARGIN * skin (0.5 would be the exact bound)
 
-    def __init__(self, wide_cap: int = 128):
+    def __init__(self, wide_cap: int = 192):      # measured on the ContinuousConv rollout step (N = 16 384): 128 / 192 / 256 -> 1.021 / 1.006 / 1.096 ms
         self.wide_cap, self.key, self.state, self.ws = int(wide_cap), None, None, None
 
     def buffers(self, n, r, cap, dev):
