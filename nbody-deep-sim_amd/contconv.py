@@ -220,6 +220,8 @@ class ContinuousConvModel(nn.Module):
         self._cache = _WeightCache(self)
         self._radius_cache = None
         self.use_radius_cache = True
+        self._side_stream = None
+        self.overlap_encoder = True
         self.to(device)
 
     def _build_weights(self):
@@ -240,17 +242,28 @@ class ContinuousConvModel(nn.Module):
         x = torch.cat((x7[:, :3], x7[:, 6:]), dim=-1) if self.in_channels == 4 else x7
         x = x.to(torch.float32).contiguous()
         pos = x[:, :3].contiguous()
-        lists = graphops.radius_lists(pos, self.radius, getattr(data, "batch", None), loop=self.self_loops,
-                                      max_num_neighbors=self.max_num_neighbors,
-                                      cache=getattr(data, "_radius_cache", None))      # predict(): a rollout's search
         c = self.continuous_conv_dim
         enc_dim = self.in_channels if w["enc"] is None else c
         cat_buf = torch.empty((n, enc_dim + c), dtype=torch.float32, device=x7.device)
         enc_view, conv_view = cat_buf[:, :enc_dim], cat_buf[:, enc_dim:]
-        if w["enc"] is None:
+        # the node encoder needs only x, the graph only the positions: the encoder's three small launches run on a
+        # second stream beside the neighbour search and the pair lists (fork / join; captured as such in a hipGraph)
+        cur = torch.cuda.current_stream(x7.device)
+        side = None
+        if self.overlap_encoder and w["enc"] is not None and n > 0:
+            if self._side_stream is None or self._side_stream.device != x7.device:
+                self._side_stream = torch.cuda.Stream(device=x7.device)
+            side = self._side_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                run_chain(x, w["enc"], out_last=enc_view)
+        elif w["enc"] is None:
             enc_view.copy_(x)
         else:
             run_chain(x, w["enc"], out_last=enc_view)
+        lists = graphops.radius_lists(pos, self.radius, getattr(data, "batch", None), loop=self.self_loops,
+                                      max_num_neighbors=self.max_num_neighbors,
+                                      cache=getattr(data, "_radius_cache", None))      # predict(): a rollout's search
         h = enc_view
         # pair lists: one launch for all the filter resolutions of the model (layers share the graph)
         pair_cache = {}
@@ -266,6 +279,8 @@ class ContinuousConvModel(nn.Module):
                                                  float(np.float32(self.radius ** 2)), jobs[lo:lo + 4])
                 pair_cache.update(zip(keys[lo:lo + 4], got))
         inv_deg = nnops.degree_scale(lists.rowptr, n, 0, x7.device) if n > 0 else None     # once for all layers
+        if side is not None:
+            cur.wait_stream(side)                                                          # the layers read the encoder's output
         for li, layer in enumerate(self.contconv):
             last = li == len(self.contconv) - 1
             pairs = pair_cache.get((layer.filter_resolution, float(layer.radius))) if layer.fused_ok() else None
