@@ -239,9 +239,13 @@ class ContinuousConvModel(nn.Module):
             raise NbdError("ContinuousConvModel.forward: data must live on the GPU (no CPU path)")
         w = self._cache.get(self._build_weights)
         n = x7.shape[0]
-        x = torch.cat((x7[:, :3], x7[:, 6:]), dim=-1) if self.in_channels == 4 else x7
-        x = x.to(torch.float32).contiguous()
-        pos = x[:, :3].contiguous()
+        pre = getattr(data, "_x_pos", None)        # predict() hands over [pos | mass] and pos as it built them
+        if pre is not None:
+            x, pos = pre
+        else:
+            x = torch.cat((x7[:, :3], x7[:, 6:]), dim=-1) if self.in_channels == 4 else x7
+            x = x.to(torch.float32).contiguous()
+            pos = x[:, :3].contiguous()
         c = self.continuous_conv_dim
         enc_dim = self.in_channels if w["enc"] is None else c
         cat_buf = torch.empty((n, enc_dim + c), dtype=torch.float32, device=x7.device)
@@ -301,7 +305,15 @@ class ContinuousConvModel(nn.Module):
             # far enough to matter (graphops.RadiusCache; the result is exact either way)
             if getattr(self, "_radius_cache", None) is None:
                 self._radius_cache = graphops.RadiusCache()
-            data = Data(x=torch.cat((pos, feat), dim=-1), batch=None)
+            if (self.in_channels == 4 and pos.dtype == torch.float32 and feat.dtype == torch.float32 and pos.is_cuda
+                    and pos.dim() == 2 and pos.shape[1] == 3 and feat.dim() == 2 and feat.shape[1] >= 4
+                    and not self.training):
+                # the model input is [pos | mass] (contconv.py:219-220): built directly -- the reference's route
+                # (cat to 7 columns, slice, cat again, two contiguous copies) is four more launches per step
+                data = Data(x=pos, batch=None)                      # .x is only consulted for its device and row count
+                data._x_pos = (torch.cat((pos, feat[:, 3:]), dim=-1), pos.contiguous())
+            else:
+                data = Data(x=torch.cat((pos, feat), dim=-1), batch=None)
             data._radius_cache = self._radius_cache if self.use_radius_cache else None
             return self.forward(data)
 
