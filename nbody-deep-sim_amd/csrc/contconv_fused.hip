@@ -15,20 +15,28 @@
 //                            the packed "rows" (distinct nodes) of each (tile, cell) and their pair ranges. ~24 B of
 //                            index data per pair, once per graph; all resolutions of a model in one launch (60 us at the
 //                            published shape for D = 6 and D = 4 together).
-//   nbd_contconv_fused_f32   per (tile, chunk of cells), 16 waves: eight producer waves gather the pairs' feature
-//                            rows (pair records by scalar loads, rows by buffer loads with the row offset in an
-//                            SGPR: no vector-ALU work per gathered row but the weighted add) and sum them into
-//                            packed A rows in LDS (32 rows per step, a ring of four buffers, two waves per buffer); eight consumer waves multiply each step by 16 columns
-//                            of the cell's I x O filter with fp32 MFMA (v_mfma_f32_16x16x4_f32; the fragment sits in
-//                            registers, pre-shuffled by the host so that every lane loads it with one dwordx4 per 16
-//                            k, the next cell's being fetched meanwhile) and add the 32 x 16 result into a
-//                            128-node x 128-column accumulator in LDS. Producers and consumers meet through LDS
-//                            flags only (no workgroup barrier inside the loop). Cell chunks of one tile are
-//                            summed in fixed order by the finishing kernel (scale, activation). No float atomics:
-//                            deterministic.
-// Measured at the published shape (tools/bench_contconv.py, profiles/r02_contconv_*): layer D = 6 0.47 ms, D = 4
-// 0.32 ms against 1.09 / 0.54 ms for binning + dense GEMM; executed 53.7 GFLOP per step (32-row granularity; the
-// touched blocks alone are 38.1) against 120; the binned matrix: 0 bytes of HBM traffic against 2.7 GB.
+//                            It also cuts every (tile, cell)'s rows into STEPS of 16 (one MFMA tile of rows) and writes
+//                            the tile's step list + step count: the unit of work of the fused kernel.
+//   nbd_contconv_fused_f32   PERSISTENT workgroups (one per CU, 16 waves) over the global step sequence (tile-major, cell,
+//                            16-row slice), cut into gridDim.x equal contiguous ranges by STEP count ("stream-K": the
+//                            matrix work of every workgroup is equal whatever the tiles' densities). Eight producer
+//                            waves, one per buffer of an eight-deep LDS ring: a producer gathers the feature rows of
+//                            its step's pairs (pair records staged once per 64 pairs in wave-private LDS and read back
+//                            as broadcasts: no scalar loads, no dependent round trip per batch of rows; rows by buffer
+//                            loads, four batches of 8 in flight) and sums them into the step's 16 packed A rows. Eight
+//                            consumer waves multiply each step by 16 columns of the cell's I x O filter with fp32 MFMA
+//                            (v_mfma_f32_16x16x4_f32, operands swapped so that a lane ends up with 4 consecutive output
+//                            columns of ONE node: the scatter into the 128-node x 128-column LDS accumulator is one
+//                            128-bit read-modify-write per lane; the filter fragment sits in registers, pre-shuffled by
+//                            the host, the next cell's fetched meanwhile). Producers and consumers meet through LDS flags
+//                            only (no workgroup barrier inside a range). When a range crosses into the next tile the
+//                            consumers write their columns of the accumulator to partial slot (workgroup + tile) -- a
+//                            merge-path numbering, unique and independent of timing -- and the finishing kernel sums a
+//                            tile's slots in workgroup order (scale, activation). No float atomics: deterministic.
+// Round 2's form (one workgroup per (tile, chunk of cells), 32-row steps, ring of four, pair records by scalar
+// loads one stage ahead) measured 0.475 / 0.32 ms per layer (D = 6 / 4) at the published shape with the MFMA pipe
+// 47 % busy: its producers paid one exposed scalar-load round trip per 8 gathered rows and ~9 us of dependent
+// latencies per half-step, and every workgroup 11 us of fill / drain.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -45,11 +53,16 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int status() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : (int)e; }
 
 constexpr int TN = NBD_CC_TILE;      // nodes per tile (128)
-constexpr int SUB = 32;              // packed rows per MFMA step
 constexpr int LDA = 132;             // A row stride in floats: 16-B aligned, conflict-free ds_read_b128 fragments
 constexpr int MAXC = 160;            // filter cells kept (reachable) supported: D = 6 at R = 1 has exactly 160; the pair
                                      // kernel's LDS tables (7 bytes per (node, cell) + scan scratch) fill the 160 KiB at that
-constexpr int CHUNK_MAX = 64;        // cells per workgroup of the fused kernel
+constexpr int SUBR = 16;             // packed rows per step of the fused kernel (one 16 x 16 MFMA tile of rows)
+
+// first step record of a tile: a (tile, cell) with r rows has ceil(r / 16) <= r / 16 + 1 steps and a tile's rows
+// are <= 8 x its edges, so e_t / 2 + tile * (cells + 2) needs no scan across tiles (one terminal record per tile)
+__host__ __device__ inline size_t step_base(int tile, int e_t, int n_cells) {
+  return (size_t)(e_t >> 1) + (size_t)tile * (size_t)(n_cells + 2);
+}
 
 struct Geo { int ix, iy, iz; float tx, ty, tz, window; };
 
@@ -119,7 +132,9 @@ struct PairJob {
   const int* cell_map;
   int2 *desc, *rows;
   int* pair_src;        // [8 * edge_capacity] source node of every (edge, corner) pair ...
-  float* pair_w;        // ... and its window * trilinear weight (two arrays: the fused kernel reads them with scalar loads)
+  float* pair_w;        // ... and its window * trilinear weight
+  int4* steps;          // per tile (at step_base): {first row, cell | rows << 8 | steps left in the cell << 16, first pair, 0}
+  int* tile_nsteps;     // [tiles]
 };
 struct PairJobs { PairJob j[NBD_CC_MAX_RES]; };
 
@@ -145,7 +160,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   unsigned* cnt32 = smem;                                   // [TN][kc/2]
   unsigned* pwithin = cnt32 + TN * kc / 2;                  // [TN][kc]
   unsigned char* rowidx = reinterpret_cast<unsigned char*>(pwithin + TN * kc);   // [TN][kc]
-  __shared__ int cell_rows[MAXC], cell_pairs[MAXC], cell_rowbase[MAXC], cell_pairbase[MAXC];
+  __shared__ int cell_rows[MAXC], cell_pairs[MAXC], cell_rowbase[MAXC], cell_pairbase[MAXC], cell_stepbase[MAXC];
   __shared__ int seg_pairs[NSEG][MAXC], seg_rows[NSEG][MAXC];
   __shared__ int rp[TN + 1];
   __shared__ int cmap[216];                                 // D <= 6
@@ -162,6 +177,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   __syncthreads();
   const int e_t = rp[0], e_end = rp[n_here];
   const size_t row_base = (size_t)8 * e_t + tile, pair_base = (size_t)8 * e_t;
+  int4* __restrict__ t_steps = job.steps + step_base(tile, e_t, n_cells);
 
   PT(1)
   // ---- A: counts (lane = edge)
@@ -206,20 +222,33 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   PT(3)
   // ---- B2: prefix over cells (one wave; cells in chunks of 64 with a running carry)
   if (wave == 0) {
-    int row_carry = 0, pair_carry = 0;
+    int row_carry = 0, pair_carry = 0, step_carry = 0;
     for (int k0 = 0; k0 < n_cells; k0 += 64) {
       const int k = k0 + lane;
       const int rv = k < n_cells ? cell_rows[k] : 0, pv = k < n_cells ? cell_pairs[k] : 0;
-      const int ri = wave_incl_scan(rv, lane), pi = wave_incl_scan(pv, lane);
+      const int sv = (rv + SUBR - 1) / SUBR;                 // steps of this cell
+      const int ri = wave_incl_scan(rv, lane), pi = wave_incl_scan(pv, lane), si = wave_incl_scan(sv, lane);
       if (k < n_cells) {
         cell_rowbase[k] = row_carry + ri - rv;
         cell_pairbase[k] = pair_carry + pi - pv;
+        cell_stepbase[k] = step_carry + si - sv;
         desc[(size_t)tile * n_cells + k] = make_int2(row_carry + ri - rv, rv);
+        for (int u = 0; u < sv; ++u) {                       // .z (first pair) comes from B3
+          int4* s = t_steps + (step_carry + si - sv + u);
+          s->x = row_carry + ri - rv + SUBR * u;
+          s->y = k | (min(SUBR, rv - SUBR * u) << 8) | ((sv - u) << 16);
+          s->w = 0;
+        }
       }
       row_carry += __shfl(ri, 63);
       pair_carry += __shfl(pi, 63);
+      step_carry += __shfl(si, 63);
     }
-    if (lane == 0) rows[row_base + row_carry] = make_int2(0, pair_carry);      // sentinel: end of the last row
+    if (lane == 0) {
+      rows[row_base + row_carry] = make_int2(0, pair_carry);      // sentinel: end of the last row
+      t_steps[step_carry] = make_int4(0, 0, pair_carry, 0);      // terminal record: end of the last step
+      job.tile_nsteps[tile] = step_carry;
+    }
   }
   __syncthreads();
 
@@ -227,8 +256,11 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   // ---- B3: row records (wave = nodes, lanes = cells: no division)
   for (int nl = wave; nl < n_here; nl += PAIR_THREADS / 64)
     for (int k = lane; k < n_cells; k += 64)
-      if (cnt16[nl * kc + k] > 0)
-        rows[row_base + cell_rowbase[k] + rowidx[nl * kc + k]] = make_int2(nl, cell_pairbase[k] + (int)pwithin[nl * kc + k]);
+      if (cnt16[nl * kc + k] > 0) {
+        const int ri = rowidx[nl * kc + k], first = cell_pairbase[k] + (int)pwithin[nl * kc + k];
+        rows[row_base + cell_rowbase[k] + ri] = make_int2(nl, first);
+        if ((ri & (SUBR - 1)) == 0) t_steps[cell_stepbase[k] + ri / SUBR].z = first;     // a step's first pair
+      }
   __syncthreads();          // B3 reads the counters that C counts down
 
   PT(5)
@@ -284,41 +316,54 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------- fused conv
-// grid = (tiles, cell chunks, column groups of 128); block = 1024 threads: waves 0-7 consume (MFMA, 16 output
-// columns each), waves 8-15 produce (gather + sum of the packed A rows; two waves per ring buffer).
+// grid = (persistent workgroups, 1, column groups of 128); block = 1024 threads: waves 0-7 consume (MFMA, 16 output
+// columns each), waves 8-15 produce (gather + sum of the packed A rows; producer p owns ring buffer p).
 //
-// A "step" is 32 packed rows of one cell. Producer wave p builds the steps p, p+4, p+8, ... into ring buffer p
-// (it owns that buffer); consumer waves walk all steps in order. The two sides meet only through LDS flags
-// -- full[b] = sequence number of the step buffer b holds, done[b] = consumer waves that have finished with
-// it -- so a producer's load latency (row records -> pairs -> feature rows, three dependent trips to L2) is
-// hidden behind three other steps, and the consumers never wait for each other: every wave owns its 32
-// output columns of the LDS accumulator. (First version: one s_barrier per step, 7 us per step against
-// 1.8 us of MFMA.)
+// A "step" is 16 packed rows (distinct nodes) of one (tile, cell). The global step sequence (tile-major, then
+// cell, then 16-row slice; the pair kernel's per-tile step lists laid end to end) is cut into gridDim.x equal
+// contiguous ranges; a workgroup copies its range's step records into LDS (<= CC_CAP at a time) and walks it.
+// Producer p builds the steps p, p + 8, p + 16, ... of the range into buffer p; consumer waves walk all steps in
+// order. The two sides meet only through LDS flags -- full[b] = number of steps buffer b has held, done[b] =
+// consumer waves that have finished with them -- so a producer has eight step-times for the latency of its step
+// (row records and pair records prefetched one own-step ahead; the feature rows of <= 32 pairs in flight), and the
+// consumers never wait for each other: every wave owns its 16 output columns of the LDS accumulator.
 #if defined(NBD_CC_ABL) && NBD_CC_ABL == 3
 #define CC_MFMA(acc, a, b) acc[0] += a * b;
 #else
 #define CC_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
 #endif
 #ifndef NBD_CC_SLEEP
-#define NBD_CC_SLEEP 4             // s_sleep between two polls of a flag (x64 cycles); 0 / 1 / 4 measured 0.479 / 0.492 / 0.474 ms (D = 6)
-#endif
-#ifndef NBD_CC_XCD_MAP
-#define NBD_CC_XCD_MAP 0
+#define NBD_CC_SLEEP 2             // s_sleep between two polls of a flag (x64 cycles)
 #endif
 #ifndef NBD_CC_PRODUCER_PRIO
-#define NBD_CC_PRODUCER_PRIO 2
+#define NBD_CC_PRODUCER_PRIO 3
 #endif
-constexpr int NBUF = 4;
+// The two consumer waves of a SIMD (w and w + 4) run at DIFFERENT priorities: at equal priority their MFMAs
+// interleave issue by issue, both bursts end together and both waves then sit in their LDS round trips (flag poll,
+// first fragment read, scatter) at the same time with the matrix pipe idle -- a convoy (in-kernel stamps, round 3:
+// 1.80 us per 16-row step against 0.98 us of matrix work, producers idle 53 % of the time). With one wave preferred
+// its burst runs uncontended while the other is in its latency phase, and vice versa.
+#ifndef NBD_CC_PRIO_HI
+#define NBD_CC_PRIO_HI 2
+#endif
+#ifndef NBD_CC_PRIO_LO
+#define NBD_CC_PRIO_LO 1
+#endif
+#ifndef NBD_CC_NBF
+#define NBD_CC_NBF 4               // batches of PB gathered rows in flight per producer wave
+#endif
+constexpr int NBUF = 8;                          // ring depth = producer waves
 constexpr int CC_CONSUMERS = 8;                  // consumer waves (16 output columns each)
-constexpr int CC_PRODUCERS = 2 * NBUF;           // producer waves: two per ring buffer, 16 packed rows each
-constexpr int CC_THREADS = (CC_CONSUMERS + CC_PRODUCERS) * 64;
-constexpr int HSUB = SUB / 2;
+constexpr int CC_THREADS = (CC_CONSUMERS + NBUF) * 64;
+constexpr int LDO = 132;                         // accumulator row stride (floats): spreads the rows of a 128-bit scatter over the banks
+constexpr int CC_CAP = 256;                      // step records held in LDS at a time (a multiple of NBUF)
+constexpr int CC_GRID = 256;                     // persistent workgroups (one per CU of an MI355X)
+constexpr int PB = 8;                            // gathered rows per batch
 typedef float f4v __attribute__((ext_vector_type(4)));
-constexpr int MAX_STEPS = CHUNK_MAX * (TN / SUB);
 
 // Flags live in LDS and guard LDS data only: relaxed workgroup-scope atomics + fences restricted to the local
 // address space, so that signalling never drains the global loads a wave keeps in flight (filter-fragment and
-// row-record prefetches).
+// record prefetches).
 #define CC_WAIT(flag, cond)                                                                                  \
   do {                                                                                                       \
     while (!(__hip_atomic_load(&(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) cond))               \
@@ -327,403 +372,476 @@ constexpr int MAX_STEPS = CHUNK_MAX * (TN / SUB);
   } while (0)
 #define CC_RELEASE_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 
+// Build-time probes (tools/build_contconv_trace.sh, tools/contconv_trace.py): -DNBD_CC_TRACE stamps every workgroup
+// (s_memrealtime) and accumulates the time consumer wave 0 / producer wave 0 spend on the LDS flags; -DNBD_CC_ABL = 3
+// is a timing-only ablation (no MFMA). Neither is in the product build.
 #ifdef NBD_CC_TRACE
 __device__ long long* g_cc_trace = nullptr;
-#endif
-
-// Build-time probes (tools/build_contconv_trace.sh, tools/contconv_trace.py): -DNBD_CC_TRACE stamps every workgroup
-// (s_memrealtime) and accumulates the time waves spend on the LDS flags; -DNBD_CC_ABL = 1 / 2 / 3 are timing-only
-// ablations (one cell's filters / feature rows from a 64 KiB table / no MFMA). None of it is in the product build.
-#ifndef NBD_CC_TRACE
-#define DBG_T(x)
-#define DBG_ACC(x)
-#define DBG_LAT(x, j)
-#define DBG_W(x)
-#define DBG_PH(i, x)
-#endif
-template <int KG>
-__global__ __launch_bounds__(CC_THREADS) void contconv_fused_kernel(
-    const float* __restrict__ feat, int ldf, int I, const int* __restrict__ rowptr, int n,
-    const int2* __restrict__ desc, const int2* __restrict__ rows, const int* __restrict__ pair_src,
-    const float* __restrict__ pair_w,
-    const f4* __restrict__ filt, int n_cells, int kq_count, int colblocks, int cells_per_chunk, int n_tiles,
-    int n_chunks, int O, float* __restrict__ partial) {
-  // f4-typed so that the dynamic region starts 16-byte aligned behind the static __shared__ variables: declared
-  // as float[] it began at an 8-byte offset and EVERY ds_read_b128 / ds_write_b64 below took the unaligned path
-  // (SQ_LDS_UNALIGNED_STALL = 85 % of all LDS cycles, LDS array 69 % busy, MFMA pipe 27 %)
-  extern __shared__ f4 lds_aligned[];
-  float* lds = reinterpret_cast<float*>(lds_aligned);
-  float* out_acc = lds;                                    // [TN + 1][128]: row TN swallows a step's padding rows
-  float* a_buf = out_acc + (TN + 1) * 128;                 // [NBUF][SUB][LDA]
-  int* rowmap = reinterpret_cast<int*>(a_buf + NBUF * SUB * LDA);   // [NBUF][SUB]
-  __shared__ int s_cell[CHUNK_MAX], s_rowbeg[CHUNK_MAX], s_nrows[CHUNK_MAX];
-  __shared__ unsigned char st_cell[MAX_STEPS], st_sub[MAX_STEPS];  // step -> (compact cell, 32-row slice)
-  __shared__ int s_ncell, s_nsteps;
-  __shared__ int full[NBUF], done[NBUF];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef NBD_CC_TRACE
-  __shared__ long long s_dbg_wait[16];
-  long long dbg_wait = 0;
 #define DBG_T(x) const long long x = __builtin_amdgcn_s_memrealtime();
-#define DBG_ACC(x) dbg_wait += __builtin_amdgcn_s_memrealtime() - x;
-#define DBG_W(x) const long long x##_w = dbg_wait;
-  long long dbg_ph[3] = {0, 0, 0}; const long long l2 = 0; (void)l2;
-#define DBG_PH(i, x) dbg_ph[i] += __builtin_amdgcn_s_memrealtime() - x;
-  long long dbg_lat = 0; int dbg_nlat = 0;
-#define DBG_LAT(x, j) if ((j) == 0) { dbg_lat += __builtin_amdgcn_s_memrealtime() - x - (dbg_wait - x##_w); ++dbg_nlat; }
-  __shared__ int s_dbg_pairs;
-  const long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
-  if (tid == 0) s_dbg_pairs = 0;
+#define DBG_ACC(cond, v, x) if (cond) v += __builtin_amdgcn_s_memrealtime() - x;
+#else
+#define DBG_T(x)
+#define DBG_ACC(cond, v, x)
 #endif
-  // Workgroup -> (tile, cell chunk), tile fastest. Measured and rejected (NBD_CC_XCD_MAP=1): chunk = index mod 8, which
-  // pins every chunk -- and its 1.3 MB slice of the filter matrix -- to ONE XCD (workgroups go to the XCDs round-robin
-  // by index: confirmed with the probes, 1024 of 1024). The filters then sit in that XCD's L2, but nothing got
-  // faster per workgroup (the kernel is not waiting on those loads) while the chunks of the central cells, now all on
-  // two XCDs, stretched the launch from 0.50 to 0.65 ms.
-  int tile, chunk;
-  if (NBD_CC_XCD_MAP && (n_chunks & 7) == 0) {
-    const int k = blockIdx.x >> 3;
-    tile = k % n_tiles; chunk = (blockIdx.x & 7) + 8 * (k / n_tiles);
-  } else {
-    tile = blockIdx.x % n_tiles; chunk = blockIdx.x / n_tiles;
-  }
-  const int n0 = tile * TN;
-  const int k_begin = chunk * cells_per_chunk, k_end = min(n_cells, k_begin + cells_per_chunk);
-  const int e_t = rowptr[n0];
-  const int2* t_rows = rows + (size_t)8 * e_t + tile;
-  const int* t_src = pair_src + (size_t)8 * e_t;
-  const float* t_w = pair_w + (size_t)8 * e_t;
 
-  // non-empty cells of this chunk, compacted, and the step table (wave 0; cells_per_chunk <= 64)
-  if (wave == 0) {
-    const int k = k_begin + lane;
-    int2 d = make_int2(0, 0);
-    if (k < k_end) d = desc[(size_t)tile * n_cells + k];
-    const unsigned long long m = __ballot(d.y > 0);
-    const int nsub = (d.y + SUB - 1) / SUB;
-    int incl = nsub;
+__device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int t = __shfl_up(incl, off);
-      if (lane >= off) incl += t;
-    }
-    if (d.y > 0) {
-      const int j = __popcll(m & ((1ull << lane) - 1ull));
-      s_cell[j] = k; s_rowbeg[j] = d.x; s_nrows[j] = d.y;
-      for (int u = 0; u < nsub; ++u) { st_cell[incl - nsub + u] = (unsigned char)j; st_sub[incl - nsub + u] = (unsigned char)u; }
-    }
-    if (lane == 63) s_nsteps = incl;
-    if (lane == 0) s_ncell = __popcll(m);
-    if (lane < NBUF) { full[lane] = 0; done[lane] = 0; }
-  }
-  for (int i = tid; i < (TN + 1) * 128 / 4; i += CC_THREADS) reinterpret_cast<f4*>(out_acc)[i] = f4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-  const int nsteps = s_nsteps;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
 
-  if (wave >= CC_CONSUMERS) {
-    const int w4 = (wave - CC_CONSUMERS) & (NBUF - 1);    // ring buffer this wave fills
-    const int hf = (wave - CC_CONSUMERS) / NBUF;           // which 16 rows of each step
-    // ---------------- producer: rows [16 hf, 16 hf + 16) of the steps w4, w4 + 4, ... into buffer w4
-    // The wave is instruction-issue bound (two waves per SIMD), so the per-pair work is kept to a handful of
-    // instructions: the pair records of 64 pairs sit one per lane; a row's byte offset is one VALU multiply for
-    // all 64; a feature row is then `v_readlane -> s_add -> global_load (scalar base + lane offset)`, and its
-    // accumulation `v_readlane -> v_pk_fma_f32`. Rows are fetched 16 at a time with the next 16 in flight
-    // (the gather wants tens of KiB outstanding per CU: MI355X_MICROARCH.md "Indexed rows"), and the wave's next
-    // step's row records are fetched while this one is summed. (First form: 64-bit index math, a predicate
-    // around every load and a clamp per pair -- 25+ instructions per pair, 5.7 us per step.)
-    constexpr int PB = 8, NBF = 4;                        // rows per batch, batches in flight per wave
-    // The producers are the YOUNGER waves of their SIMDs (waves 8-15 behind the consumers' 0-7): at equal priority
-    // the issue arbiter serves age first, and the consumers' back-to-back MFMAs left a producer one instruction
-    // slot in ~70 (in-kernel stamps: 2.1 us to ISSUE a batch of 16 row loads, 1.4 us to sum it -- the same with the
-    // rows coming from a 64 KiB table as from the 8 MB one, i.e. not a memory effect). Their stream is sparse (about
-    // ten instructions per gathered row), so raised priority costs the consumers little.
-    __builtin_amdgcn_s_setprio(NBD_CC_PRODUCER_PRIO);
-    float* a_dst = a_buf + (w4 * SUB + hf * HSUB) * LDA;
-    const bool live = 2 * lane < I;
-    const unsigned lane8 = (unsigned)min(2 * lane, I - 2) * 4u;      // clamped: every lane reads inside the row
-    const unsigned ldb = (unsigned)ldf * 4u;
-    // this half's rows of step s (clamped to the last step: ONE load whatever s, so that hipcc can count its
-    // s_waitcnt vmcnt); lane `cnt` holds the row behind the last one (or the tile's sentinel): its first pair ends the step
-    auto step_cnt = [&](int s) { return max(0, min(HSUB, s_nrows[st_cell[s]] - st_sub[s] * SUB - hf * HSUB)); };
-    auto row_records = [&](int s_want) {
-      const int s = min(s_want, nsteps - 1), j = st_cell[s], cnt = step_cnt(s);
-      const int2 v = t_rows[s_rowbeg[j] + st_sub[s] * SUB + (cnt > 0 ? hf * HSUB + min(lane, cnt) : 0)];
-      return (lane <= cnt && cnt > 0) ? v : make_int2(-1, 0);
-    };
-    // The feature matrix through a buffer descriptor: a row is fetched by `buffer_load_dwordx2 v, v_lane, s[rsrc], s_row offen`
-    // with the row's byte offset in an SGPR -- and the pair records {source, weight} are read with SCALAR loads
-    // (uniform addresses), so gathering a row costs the vector ALU nothing and summing it one v_pk_fma_f32 with the
-    // weight as a scalar operand. The fp32 MFMAs of the consumer waves keep the SIMDs' vector issue busy: in-kernel
-    // stamps showed a producer getting one VALU slot per ~35 cycles (1.5-2 us to ISSUE 16 row loads when each cost a
-    // v_readlane + a 64-bit VALU add; the same from a 64 KiB table as from the 8 MB one, so not a memory effect).
-    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feat), 0, (int)min((size_t)0x7fffffff, ((size_t)(n - 1) * ldf + I) * 4), 0x00020000);
-    int2 rinfo = make_int2(-1, 0), rinfo_n = make_int2(-1, 0);
-    if (nsteps > 0) { rinfo = row_records(w4); rinfo_n = row_records(w4 + NBUF); }
-    for (int s = w4, use = 0; s < nsteps; s += NBUF, ++use) {
-      const int cnt = step_cnt(s);
-      const int p_begin = __builtin_amdgcn_readlane(rinfo.y, 0), p_end = __builtin_amdgcn_readlane(rinfo.y, cnt);
-#ifdef NBD_CC_TRACE
-      if (lane == 0) atomicAdd(&s_dbg_pairs, p_end - p_begin);
-#endif
-      const int2 rinfo_cur = rinfo;
-      rinfo = rinfo_n;
+// LDS / memory loads are "divergent" to the compiler even at wave-uniform addresses: values that steer control flow
+// are moved to SGPRs explicitly, or every `if` on them becomes v_cmp + s_and_saveexec and the counters VGPRs
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+__device__ __forceinline__ int4 uni4(int4 v) { return make_int4(UNI(v.x), UNI(v.y), UNI(v.z), UNI(v.w)); }
+__device__ __forceinline__ int2 uni2(int2 v) { return make_int2(UNI(v.x), UNI(v.y)); }
+
+// range of workgroup w of G over T steps: [T w / G, T (w + 1) / G)
+__host__ __device__ inline int range_begin(long long T, int w, int G) { return (int)(T * w / G); }
+
+struct CCArgs {
+  const float* feat; int ldf, I; const int* rowptr; int n, n_tiles;
+  const int2* rows; const int* pair_src; const float* pair_w; const int4* steps; const int* tile_nsteps;
+  const f4* filt; int n_cells, kq_count, colblocks, OP; float* partial;
+};
+
+// LDS carve-up of the fused kernel (dynamic region, 16-byte aligned)
+struct CCLds {
+  float* out_acc;      // [TN][LDO]
+  float* a_buf;        // [NBUF][SUBR][LDA]
+  int* rowmap;         // [NBUF][SUBR]
+  int2* scratch;       // [NBUF producers][64] {row byte offset, weight}
+  int4* st4;           // [CC_CAP] {first row, cell | rows << 8 | left << 16, tile, e_t}
+  int2* st2;           // [CC_CAP] {first pair, end pair}
+  int* seg;            // [3][CC_CAP], borrows the ring's first buffer while the ring is idle
+  int *s_red, *s_nseg, *full, *done;
+};
+__device__ __forceinline__ CCLds cc_lds(float* lds, int* statics) {
+  CCLds L;
+  L.out_acc = lds;
+  L.a_buf = L.out_acc + TN * LDO;
+  L.rowmap = reinterpret_cast<int*>(L.a_buf + NBUF * SUBR * LDA);
+  L.scratch = reinterpret_cast<int2*>(L.rowmap + NBUF * SUBR);
+  L.st4 = reinterpret_cast<int4*>(L.scratch + NBUF * 64);
+  L.st2 = reinterpret_cast<int2*>(L.st4 + CC_CAP);
+  L.seg = reinterpret_cast<int*>(L.a_buf);
+  L.s_red = statics; L.s_nseg = statics + 16; L.full = statics + 24; L.done = statics + 32;
+  return L;
+}
+constexpr size_t CC_LDS_BYTES = (size_t)(TN * LDO + NBUF * SUBR * LDA) * sizeof(float) + NBUF * SUBR * sizeof(int) +
+                                NBUF * 64 * sizeof(int2) + CC_CAP * (sizeof(int4) + sizeof(int2));
+
+// The step records of [p0, p1) of the global sequence -> LDS (all 1024 threads; both roles call it at the same
+// points, so the barriers match). The ring is idle here (first pass: untouched; later passes: every wave has left
+// the previous pass), so the segment list may borrow its first buffer.
+__device__ __forceinline__ void cc_load_table(const CCArgs& A, const CCLds& L, int p0, int p1, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  __syncthreads();
+  if (tid == 0) *L.s_nseg = 0;
+  __syncthreads();
+  int carry = 0;
+  for (int c0 = 0; c0 < A.n_tiles && carry < p1; c0 += CC_THREADS) {
+    const int t = c0 + tid;
+    const int v = t < A.n_tiles ? A.tile_nsteps[t] : 0;
+    const int incl = wave_incl_scan(v, lane);
+    if (lane == 63) L.s_red[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int i = 0; i < CC_THREADS / 64; ++i) { const int x = L.s_red[i]; woff += i < wave ? x : 0; tot += x; }
+    tot = UNI(tot);
+    const int base = carry + woff + incl - v;
+    if (v > 0 && base < p1 && base + v > p0) {
+      const int s = atomicAdd(L.s_nseg, 1);                        // order-free: every segment is copied whole
+      L.seg[s] = t; L.seg[CC_CAP + s] = base; L.seg[2 * CC_CAP + s] = v;
+    }
+    carry += tot;
+    __syncthreads();
+  }
+  __syncthreads();
+  const int nseg = UNI(*L.s_nseg);
+  for (int s = 0; s < nseg; ++s) {
+    const int t = UNI(L.seg[s]), base = UNI(L.seg[CC_CAP + s]), cnt = UNI(L.seg[2 * CC_CAP + s]);
+    const int e_t = UNI(A.rowptr[t * TN]);
+    const int4* ts = A.steps + step_base(t, e_t, A.n_cells);
+    const int j_lo = max(p0 - base, 0), j_hi = min(p1 - base, cnt);
+    for (int j = j_lo + tid; j < j_hi; j += CC_THREADS) {
+      const int4 r = ts[j];
+      const int nx = ts[j + 1].z;                                  // next step's (or the terminal record's) first pair
+      L.st4[base + j - p0] = make_int4(r.x, r.y, t, e_t);
+      L.st2[base + j - p0] = make_int2(r.z, nx);
+    }
+  }
+  __syncthreads();
+}
+
+// ---------------- producer p: steps p, p + 8, ... of every pass into ring buffer p
+// Per gathered row: one broadcast ds_read of its record {byte offset of the row, weight}, one v_add (lane offset),
+// one buffer_load_dwordx2, one v_pk_fma_f32. No scalar loads and no round trip to memory between the batches of a
+// step: the records of 64 pairs are fetched by ONE coalesced vector load (the first 64 of a step already while the
+// wave's previous step was summed) and parked in wave-private LDS.
+__device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int g0, int g1, int tid, long long* dbg) {
+  const int lane = tid & 63, p = (tid >> 6) - CC_CONSUMERS;
+  __builtin_amdgcn_s_setprio(NBD_CC_PRODUCER_PRIO);
+  float* a_dst = L.a_buf + p * SUBR * LDA;
+  int2* my_scr = L.scratch + p * 64;
+  const int I = A.I;
+  const bool live = 2 * lane < I;
+  const unsigned lane8 = (unsigned)min(2 * lane, I - 2) * 4u;      // clamped: every lane reads inside the row
+  const unsigned ldb = (unsigned)A.ldf * 4u;
+  const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(A.feat), 0, (int)min((size_t)0x7fffffff, ((size_t)(A.n - 1) * A.ldf + I) * 4), 0x00020000);
+  // row records (lane r <= rows: {node, first pair}; lane `rows` = the row behind the last: its first pair ends
+  // the step) and the first 64 pair records of step i
+  auto fetch = [&](int i, int2& rinfo, int& psrc, float& pw) {
+    const int4 r = uni4(L.st4[i]);
+    const int2 pr = uni2(L.st2[i]);
+    const size_t e8 = (size_t)8 * r.w;
+    rinfo = (A.rows + e8 + r.z)[r.x + min(lane, (r.y >> 8) & 31)];
+    const int at = pr.x + min(lane, pr.y - pr.x - 1);
+    psrc = (A.pair_src + e8)[at];
+    pw = (A.pair_w + e8)[at];
+  };
+  int qbase = 0;
+  for (int p0 = g0; p0 < g1; p0 += CC_CAP) {
+    const int p1 = min(g1, p0 + CC_CAP), npass = p1 - p0;
+    DBG_T(t0_)
+    cc_load_table(A, L, p0, p1, tid);
+    DBG_ACC(true, dbg[2], t0_)
+    int2 rinfo_n = make_int2(0, 0);
+    int psrc_n = 0;
+    float pw_n = 0.f;
+    if (p < npass) fetch(p, rinfo_n, psrc_n, pw_n);
+    for (int i = p; i < npass; i += NBUF) {
+      const int use = (qbase + i) / NBUF;
+      DBG_T(s0_)
+      const int4 r = uni4(L.st4[i]);
+      const int2 pr = uni2(L.st2[i]);
+      const int cnt = (r.y >> 8) & 31, pb = pr.x, np = pr.y - pr.x;
+      const int2 rinfo = rinfo_n;
+      int psrc = psrc_n;
+      float pw = pw_n;
+      fetch(min(i + NBUF, npass - 1), rinfo_n, psrc_n, pw_n);      // unconditional (the last steps re-fetch themselves)
       // the ring buffer is claimed only when the first feature rows are already on their way
       bool claimed = false;
       auto claim = [&]() {
         if (!claimed) {
-          DBG_T(p0) if (use > 0) CC_WAIT(done[w4], >= CC_CONSUMERS * use);   // the consumers are done with this buffer
-          DBG_ACC(p0)
-          if (lane < HSUB) rowmap[w4 * SUB + hf * HSUB + lane] = lane < cnt ? rinfo_cur.x : TN;   // padding rows -> the dummy row
+          DBG_T(c0_)
+          if (use > 0) CC_WAIT(L.done[p], >= CC_CONSUMERS * use);  // the consumers are done with this buffer
+          DBG_ACC(true, dbg[0], c0_)
+          if (lane < SUBR) L.rowmap[p * SUBR + lane] = lane < cnt ? rinfo.x : -1;   // padding rows: no node
           claimed = true;
         }
       };
       int cur = 0;
-      int next_begin = __builtin_amdgcn_readlane(rinfo_cur.y, 1);
+      int next_begin = __builtin_amdgcn_readlane(rinfo.y, 1);
       f2 acc = {0.f, 0.f};
-      auto flush = [&]() {                                           // row `cur` is complete
+      auto flush = [&]() {                                         // row `cur` is complete
         *reinterpret_cast<f2*>(a_dst + cur * LDA + 2 * lane) = live ? acc : f2{0.f, 0.f};
         acc = f2{0.f, 0.f};
         ++cur;
-        next_begin = __builtin_amdgcn_readlane(rinfo_cur.y, cur + 1);
+        next_begin = __builtin_amdgcn_readlane(rinfo.y, cur + 1);
       };
-      // The step-half's pairs as one stream of 16-row batches, two in flight. EVERY stage issues exactly 16 row loads
-      // (past the end: re-reads of the last pair's row, L1 hits), and the row records of the step after next ONE:
-      // only then can hipcc count its s_waitcnt vmcnt() and let batch j be summed while batch j + 1 is in flight
-      // (with `if (more) issue(...)` the merged paths made it assume no younger loads: summing row u of one batch
-      // waited for row u of the NEXT batch -- vmcnt(15..0) behind a conditional block of 16 loads in the ISA).
-      const int np = p_end - p_begin, nb = (np + PB - 1) / PB;
-      if (nb > 0) {
-        // NBF batches of PB rows in flight. A batch's pair records sit in SGPRs, fetched by scalar loads one stage
-        // before they are needed: its PB sources (for the row loads) NBF - 1 stages before its PB weights (for the
-        // sum), two register sets each, alternating. Inline asm: hipcc selects scalar loads only for memory it can
-        // prove unclobbered, and the LDS fences of the flag protocol defeat that proof (it fell back to vector
-        // loads + a v_readfirstlane waterfall per row).
-        f2 fbuf[NBF][PB];
-        i8v srcA, srcB, wgtA, wgtB;
-        auto req_src = [&](i8v& src, int j) {                        // batches past the end: no request, row 0 is gathered
-          if (j < nb) asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(src) : "s"(t_src + p_begin + PB * j) : "memory");
-        };
-        auto req_wgt = [&](i8v& wgt, int j) {
-          if (j < nb) asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(wgt) : "s"(t_w + p_begin + PB * j) : "memory");
-        };
-        auto landed = [&](i8v& a, i8v& b, i8v& c, i8v& d) {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
-        };
-        auto issue = [&](f2* f, const i8v& src, int j) {
-          const int valid = np - PB * j;                             // records past the step's last pair: gather row 0 of
-#pragma unroll                                                       // the batch again instead of whatever follows
-          for (int u = 0; u < PB; ++u) {
-            const int sidx = u < valid ? src[u] : (valid > 0 ? src[0] : 0);     // nothing left at all: row 0, a hot line
-#if defined(NBD_CC_ABL) && NBD_CC_ABL == 2
-            const unsigned ro = (unsigned)(sidx & 127) * ldb;
-#else
-            const unsigned ro = (unsigned)sidx * ldb;
-#endif
-            f[u] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(frs, (int)lane8, (int)ro, 0));
-          }
-        };
-        auto sum = [&](const f2* f, const i8v& wgt, int j) {
-          const int valid = min(PB, np - PB * j), q0 = p_begin + PB * j;
-          if (valid == PB) {
-#pragma unroll
-            for (int u = 0; u < PB; ++u) {
-              if (q0 + u == next_begin) flush();                     // wave-uniform
-              const float w = __int_as_float(wgt[u]);
-              acc = __builtin_elementwise_fma(f2{w, w}, f[u], acc);
-            }
-          } else {
-#pragma unroll
-            for (int u = 0; u < PB; ++u) {
-              if (u < valid) {                                       // wave-uniform
-                if (q0 + u == next_begin) flush();
-                const float w = __int_as_float(wgt[u]);
-                acc = __builtin_elementwise_fma(f2{w, w}, f[u], acc);
-              }
-            }
-          }
-        };
-        static_assert(NBF == 4, "the stage rotation below is written out for four batches in flight");
-        DBG_T(l0) DBG_W(l0)
-        req_src(srcA, 0); req_src(srcB, 1);
-        landed(srcA, srcB, wgtA, wgtB);
-        issue(fbuf[0], srcA, 0); issue(fbuf[1], srcB, 1);
-        req_src(srcA, 2); req_src(srcB, 3); req_wgt(wgtA, 0);
-        rinfo_n = row_records(s + 2 * NBUF);
-        landed(srcA, srcB, wgtA, wgtB);
-        issue(fbuf[2], srcA, 2);
-        DBG_PH(0, l0)
-        claim();
-        DBG_T(l1)
-        // stage K: rows of batch j + K + 3 on their way, next records requested, batch j + K summed meanwhile
-#define CC_STAGE(K, SRC_CUR, SRC_OTHER, WGT_CUR, WGT_OTHER)                                                   \
-        landed(srcA, srcB, wgtA, wgtB);                                                                      \
-        issue(fbuf[(K + NBF - 1) % NBF], SRC_CUR, j + K + NBF - 1);                                          \
-        req_src(SRC_OTHER, j + K + NBF); req_wgt(WGT_OTHER, j + K + 1);                                      \
-        sum(fbuf[K], WGT_CUR, j + K);                                                                        \
-        if (j + K + 1 >= nb) break;
-        for (int j = 0;; j += NBF) {
-          CC_STAGE(0, srcB, srcA, wgtA, wgtB)
-          if (j == 0) { DBG_PH(1, l1) DBG_LAT(l0, j) }
-          CC_STAGE(1, srcA, srcB, wgtB, wgtA)
-          CC_STAGE(2, srcB, srcA, wgtA, wgtB)
-          CC_STAGE(3, srcA, srcB, wgtB, wgtA)
+      for (int c0 = 0; c0 < np; c0 += 64) {
+        const int npc = min(64, np - c0), nb = (npc + PB - 1) / PB;
+        if (c0 > 0) {
+          const size_t at = (size_t)8 * r.w + pb + c0 + min(lane, npc - 1);
+          psrc = A.pair_src[at];
+          pw = A.pair_w[at];
         }
+        // slots behind the chunk's last pair: the last pair's row (a hot line) with weight 0
+        __builtin_amdgcn_wave_barrier();
+        my_scr[lane] = make_int2((int)((unsigned)psrc * ldb), lane < npc ? __float_as_int(pw) : 0);
+        __builtin_amdgcn_wave_barrier();
+        // NBF batches of PB rows in flight. EVERY stage issues exactly PB row loads (past the end: re-reads of the
+        // last pair's row, L1 hits): only then can hipcc count its s_waitcnt vmcnt() and let batch j be summed while
+        // the younger batches are in flight.
+        f2 fbuf[NBD_CC_NBF][PB];
+#define CC_ISSUE(J)                                                                                          \
+        {                                                                                                    \
+          _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                                   \
+            const unsigned ro = (unsigned)my_scr[PB * (J) + u].x;                                            \
+            fbuf[(J) % NBD_CC_NBF][u] = __builtin_bit_cast(                                                  \
+                f2, __builtin_amdgcn_raw_buffer_load_b64(frs, (int)(ro + lane8), 0, 0));                     \
+          }                                                                                                  \
+        }
+#define CC_SUM(J)                                                                                            \
+        {                                                                                                    \
+          const int valid = min(PB, npc - PB * (J)), q0 = pb + c0 + PB * (J);                                \
+          float wv[PB];                            /* the weights: broadcast reads of the parked records */  \
+          _Pragma("unroll") for (int u = 0; u < PB; ++u) wv[u] = __int_as_float(my_scr[PB * (J) + u].y);     \
+          if (valid == PB) {                                                                                 \
+            _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                                 \
+              if (q0 + u == next_begin) flush();                       /* wave-uniform */                    \
+              const float w = wv[u];                                                                         \
+              acc = __builtin_elementwise_fma(f2{w, w}, fbuf[(J) % NBD_CC_NBF][u], acc);                     \
+            }                                                                                                \
+          } else {                                                                                           \
+            _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                                 \
+              if (u < valid) {                                         /* wave-uniform */                    \
+                if (q0 + u == next_begin) flush();                                                           \
+                const float w = wv[u];                                                                       \
+                acc = __builtin_elementwise_fma(f2{w, w}, fbuf[(J) % NBD_CC_NBF][u], acc);                   \
+              }                                                                                              \
+            }                                                                                                \
+          }                                                                                                  \
+        }
+        // stage J: rows of batch J + NBF - 1 on their way, batch J summed meanwhile (64 pairs = 8 batches)
+#define CC_STAGE(J)                                                                                          \
+        if ((J) + NBD_CC_NBF - 1 < 64 / PB) CC_ISSUE((J) + NBD_CC_NBF - 1)                                   \
+        CC_SUM(J)                                                                                            \
+        if ((J) + 1 >= nb) break;
+        static_assert(64 / PB == 8 && NBD_CC_NBF >= 2 && NBD_CC_NBF <= 5, "stages below are written out for 8 batches");
+        do {
+          CC_ISSUE(0)
+          if (NBD_CC_NBF > 2) CC_ISSUE(1)
+          if (NBD_CC_NBF > 3) CC_ISSUE(2)
+          if (NBD_CC_NBF > 4) CC_ISSUE(3)
+          claim();
+          CC_STAGE(0) CC_STAGE(1) CC_STAGE(2) CC_STAGE(3) CC_STAGE(4) CC_STAGE(5) CC_STAGE(6) CC_STAGE(7)
+        } while (0);
 #undef CC_STAGE
-      } else {
-        rinfo_n = row_records(s + 2 * NBUF);
+#undef CC_SUM
+#undef CC_ISSUE
       }
       claim();
-      if (cnt > 0) *reinterpret_cast<f2*>(a_dst + cur * LDA + 2 * lane) = live ? acc : f2{0.f, 0.f};
+      *reinterpret_cast<f2*>(a_dst + cur * LDA + 2 * lane) = live ? acc : f2{0.f, 0.f};
       CC_RELEASE_FENCE();
-      if (lane == 0) __hip_atomic_fetch_add(&full[w4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // both halves -> 2 (use + 1)
+      if (lane == 0) __hip_atomic_store(&L.full[p], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      DBG_ACC(true, dbg[1], s0_)
     }
-  } else {
-    // ---------------- consumer: 16 output columns, all steps in order
-    // Two consumer waves share a SIMD (waves w and w + 4): while one scatters its results or waits on a flag,
-    // the other's MFMAs keep the matrix pipe busy. Each wave multiplies the step's 32 packed rows (two 16-row
-    // tiles = two independent accumulator chains) by its 16 columns of the cell's filter with
-    // v_mfma_f32_16x16x4_f32; the fragment (I/16 dwordx4 per lane) sits in registers, the next cell's is fetched
-    // into a second set while this one multiplies (the two sets alternate: no copies).
-    // (With ONE consumer wave per SIMD on 32 columns, 32x32x2 MFMA, a step took 6500 cycles against 4096 of
-    // matrix work: the scatter and the flag handling of that one wave were all lost matrix time.)
-    const int cw = wave;                                   // 0..7
-    const int cb = blockIdx.z * CC_CONSUMERS + cw;         // 16-column block of the output
-    const bool has_cols = cb < colblocks;
-    f4 bf0[KG], bf1[KG];
-    // always exactly KG loads (clamped index, zeroed afterwards): a counted s_waitcnt vmcnt(KG) is only possible
-    // when the number of younger loads does not depend on the path taken
-    auto load_b = [&](f4* dstv, int cell) {
-#if defined(NBD_CC_ABL) && NBD_CC_ABL == 1
-      cell = 0;
-#endif
-      const f4* src = filt + (((size_t)cell * colblocks + min(cb, colblocks - 1)) * kq_count) * 64 + lane;
+    qbase += npass;
+  }
+}
+
+// ---------------- consumer: 16 output columns, all steps in order
+// Two consumer waves share a SIMD (waves w and w + 4): while one scatters its results or waits on a flag, the
+// other's MFMAs keep the matrix pipe busy. A step is ONE 16 x 16 tile per wave, the K = I contraction in two
+// independent accumulator chains; the MFMA takes the filter fragment as its first operand and the packed A rows as
+// its second, so the result comes out transposed -- lane l holds output columns 4 (l >> 4) .. + 3 of packed row
+// l & 15 -- and the scatter into the node's accumulator row is one ds_read_b128 + ds_write_b128 per lane (with the
+// operands the other way round a lane held one column of four rows: eight 32-bit read-modify-writes per step).
+// The fragment (I / 16 dwordx4 per lane) sits in registers, the next cell's is fetched into a second set while
+// this one multiplies (the two sets alternate: no copies). When the range crosses into the next tile (and at its
+// end) the wave writes its 16 columns of the accumulator to partial slot (workgroup + tile) and zeroes them.
+template <int KG>
+__device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int g0, int g1, int tid, long long* dbg) {
+  const int lane = tid & 63, cw = tid >> 6;
+  if (cw < CC_CONSUMERS / 2) __builtin_amdgcn_s_setprio(NBD_CC_PRIO_HI);
+  else __builtin_amdgcn_s_setprio(NBD_CC_PRIO_LO);
+  const int cb = blockIdx.z * CC_CONSUMERS + cw;                   // 16-column block of the output
+  const int colblocks = A.colblocks, kq_count = A.kq_count;
+  const bool has_cols = cb < colblocks;
+  int cur_tile = -1;
+  auto flush_acc = [&](int tile) {
+    float* dst = A.partial + ((size_t)(blockIdx.x + tile) * TN) * A.OP + (size_t)blockIdx.z * 128 + cw * 16 + (lane & 3) * 4;
+    float* src = L.out_acc + cw * 16 + (lane & 3) * 4;
+#pragma unroll 4
+    for (int r0 = 0; r0 < TN; r0 += 16) {
+      const int r = r0 + (lane >> 2);
+      f4* a = reinterpret_cast<f4*>(src + r * LDO);
+      *reinterpret_cast<f4*>(dst + (size_t)r * A.OP) = *a;
+      *a = f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  f4 bf0[KG], bf1[KG];
+  // always exactly KG loads (clamped index, zeroed afterwards): a counted s_waitcnt vmcnt(KG) is only possible
+  // when the number of younger loads does not depend on the path taken
+  auto load_b = [&](f4* dstv, int cell) {
+    const f4* src = A.filt + (((size_t)cell * colblocks + min(cb, colblocks - 1)) * kq_count) * 64 + lane;
 #pragma unroll
-      for (int g = 0; g < KG; ++g) {
-        const f4 v = src[(size_t)min(g, kq_count - 1) * 64];
-        dstv[g] = (g < kq_count) ? v : f4{0.f, 0.f, 0.f, 0.f};
-      }
-    };
-    if (nsteps > 0) load_b(bf0, s_cell[0]);
-    float* o_col = out_acc + cw * 16 + (lane & 15);
-#define CC_STEP(BC)                                                                                          \
+    for (int g = 0; g < KG; ++g) {
+      const f4 v = src[(size_t)min(g, kq_count - 1) * 64];
+      dstv[g] = (g < kq_count) ? v : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  int qbase = 0;
+  for (int p0 = g0; p0 < g1; p0 += CC_CAP) {
+    const int p1 = min(g1, p0 + CC_CAP), npass = p1 - p0;
+    DBG_T(t0_)
+    cc_load_table(A, L, p0, p1, tid);
+    DBG_ACC(true, dbg[2], t0_)
+#define CC_STEP(BC, IDX)                                                                                     \
     {                                                                                                        \
-      f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};                                          \
-      const float* a_base = a_buf + (b * SUB + (lane & 15)) * LDA + (lane >> 4) * 4;                         \
-      _Pragma("unroll") for (int g = 0; g < KG; ++g) {                                                       \
-        const f4 a0 = *reinterpret_cast<const f4*>(a_base + g * 16);                                         \
-        const f4 a1 = *reinterpret_cast<const f4*>(a_base + 16 * LDA + g * 16);                              \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
-          CC_MFMA(acc0, a0[j], BC[g][j]) CC_MFMA(acc1, a1[j], BC[g][j])                                      \
-        }                                                                                                    \
+      const int q_ = qbase + (IDX), b = q_ & (NBUF - 1), use = q_ / NBUF;                                    \
+      const int tile_ = UNI(L.st4[IDX].z);                                                                   \
+      if (tile_ != cur_tile) {                         /* the range crosses into the next tile */          \
+        if (cur_tile >= 0 && has_cols) flush_acc(cur_tile);                                                  \
+        cur_tile = tile_;                                                                                    \
       }                                                                                                      \
-      /* C row = 4 (lane >> 4) + reg (+ 16 for the second tile), column = lane & 15 -> node of the tile */  \
-      const int4 n0v = *reinterpret_cast<const int4*>(rowmap + b * SUB + 4 * (lane >> 4));                   \
-      const int4 n1v = *reinterpret_cast<const int4*>(rowmap + b * SUB + 16 + 4 * (lane >> 4));              \
-      /* the buffer can go back to its producer: A and the row map are in registers */                      \
-      CC_RELEASE_FENCE();                                                                                    \
-      if (lane == 0) __hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    \
-      const int nd[8] = {n0v.x, n0v.y, n0v.z, n0v.w, n1v.x, n1v.y, n1v.z, n1v.w};                            \
-      float old[8];                                                                                          \
-      _Pragma("unroll") for (int r = 0; r < 8; ++r) old[r] = o_col[nd[r] * 128];                             \
-      _Pragma("unroll") for (int r = 0; r < 4; ++r) o_col[nd[r] * 128] = old[r] + acc0[r];                   \
-      _Pragma("unroll") for (int r = 0; r < 4; ++r) o_col[nd[4 + r] * 128] = old[4 + r] + acc1[r];           \
+      DBG_T(c0_) CC_WAIT(L.full[b], >= use + 1);                                                             \
+      DBG_ACC(true, dbg[0], c0_)                                                                             \
+      DBG_T(w0_)                                                                                             \
+      if (has_cols) {                                                                                        \
+        f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};                                        \
+        const float* a_base = L.a_buf + (b * SUBR + (lane & 15)) * LDA + (lane >> 4) * 4;                    \
+        f4 av[KG];                                                                                           \
+        /* Issue order (left alone, hipcc issued read, wait, 4 MFMAs, read, wait ...): the row map and two      \
+           fragment reads ahead; then one LDS read behind every four MFMAs -- the next-but-one fragment, last   \
+           the node's accumulator quad (padding rows: row 0, discarded; in program order behind the previous    \
+           step's write of this wave) -- so that each read's latency runs under 128 cycles of matrix work. */   \
+        const int node = L.rowmap[b * SUBR + (lane & 15)];                                                   \
+        av[0] = *reinterpret_cast<const f4*>(a_base);                                                        \
+        if (KG > 1) av[1] = *reinterpret_cast<const f4*>(a_base + 16);                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        _Pragma("unroll") for (int g = 2; g < KG; ++g) av[g] = *reinterpret_cast<const f4*>(a_base + g * 16); \
+        f4* o = reinterpret_cast<f4*>(L.out_acc + max(node, 0) * LDO + cw * 16 + 4 * (lane >> 4));           \
+        const f4 old = *o;                                                                                   \
+        _Pragma("unroll") for (int g = 0; g < KG; ++g) {                                                     \
+          CC_MFMA(acc0, BC[g][0], av[g][0]) CC_MFMA(acc1, BC[g][1], av[g][1])                                \
+          CC_MFMA(acc0, BC[g][2], av[g][2]) CC_MFMA(acc1, BC[g][3], av[g][3])                                \
+        }                                                                                                    \
+        if (KG == 8) {                                                                                       \
+          _Pragma("unroll") for (int g = 0; g < 7; ++g) {                                                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                               \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
+          }                                                                                                  \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                 \
+        }                                                                                                    \
+        /* the buffer can go back to its producer: A and the row map are in registers */                    \
+        CC_RELEASE_FENCE();                                                                                  \
+        if (lane == 0) __hip_atomic_fetch_add(&L.done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\
+        if (node >= 0)                                                                                       \
+          *o = f4{old[0] + (acc0[0] + acc1[0]), old[1] + (acc0[1] + acc1[1]), old[2] + (acc0[2] + acc1[2]),  \
+                  old[3] + (acc0[3] + acc1[3])};                                                             \
+      } else if (lane == 0) {                                                                                \
+        __hip_atomic_fetch_add(&L.done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);               \
+      }                                                                                                      \
+      DBG_ACC(true, dbg[1], w0_)                                                                             \
     }
     // Cells two at a time: the even cell multiplies with fragment set 0 while set 1 is fetched for the odd cell
     // and vice versa. Written out like this (instead of a parity switch inside one loop) the loads of the NEXT
     // cell are the only ones younger than the current cell's, so the wait before the first MFMA is a counted
-    // vmcnt(KG) and the prefetch really stays in flight (with the switch the compiler had to use vmcnt(0):
-    // every cell change paid the full L2 / Infinity Cache latency).
-    auto cell_steps = [&](int j) { return (s_nrows[j] + SUB - 1) / SUB; };
-#define CC_ONE_STEP(BC)                                                                                      \
-    {                                                                                                        \
-      const int b = s & (NBUF - 1), use = s / NBUF;                                                          \
-      DBG_T(c0) CC_WAIT(full[b], == 2 * (use + 1)); DBG_ACC(c0)                                              \
-      if (has_cols) CC_STEP(BC) else if (lane == 0)                                                          \
-        __hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                 \
-      ++s;                                                                                                   \
-    }
-    /* the cell's first step is peeled: its fragment wait then sits in straight-line code behind the prefetch */ \
-
-#define CC_CELL(BC)                                                                                          \
-    {                                                                                                        \
-      const int nsub = cell_steps(j);                                                                        \
-      CC_ONE_STEP(BC)                                                                                        \
-      for (int u = 1; u < nsub; ++u) CC_ONE_STEP(BC)                                                         \
-    }
-    {
-      int s = 0;
-      const int ncell = s_ncell;
-      for (int j = 0; j < ncell;) {
-        load_b(bf1, s_cell[min(j + 1, ncell - 1)]);        // the last cell re-fetches itself: never used
-        CC_CELL(bf0)
-        if (++j >= ncell) break;
-        load_b(bf0, s_cell[min(j + 1, ncell - 1)]);
-        CC_CELL(bf1)
-        ++j;
+    // vmcnt(KG) and the prefetch really stays in flight.
+    auto cell_of = [&](int i) { return UNI(L.st4[i].y) & 0xff; };
+    auto left_of = [&](int i) { return min((UNI(L.st4[i].y) >> 16) & 0xff, npass - i); };
+    int i = 0;
+    if (has_cols) load_b(bf0, cell_of(0));
+    while (i < npass) {
+      {
+        const int rem = left_of(i), inext = i + rem;
+        if (has_cols) load_b(bf1, cell_of(min(inext, npass - 1)));   // the last cell re-fetches itself: never used
+        CC_STEP(bf0, i)
+        for (int u = 1; u < rem; ++u) CC_STEP(bf0, i + u)
+        i = inext;
+      }
+      if (i >= npass) break;
+      {
+        const int rem = left_of(i), inext = i + rem;
+        if (has_cols) load_b(bf0, cell_of(min(inext, npass - 1)));
+        CC_STEP(bf1, i)
+        for (int u = 1; u < rem; ++u) CC_STEP(bf1, i + u)
+        i = inext;
       }
     }
-#undef CC_CELL
-#undef CC_ONE_STEP
 #undef CC_STEP
+    qbase += npass;
   }
-#ifdef NBD_CC_TRACE
-  if (lane == 0) s_dbg_wait[wave] = wave == 9 ? dbg_lat : (wave == 13 ? dbg_nlat : (wave == 10 ? dbg_ph[0] : (wave == 11 ? dbg_ph[1] : (wave == 14 ? dbg_ph[2] : (wave == 15 ? dbg_nlat : dbg_wait)))));
-#endif
-  __syncthreads();
-#ifdef NBD_CC_TRACE
-  const long long dbg_t1 = __builtin_amdgcn_s_memrealtime();
-#endif
+  if (has_cols && cur_tile >= 0) flush_acc(cur_tile);
+}
 
-  // ---- write the tile's partial sums for this cell chunk: partial[chunk][node][column]
-  float* dst = partial + ((size_t)chunk * n + n0) * O;
-  const int col0 = blockIdx.z * 128;
-  const int n_here = min(TN, n - n0), cols = min(128, O - col0);
-  for (int i = tid; i < n_here * 128; i += CC_THREADS) {
-    const int nl = i >> 7, c = i & 127;
-    if (c < cols) dst[(size_t)nl * O + col0 + c] = out_acc[nl * 128 + c];
-  }
+template <int KG>
+__global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArgs A) {
+  // f4-typed so that the dynamic region starts 16-byte aligned behind the static __shared__ variables (declared as
+  // float[] it began at an 8-byte offset and every ds_read_b128 / ds_write_b64 took the unaligned path)
+  extern __shared__ f4 lds_aligned[];
+  __shared__ int statics[48];                                      // s_red[16], s_nseg, full[8], done[8]
+  __shared__ int s_total;
+  const CCLds L = cc_lds(reinterpret_cast<float*>(lds_aligned), statics);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef NBD_CC_TRACE
+  const long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+  __shared__ long long s_dbg[16][4];
+#endif
+  long long dbg_wait[4] = {0, 0, 0, 0};        // [0] time on the flags, [1] in the steps, [2] in the table loads, [3] whole role
+
+  // ---- this workgroup's range of the global step sequence: [T w / G, T (w + 1) / G)
+  {
+    int loc = 0;
+    for (int t = tid; t < A.n_tiles; t += CC_THREADS) loc += A.tile_nsteps[t];
+    loc = wave_sum(loc);
+    if (lane == 0) L.s_red[wave] = loc;
+    __syncthreads();
+    if (tid == 0) {
+      int T = 0;
+      for (int i = 0; i < CC_THREADS / 64; ++i) T += L.s_red[i];
+      s_total = T;
+    }
+    if (tid < NBUF) { L.full[tid] = 0; L.done[tid] = 0; }
+    __syncthreads();
+  }
+  const long long T = UNI(s_total);
+  const int g0 = range_begin(T, blockIdx.x, gridDim.x), g1 = range_begin(T, blockIdx.x + 1, gridDim.x);
+  if (g0 >= g1) return;                                            // uniform: the whole workgroup leaves
+  for (int i = tid; i < TN * LDO / 4; i += CC_THREADS) reinterpret_cast<f4*>(L.out_acc)[i] = f4{0.f, 0.f, 0.f, 0.f};
+  // (the first cc_load_table's barriers order the zeroing before any consumer's first scatter)
+  DBG_T(r0_)
+  if (wave >= CC_CONSUMERS) cc_producer(A, L, g0, g1, tid, dbg_wait);
+  else cc_consumer<KG>(A, L, g0, g1, tid, dbg_wait);
+  DBG_ACC(true, dbg_wait[3], r0_)
+#ifdef NBD_CC_TRACE
+  if (lane == 0) { for (int i = 0; i < 4; ++i) s_dbg[wave][i] = dbg_wait[i]; }
   __syncthreads();
-  if (tid == 0 && g_cc_trace) {
-    long long* t = g_cc_trace + (size_t)blockIdx.x * 16;
-    t[6] = s_dbg_wait[0]; t[7] = s_dbg_wait[4]; t[8] = s_dbg_wait[8]; t[9] = s_dbg_wait[12];
-    t[10] = s_dbg_wait[9]; t[11] = s_dbg_wait[13]; t[12] = s_dbg_wait[10]; t[13] = s_dbg_wait[11]; t[14] = s_dbg_wait[14]; t[15] = s_dbg_wait[15];
-    t[0] = dbg_t0; t[1] = dbg_t1; t[2] = __builtin_amdgcn_s_memrealtime(); t[3] = nsteps; t[4] = s_dbg_pairs;
-    t[5] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+  if (tid < 64 && g_cc_trace && blockIdx.z == 0) {
+    long long* t = g_cc_trace + (size_t)blockIdx.x * 72;
+    if (tid == 0) {
+      t[0] = dbg_t0; t[1] = g1 - g0; t[2] = __builtin_amdgcn_s_memrealtime();
+      t[3] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+    t[8 + tid] = s_dbg[tid >> 2][tid & 3];
   }
 #endif
 }
 
-// out = act(scale * sum of the chunk partials), fixed chunk order
-__global__ __launch_bounds__(256) void contconv_finish_kernel(const float* __restrict__ partial, int n_chunks,
-                                                              const float* __restrict__ rowscale, int act,
-                                                              float* __restrict__ out, int ldo, int n, int O) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)n * O;
-  if (i >= total) return;
-  const int row = (int)(i / O), col = (int)(i - (size_t)row * O);
-  float v = partial[i];
-  for (int s = 1; s < n_chunks; ++s) v += partial[(size_t)s * total + i];
-  if (rowscale) v = __fmul_rn(v, rowscale[row]);
-  out[(size_t)row * ldo + col] = act == 1 ? tanhf(v) : v;
-}
-
-struct FusedPlan { int tiles, chunks, cells_per_chunk, colgroups; };
-FusedPlan plan_fused(int n, int n_cells, int O) {
-  FusedPlan p;
-  p.tiles = ceil_div(n, TN);
-  p.colgroups = ceil_div(O, 128);
-  // ~2 workgroups per CU over the launch (a workgroup carries ~10 us of fixed cost: fill, drain, 64 KiB of partial
-  // sums; measured at N = 16 384, D = 6 / 4: 3 / 4 / 5 / 6 / 8 / 12 / 16 chunks 0.512 / 0.465 / 0.495 / 0.480 /
-  // 0.485 / 0.497 / 0.510 and 0.372 / 0.315 / 0.319 / 0.319 / 0.317 / 0.329 / 0.347 ms); <= 64 cells per chunk
-  int chunks = ceil_div(512, p.tiles * p.colgroups);
-  if (chunks > 16) chunks = 16;                      // bounds the partial-sum traffic of small problems
-  if (chunks > n_cells) chunks = n_cells;
-  if (chunks < ceil_div(n_cells, CHUNK_MAX)) chunks = ceil_div(n_cells, CHUNK_MAX);
-  if (chunks < 1) chunks = 1;
-  p.cells_per_chunk = ceil_div(n_cells, chunks);
-  p.chunks = ceil_div(n_cells, p.cells_per_chunk);
-  return p;
+// out = act(scale * sum of the tile's partial slots), in workgroup order. grid (tiles, 4): 32 rows of a tile each.
+__global__ __launch_bounds__(256) void contconv_stream_finish_kernel(
+    const float* __restrict__ partial, const int* __restrict__ tile_nsteps, int n_tiles, int G,
+    const float* __restrict__ rowscale, int act, float* __restrict__ out, int ldo, int n, int O, int OP) {
+  __shared__ int s_lo[4], s_tot[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
+  int lo = 0, tot = 0;
+  for (int t = tid; t < n_tiles; t += 256) {
+    const int v = tile_nsteps[t];
+    tot += v;
+    lo += t < tile ? v : 0;
+  }
+  lo = wave_sum(lo); tot = wave_sum(tot);
+  if (lane == 0) { s_lo[wave] = lo; s_tot[wave] = tot; }
+  __syncthreads();
+  const int base = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
+  const long long T = (long long)s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+  const int cnt = tile_nsteps[tile];
+  int w_first = 0, w_last = -1;
+  if (cnt > 0) {
+    // owner of step g: the workgroup w with range_begin(w) <= g < range_begin(w + 1)
+    auto owner = [&](int g) {
+      int w = (int)((long long)g * G / T);
+      while (w + 1 < G && range_begin(T, w + 1, G) <= g) ++w;
+      while (w > 0 && range_begin(T, w, G) > g) --w;
+      return w;
+    };
+    w_first = owner(base);
+    w_last = owner(base + cnt - 1);
+  }
+  const int r0 = tile * TN + blockIdx.y * 32;
+  for (int e = tid; e < 32 * OP / 4; e += 256) {
+    const int rl = e / (OP / 4), c = (e - rl * (OP / 4)) * 4;
+    const int row = r0 + rl;
+    if (row >= n || c >= O) continue;
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int w = w_first; w <= w_last; ++w) {
+      if (range_begin(T, w, G) >= range_begin(T, w + 1, G)) continue;          // empty range: wrote nothing
+      const f4 x = *reinterpret_cast<const f4*>(partial + ((size_t)(w + tile) * TN + (row - tile * TN)) * OP + c);
+      v = f4{v[0] + x[0], v[1] + x[1], v[2] + x[2], v[3] + x[3]};
+    }
+    const float sc = rowscale ? rowscale[row] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (c + j < O) {
+        float y = rowscale ? __fmul_rn(v[j], sc) : v[j];
+        out[(size_t)row * ldo + c + j] = act == 1 ? tanhf(y) : y;
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -743,26 +861,27 @@ int nbd_contconv_fused_supported(int in_channels, int out_channels, int n_cells)
          n_cells <= MAXC;
 }
 
+namespace {
+struct PairsLayout { size_t desc, rows, src, w, steps, nsteps, total; };
+PairsLayout pairs_layout(int n, int64_t edge_capacity, int n_cells) {
+  const size_t tiles = (size_t)ceil_div(n, TN);
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  PairsLayout L;
+  size_t at = 0;
+  L.desc = at; at += up(tiles * n_cells * sizeof(int2));
+  L.rows = at; at += up(((size_t)8 * edge_capacity + tiles) * sizeof(int2));
+  L.src = at; at += up((size_t)8 * edge_capacity * sizeof(int));
+  L.w = at; at += up((size_t)8 * edge_capacity * sizeof(float));
+  L.steps = at; at += up((step_base((int)tiles, (int)edge_capacity, n_cells) + 2) * sizeof(int4));
+  L.nsteps = at; at += up(tiles * sizeof(int));
+  L.total = at + 256;
+  return L;
+}
+}  // namespace
+
 size_t nbd_contconv_pairs_bytes(int n, int64_t edge_capacity, int n_cells) {
   if (n <= 0 || edge_capacity < 0 || n_cells <= 0) return 0;
-  const size_t tiles = (size_t)ceil_div(n, TN);
-  const size_t desc = tiles * n_cells * sizeof(int2);
-  const size_t rows = ((size_t)8 * edge_capacity + tiles) * sizeof(int2);
-  const size_t pairs = 2 * (((size_t)8 * edge_capacity * sizeof(int) + 255) & ~(size_t)255);   // sources, weights
-  return ((desc + 255) & ~(size_t)255) + ((rows + 255) & ~(size_t)255) + pairs + 256;
-}
-
-static void split_pairs_buffer(void* buf, int n, int64_t edge_capacity, int n_cells, int2** desc, int2** rows, int** pair_src,
-                               float** pair_w) {
-  const size_t tiles = (size_t)ceil_div(n, TN);
-  char* p = static_cast<char*>(buf);
-  *desc = reinterpret_cast<int2*>(p);
-  p += (tiles * n_cells * sizeof(int2) + 255) & ~(size_t)255;
-  *rows = reinterpret_cast<int2*>(p);
-  p += (((size_t)8 * edge_capacity + tiles) * sizeof(int2) + 255) & ~(size_t)255;
-  *pair_src = reinterpret_cast<int*>(p);
-  p += ((size_t)8 * edge_capacity * sizeof(int) + 255) & ~(size_t)255;
-  *pair_w = reinterpret_cast<float*>(p);
+  return pairs_layout(n, edge_capacity, n_cells).total;
 }
 
 int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int* centres, int n, int64_t edge_capacity,
@@ -773,6 +892,7 @@ int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int*
   if (!filter_resolutions || !cell_maps || !n_cells || !pair_lists || !pair_lists_bytes) return NBD_E_BADARG;
   if (n == 0) return 0;
   if (!pos || !rowptr || !centres) return NBD_E_BADARG;
+  if (edge_capacity > (int64_t)0x0fffffff) return NBD_E_BADARG;       // 8 x edges indexes the pair arrays as int
   PairJobs jobs;
   int kc_max = 0;
   for (int r = 0; r < n_res; ++r) {
@@ -783,7 +903,11 @@ int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int*
     if (pair_lists_bytes[r] < nbd_contconv_pairs_bytes(n, edge_capacity, nc)) return NBD_E_WORKSPACE;
     PairJob& j = jobs.j[r];
     j.D = d; j.n_cells = nc; j.cell_map = cell_maps[r];
-    split_pairs_buffer(pair_lists[r], n, edge_capacity, nc, &j.desc, &j.rows, &j.pair_src, &j.pair_w);
+    const PairsLayout L = pairs_layout(n, edge_capacity, nc);
+    char* base = static_cast<char*>(pair_lists[r]);
+    j.desc = reinterpret_cast<int2*>(base + L.desc); j.rows = reinterpret_cast<int2*>(base + L.rows);
+    j.pair_src = reinterpret_cast<int*>(base + L.src); j.pair_w = reinterpret_cast<float*>(base + L.w);
+    j.steps = reinterpret_cast<int4*>(base + L.steps); j.tile_nsteps = reinterpret_cast<int*>(base + L.nsteps);
     const int kc = (nc + 3) & ~3;
     if (kc > kc_max) kc_max = kc;
   }
@@ -808,10 +932,10 @@ int nbd_contconv_pairs_f32(const float* pos, const int* rowptr, const int* centr
                                       &n_cells, lists, &pair_lists_bytes, stream);
 }
 
+// partial slots: (workgroup + tile) < CC_GRID + tiles, each TN rows x (column groups x 128) floats
 size_t nbd_contconv_fused_workspace_bytes(int n, int n_cells, int out_channels) {
   if (n <= 0 || n_cells <= 0 || out_channels <= 0) return 0;
-  const FusedPlan p = plan_fused(n, n_cells, out_channels);
-  return (size_t)p.chunks * n * out_channels * sizeof(float);
+  return (size_t)(CC_GRID + ceil_div(n, TN)) * TN * (size_t)(ceil_div(out_channels, 128) * 128) * sizeof(float);
 }
 
 size_t nbd_contconv_filter_floats(int in_channels, int out_channels, int n_cells) {
@@ -829,34 +953,40 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
   if (n == 0) return 0;
   if (!feat || !rowptr || !pair_lists || !filters_shuffled || !out) return NBD_E_BADARG;
   if ((reinterpret_cast<uintptr_t>(feat) & 7) || (reinterpret_cast<uintptr_t>(filters_shuffled) & 15)) return NBD_E_BADARG;
-  if (!workspace || workspace_bytes < nbd_contconv_fused_workspace_bytes(n, n_cells, out_channels)) return NBD_E_WORKSPACE;
+  if ((size_t)n * ldf * 4 > (size_t)0x7fffffff) return NBD_E_BADARG;       // a row's byte offset is a 32-bit buffer offset
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15) ||
+      workspace_bytes < nbd_contconv_fused_workspace_bytes(n, n_cells, out_channels))
+    return NBD_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int2 *desc, *rows;
-  int* pair_src;
-  float* pair_w;
-  split_pairs_buffer(const_cast<void*>(pair_lists), n, edge_capacity, n_cells, &desc, &rows, &pair_src, &pair_w);
-  const FusedPlan p = plan_fused(n, n_cells, out_channels);
-  const size_t lds = (size_t)((TN + 1) * 128 + NBUF * SUB * LDA) * sizeof(float) + NBUF * SUB * sizeof(int);
+  const PairsLayout L = pairs_layout(n, edge_capacity, n_cells);
+  const char* base = static_cast<const char*>(pair_lists);
+  const int2* rows = reinterpret_cast<const int2*>(base + L.rows);
+  const int* pair_src = reinterpret_cast<const int*>(base + L.src);
+  const float* pair_w = reinterpret_cast<const float*>(base + L.w);
+  const int4* steps = reinterpret_cast<const int4*>(base + L.steps);
+  const int* tile_nsteps = reinterpret_cast<const int*>(base + L.nsteps);
+  const int tiles = ceil_div(n, TN), colgroups = ceil_div(out_channels, 128), OP = colgroups * 128;
   float* partial = static_cast<float*>(workspace);
-  const dim3 grid(p.tiles * p.chunks, 1, p.colgroups);
+  const dim3 grid(CC_GRID, 1, colgroups);
   const int kq_count = ceil_div(in_channels, 16);
+  CCArgs A;
+  A.feat = feat; A.ldf = ldf; A.I = in_channels; A.rowptr = rowptr; A.n = n; A.n_tiles = tiles;
+  A.rows = rows; A.pair_src = pair_src; A.pair_w = pair_w; A.steps = steps; A.tile_nsteps = tile_nsteps;
+  A.filt = reinterpret_cast<const f4*>(filters_shuffled); A.n_cells = n_cells; A.kq_count = kq_count;
+  A.colblocks = ceil_div(out_channels, 16); A.OP = OP; A.partial = partial;
 #define CC_LAUNCH(K)                                                                                                \
   do {                                                                                                              \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(contconv_fused_kernel<K>),                     \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                     \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(contconv_stream_kernel<K>),                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);                     \
     if (e != hipSuccess) return (int)e;                                                                             \
-    contconv_fused_kernel<K><<<grid, CC_THREADS, lds, st>>>(feat, ldf, in_channels, rowptr, n, desc, rows, pair_src, pair_w, \
-                                                           reinterpret_cast<const f4*>(filters_shuffled), n_cells, \
-                                                           kq_count, ceil_div(out_channels, 16), p.cells_per_chunk, \
-                                                           p.tiles, p.chunks, out_channels, partial);              \
+    contconv_stream_kernel<K><<<grid, CC_THREADS, CC_LDS_BYTES, st>>>(A);                                           \
   } while (0)
   if (kq_count <= 2) CC_LAUNCH(2); else CC_LAUNCH(8);      // K depth: I <= 32 / I <= 128
 #undef CC_LAUNCH
   int rc = status();
   if (rc) return rc;
-  const size_t total = (size_t)n * out_channels;
-  contconv_finish_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(partial, p.chunks, rowscale, act, out, ldo, n,
-                                                                         out_channels);
+  contconv_stream_finish_kernel<<<dim3(tiles, 4), 256, 0, st>>>(partial, tile_nsteps, tiles, CC_GRID, rowscale, act, out,
+                                                                 ldo, n, out_channels, OP);
   return status();
 }
 

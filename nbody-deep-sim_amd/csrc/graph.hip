@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void radius_snapshot_kernel(const float* __res
   if (flags[0] == 0) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < 3 * n) ref[i] = pos[i];
-  if (i == 0) { flags[1] = 1; flags[2] = n; }
+  if (i == 0) { flags[1] = 1; flags[2] = n; flags[3] += 1; }        // [3]: builds so far (read by RadiusCache.rebuilds())
 }
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_refresh_kernel(
@@ -848,7 +848,7 @@ int nbd_radius_cached_search_f32(const float* pos, int n, float radius_sq, float
   if ((long long)p.slices * n * wide_cap > 0x7fffffffLL * 2) return NBD_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   char* sp = static_cast<char*>(state);
-  int* flags = reinterpret_cast<int*>(sp);                         // [0] rebuild now, [1] built, [2] n of the build
+  int* flags = reinterpret_cast<int*>(sp);                         // [0] rebuild now, [1] built, [2] n of the build, [3] builds so far
   float* ref = reinterpret_cast<float*>(sp + 64);
   int* wdeg = reinterpret_cast<int*>(sp + 64 + ((size_t)3 * n * sizeof(float) + 63) / 64 * 64);
   int* wlast = wdeg + n;

@@ -132,6 +132,13 @@ class RadiusCache:
             self.key = key
         return wide, self.state, self.ws
 
+    def rebuilds(self) -> int:
+        """How many times the O(n^2) candidate-list build has run in this state (one host read-back: for reports,
+        not for the rollout loop). The first search of a sequence counts as one."""
+        if self.state is None:
+            return 0
+        return int(self.state[:16].view(torch.int32)[3].item())
+
 
 def radius_lists(pos: torch.Tensor, r: float, batch=None, loop: bool = False, max_num_neighbors: int = 32,
                  transpose: bool = True, scan_transpose: bool = False, cache: RadiusCache | None = None) -> RadiusLists:

@@ -17,7 +17,7 @@ from nbd import graphops, nnops, _lib
 from nbd.plummer import generate_plummer
 
 SCALE = 4.599349753792708
-REC = 16                                  # int64 per workgroup record (csrc/contconv_fused.hip, NBD_CC_TRACE)
+REC = 72                                  # int64 per workgroup record (csrc/contconv_fused.hip, NBD_CC_TRACE)
 
 
 def main():
@@ -41,48 +41,36 @@ def main():
         with torch.no_grad():
             for _ in range(3):
                 layer(pos, feat, lists=lists, act="tanh", wt=wf, pairs=pairs)
-            tr = torch.zeros(4096 * REC, dtype=torch.int64, device="cuda")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                layer(pos, feat, lists=lists, act="tanh", wt=wf, pairs=pairs)
+            e1.record(); torch.cuda.synchronize()
+            layer_ms = e0.elapsed_time(e1) / 10
+            tr = torch.zeros(1024 * REC, dtype=torch.int64, device="cuda")
             assert L.nbd_debug_cc_trace(tr.data_ptr()) == 0
             layer(pos, feat, lists=lists, act="tanh", wt=wf, pairs=pairs)
             torch.cuda.synchronize()
             assert L.nbd_debug_cc_trace(None) == 0
         t = tr.view(-1, REC).cpu().numpy()
-        idx = np.nonzero(t[:, 0] != 0)[0]
-        t = t[idx]
-        xcc = (t[:, 5] >> 32) & 0xf
-        tab = np.zeros((8, 16), dtype=int)
-        for a, b in zip(idx % 8, xcc):
-            tab[a, b] += 1
+        t = t[t[:, 0] != 0]
         t0 = t[:, 0].min()
-        start, body_end, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0   # us
-        steps, prs = t[:, 3], t[:, 4]
-        hw = t[:, 5] & 0xffffffff
-        cu = ((xcc & 0xf) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)
-        dur = body_end - start
-        A = np.stack([np.ones_like(dur), steps, prs], 1).astype(np.float64)
-        coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
-        res = {"workgroups": int(len(t)), "launch_span_us": float(end.max()), "dur_mean_us": float(dur.mean()),
-               "dur_min_max_us": [float(dur.min()), float(dur.max())], "epilogue_mean_us": float((end - body_end).mean()),
-               "fit_us": {"fixed": coef[0], "per_step": coef[1], "per_pair": coef[2]},
-               "fit_resid_rms_us": float(np.sqrt(((A @ coef - dur) ** 2).mean())),
-               "steps_mean": float(steps.mean()), "pairs_mean": float(prs.mean()), "pairs_max": int(prs.max()),
-               "wg_index_mod8_to_xcc_consistency": float(tab.max(axis=1).sum() / len(idx))}
-        busy = {}
-        for k, a, b in zip(cu, start, end):
-            busy.setdefault(int(k), []).append((a, b))
-        res["distinct_cus"] = len(busy)
-        res["cu_busy_frac_mean"] = float(np.mean([sum(b - a for a, b in v) for v in busy.values()]) / end.max())
-        res["cu_last_end_us_p10_p50_p90_max"] = [float(x) for x in np.percentile([max(b for a, b in v) for v in busy.values()],
-                                                                                  [10, 50, 90, 100])]
-        heavy = prs > np.percentile(prs, 90)
-        for name, col in (("consumer0_wait", 6), ("consumer4_wait", 7), ("producer0_wait", 8), ("producer4_wait", 9)):
-            wt = t[:, col] / 100.0
-            res[name + "_frac_of_dur"] = float((wt / dur).mean())
-            res[name + "_frac_densest_10pct"] = float((wt[heavy] / dur[heavy]).mean())
-        nlat = max(t[:, 11].sum(), 1)
-        res["producer_first_batch_issue_to_summed_us"] = float((t[:, 10] / 100.0).sum() / nlat)
-        res["producer_phase_us_prologue__first_stage"] = [float((t[:, 12] / 100.0).sum() / nlat),
-                                                           float((t[:, 13] / 100.0).sum() / nlat)]
+        start, end = (t[:, 0] - t0) / 100.0, (t[:, 2] - t0) / 100.0            # us (s_memrealtime: 100 MHz)
+        steps = t[:, 1]
+        dur = end - start
+        res = {"layer_ms_untraced_loop": layer_ms, "workgroups": int(len(t)), "launch_span_us": float(end.max()),
+               "start_spread_us": float(start.max()), "dur_mean_us": float(dur.mean()),
+               "dur_min_max_us": [float(dur.min()), float(dur.max())], "steps_total": int(steps.sum()),
+               "steps_per_wg_min_max": [int(steps.min()), int(steps.max())],
+               "us_per_step_mean": float((dur / np.maximum(steps, 1)).mean()),
+               "mfma_bound_us_per_step_at_2.1GHz": 16 * 128 * 128 * 2 / (256 * 2.1e9) * 1e6}
+        w = t[:, 8:72].reshape(-1, 16, 4) / 100.0          # us: [wave][flags, steps, table loads, whole role]
+        slow = dur > np.percentile(dur, 90)
+        for name, sel in (("all", slice(None)), ("slowest_10pct", slow)):
+            ws = w[sel]
+            res[name] = {"dur_us": float(dur[sel].mean()),
+                         "consumer_wave_us_flags_steps_tables_role": [[float(x) for x in ws[:, k].mean(0)] for k in (0, 3, 4, 7)],
+                         "producer_wave_us_flags_steps_tables_role": [[float(x) for x in ws[:, k].mean(0)] for k in (8, 11, 12, 15)]}
         out[f"D{d}"] = res
     print(json.dumps(out))
 
