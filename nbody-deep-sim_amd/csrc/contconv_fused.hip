@@ -42,6 +42,9 @@
 
 #include "../../include/nbd.h"
 
+#define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -57,6 +60,14 @@ constexpr int LDA = 132;             // A row stride in floats: 16-B aligned, co
 constexpr int MAXC = 160;            // filter cells kept (reachable) supported: D = 6 at R = 1 has exactly 160; the pair
                                      // kernel's LDS tables (7 bytes per (node, cell) + scan scratch) fill the 160 KiB at that
 constexpr int SUBR = 16;             // packed rows per step of the fused kernel (one 16 x 16 MFMA tile of rows)
+// Cost of a step for the fused kernel's split of the step sequence over its workgroups, in pairs: a step takes the
+// consumers ~1.45 us whatever it holds and the producers ~14.5 ns per pair (in-kernel stamps at the published shape,
+// round 3: the gathers are served from the Infinity Cache at ~3.5 TB/s), so below ~100 pairs the matrix side sets
+// the pace and above it the gather.
+#ifndef NBD_CC_COST_MIN
+#define NBD_CC_COST_MIN 96
+#endif
+constexpr int CC_COST_MIN = NBD_CC_COST_MIN;
 
 // first step record of a tile: a (tile, cell) with r rows has ceil(r / 16) <= r / 16 + 1 steps and a tile's rows
 // are <= 8 x its edges, so e_t / 2 + tile * (cells + 2) needs no scan across tiles (one terminal record per tile)
@@ -135,6 +146,8 @@ struct PairJob {
   float* pair_w;        // ... and its window * trilinear weight
   int4* steps;          // per tile (at step_base): {first row, cell | rows << 8 | steps left in the cell << 16, first pair, 0}
   int* tile_nsteps;     // [tiles]
+  int* tile_cost;       // [tiles] sum of the tile's step costs (each step: max(CC_COST_MIN, its pairs)); the running
+                        // (inclusive) sum inside the tile is the step records' .w
 };
 struct PairJobs { PairJob j[NBD_CC_MAX_RES]; };
 
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   __shared__ int seg_pairs[NSEG][MAXC], seg_rows[NSEG][MAXC];
   __shared__ int rp[TN + 1];
   __shared__ int cmap[216];                                 // D <= 6
-  __shared__ int next_node;
+  __shared__ int next_node, s_tile_steps;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x, n0 = tile * TN, n_here = min(TN, n - n0);
   const float half = (float)(D - 1) / 2.0f;
@@ -236,8 +249,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
         for (int u = 0; u < sv; ++u) {                       // .z (first pair) comes from B3
           int4* s = t_steps + (step_carry + si - sv + u);
           s->x = row_carry + ri - rv + SUBR * u;
-          s->y = k | (min(SUBR, rv - SUBR * u) << 8) | ((sv - u) << 16);
-          s->w = 0;
+          s->y = k | (min(SUBR, rv - SUBR * u) << 8) | ((sv - u) << 16);      // .w (running cost) comes from B4
         }
       }
       row_carry += __shfl(ri, 63);
@@ -248,6 +260,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
       rows[row_base + row_carry] = make_int2(0, pair_carry);      // sentinel: end of the last row
       t_steps[step_carry] = make_int4(0, 0, pair_carry, 0);      // terminal record: end of the last step
       job.tile_nsteps[tile] = step_carry;
+      s_tile_steps = step_carry;
     }
   }
   __syncthreads();
@@ -262,6 +275,25 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
         if ((ri & (SUBR - 1)) == 0) t_steps[cell_stepbase[k] + ri / SUBR].z = first;     // a step's first pair
       }
   __syncthreads();          // B3 reads the counters that C counts down
+
+  // ---- B4: running cost of the tile's steps (a step's pairs = next step's first pair - its own)
+  {
+    const int ns = s_tile_steps;
+    int carry = 0;
+    for (int j0 = 0; j0 < ns; j0 += PAIR_THREADS) {
+      const int j = j0 + tid;
+      const int c = j < ns ? max(CC_COST_MIN, t_steps[j + 1].z - t_steps[j].z) : 0;
+      const int incl = wave_incl_scan(c, lane);
+      if (lane == 63) seg_pairs[0][wave] = incl;              // B's scratch, free by now
+      __syncthreads();
+      int woff = 0, tot = 0;
+      for (int i = 0; i < PAIR_THREADS / 64; ++i) { const int x = seg_pairs[0][i]; woff += i < wave ? x : 0; tot += x; }
+      if (j < ns) t_steps[j].w = carry + woff + incl;
+      carry += tot;
+      __syncthreads();
+    }
+    if (tid == 0) job.tile_cost[tile] = carry;
+  }
 
   PT(5)
   // ---- C: place the pairs (counters count down: slot = old - 1). A half-wave takes the next node from the
@@ -327,6 +359,16 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
 // consumer waves that have finished with them -- so a producer has eight step-times for the latency of its step
 // (row records and pair records prefetched one own-step ahead; the feature rows of <= 32 pairs in flight), and the
 // consumers never wait for each other: every wave owns its 16 output columns of the LDS accumulator.
+#if defined(NBD_CC_ABL) && NBD_CC_ABL == 5           /* timing only: the consumers just hand the buffers back */
+#define CC_ABL_NO_CONSUME 1
+#else
+#define CC_ABL_NO_CONSUME 0
+#endif
+#if defined(NBD_CC_ABL) && NBD_CC_ABL == 6           /* timing only: one cell's filter fragment for all cells */
+#define CC_ABL_ONE_FRAGMENT 1
+#else
+#define CC_ABL_ONE_FRAGMENT 0
+#endif
 #if defined(NBD_CC_ABL) && NBD_CC_ABL == 3
 #define CC_MFMA(acc, a, b) acc[0] += a * b;
 #else
@@ -371,6 +413,15 @@ typedef float f4v __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");                                          \
   } while (0)
 #define CC_RELEASE_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+// done[b][w] = uses of buffer b consumer wave w has finished with (plain stores by one lane: no read-modify-write, and
+// none of the ballot / count code hipcc wraps around an atomic add); the producer reads the eight words lane-parallel
+#define CC_WAIT_ALL_DONE(ptr, want)                                                                          \
+  do {                                                                                                       \
+    while (__builtin_amdgcn_ballot_w64(__hip_atomic_load((ptr) + (lane & (CC_CONSUMERS - 1)), __ATOMIC_RELAXED, \
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP) < (want)) != 0ull)      \
+      __builtin_amdgcn_s_sleep(NBD_CC_SLEEP);                                                                \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");                                          \
+  } while (0)
 
 // Build-time probes (tools/build_contconv_trace.sh, tools/contconv_trace.py): -DNBD_CC_TRACE stamps every workgroup
 // (s_memrealtime) and accumulates the time consumer wave 0 / producer wave 0 spend on the LDS flags; -DNBD_CC_ABL = 3
@@ -401,7 +452,8 @@ __host__ __device__ inline int range_begin(long long T, int w, int G) { return (
 
 struct CCArgs {
   const float* feat; int ldf, I; const int* rowptr; int n, n_tiles;
-  const int2* rows; const int* pair_src; const float* pair_w; const int4* steps; const int* tile_nsteps;
+  const int2* rows; const int* pair_src; const float* pair_w; const int4* steps; const int* tile_nsteps; const int* tile_cost;
+  int* cuts;           // [gridDim.x + 1] first step of every workgroup's range, written here, read by the finishing kernel
   const f4* filt; int n_cells, kq_count, colblocks, OP; float* partial;
 };
 
@@ -410,8 +462,8 @@ struct CCLds {
   float* out_acc;      // [TN][LDO]
   float* a_buf;        // [NBUF][SUBR][LDA]
   int* rowmap;         // [NBUF][SUBR]
-  int2* scratch;       // [NBUF producers][64] {row byte offset, weight}
-  int4* st4;           // [CC_CAP] {first row, cell | rows << 8 | left << 16, tile, e_t}
+  int2* scratch;       // [NBUF producers][2][64] {row byte offset, weight}: two groups of 64 pair records per wave
+  int4* st4;           // [CC_CAP] {cell | rows << 8 | steps left in the cell << 16, tile, first row, e_t}
   int2* st2;           // [CC_CAP] {first pair, end pair}
   int* seg;            // [3][CC_CAP], borrows the ring's first buffer while the ring is idle
   int *s_red, *s_nseg, *full, *done;
@@ -422,20 +474,20 @@ __device__ __forceinline__ CCLds cc_lds(float* lds, int* statics) {
   L.a_buf = L.out_acc + TN * LDO;
   L.rowmap = reinterpret_cast<int*>(L.a_buf + NBUF * SUBR * LDA);
   L.scratch = reinterpret_cast<int2*>(L.rowmap + NBUF * SUBR);
-  L.st4 = reinterpret_cast<int4*>(L.scratch + NBUF * 64);
+  L.st4 = reinterpret_cast<int4*>(L.scratch + NBUF * 128);
   L.st2 = reinterpret_cast<int2*>(L.st4 + CC_CAP);
   L.seg = reinterpret_cast<int*>(L.a_buf);
-  L.s_red = statics; L.s_nseg = statics + 16; L.full = statics + 24; L.done = statics + 32;
+  L.s_red = statics; L.s_nseg = statics + 16; L.full = statics + 24; L.done = statics + 32;   // done[NBUF][CC_CONSUMERS]
   return L;
 }
 constexpr size_t CC_LDS_BYTES = (size_t)(TN * LDO + NBUF * SUBR * LDA) * sizeof(float) + NBUF * SUBR * sizeof(int) +
-                                NBUF * 64 * sizeof(int2) + CC_CAP * (sizeof(int4) + sizeof(int2));
+                                NBUF * 128 * sizeof(int2) + CC_CAP * (sizeof(int4) + sizeof(int2));
 
 // The step records of [p0, p1) of the global sequence -> LDS (all 1024 threads; both roles call it at the same
 // points, so the barriers match). The ring is idle here (first pass: untouched; later passes: every wave has left
 // the previous pass), so the segment list may borrow its first buffer.
 __device__ __forceinline__ void cc_load_table(const CCArgs& A, const CCLds& L, int p0, int p1, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = UNI(tid >> 6);
   __syncthreads();
   if (tid == 0) *L.s_nseg = 0;
   __syncthreads();
@@ -467,7 +519,7 @@ __device__ __forceinline__ void cc_load_table(const CCArgs& A, const CCLds& L, i
     for (int j = j_lo + tid; j < j_hi; j += CC_THREADS) {
       const int4 r = ts[j];
       const int nx = ts[j + 1].z;                                  // next step's (or the terminal record's) first pair
-      L.st4[base + j - p0] = make_int4(r.x, r.y, t, e_t);
+      L.st4[base + j - p0] = make_int4(r.y, t, r.x, e_t);
       L.st2[base + j - p0] = make_int2(r.z, nx);
     }
   }
@@ -480,10 +532,10 @@ __device__ __forceinline__ void cc_load_table(const CCArgs& A, const CCLds& L, i
 // step: the records of 64 pairs are fetched by ONE coalesced vector load (the first 64 of a step already while the
 // wave's previous step was summed) and parked in wave-private LDS.
 __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int g0, int g1, int tid, long long* dbg) {
-  const int lane = tid & 63, p = (tid >> 6) - CC_CONSUMERS;
+  const int lane = tid & 63, p = UNI(tid >> 6) - CC_CONSUMERS;     // the wave index in an SGPR: `p`-dependent branches are scalar
   __builtin_amdgcn_s_setprio(NBD_CC_PRODUCER_PRIO);
   float* a_dst = L.a_buf + p * SUBR * LDA;
-  int2* my_scr = L.scratch + p * 64;
+  int2* my_scr = L.scratch + p * 128;
   const int I = A.I;
   const bool live = 2 * lane < I;
   const unsigned lane8 = (unsigned)min(2 * lane, I - 2) * 4u;      // clamped: every lane reads inside the row
@@ -491,15 +543,18 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
   const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(A.feat), 0, (int)min((size_t)0x7fffffff, ((size_t)(A.n - 1) * A.ldf + I) * 4), 0x00020000);
   // row records (lane r <= rows: {node, first pair}; lane `rows` = the row behind the last: its first pair ends
-  // the step) and the first 64 pair records of step i
-  auto fetch = [&](int i, int2& rinfo, int& psrc, float& pw) {
+  // the step) and the first 128 pair records of step i (s0 / w0: pairs 0 .. 63; s1 / w1: pairs 64 .. 127; past the
+  // end: the last pair again)
+  struct Pre { int2 rinfo; int s0, s1; float w0, w1; };
+  auto fetch = [&](int i, Pre& f) {
     const int4 r = uni4(L.st4[i]);
     const int2 pr = uni2(L.st2[i]);
     const size_t e8 = (size_t)8 * r.w;
-    rinfo = (A.rows + e8 + r.z)[r.x + min(lane, (r.y >> 8) & 31)];
-    const int at = pr.x + min(lane, pr.y - pr.x - 1);
-    psrc = (A.pair_src + e8)[at];
-    pw = (A.pair_w + e8)[at];
+    f.rinfo = (A.rows + e8 + r.y)[r.z + min(lane, (r.x >> 8) & 31)];
+    const int np = pr.y - pr.x;
+    const int at0 = pr.x + min(lane, np - 1), at1 = pr.x + min(64 + lane, np - 1);
+    f.s0 = (A.pair_src + e8)[at0]; f.w0 = (A.pair_w + e8)[at0];
+    f.s1 = (A.pair_src + e8)[at1]; f.w1 = (A.pair_w + e8)[at1];
   };
   int qbase = 0;
   for (int p0 = g0; p0 < g1; p0 += CC_CAP) {
@@ -507,26 +562,32 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
     DBG_T(t0_)
     cc_load_table(A, L, p0, p1, tid);
     DBG_ACC(true, dbg[2], t0_)
-    int2 rinfo_n = make_int2(0, 0);
-    int psrc_n = 0;
-    float pw_n = 0.f;
-    if (p < npass) fetch(p, rinfo_n, psrc_n, pw_n);
+    Pre nx = {make_int2(0, 0), 0, 0, 0.f, 0.f};
+    if (p < npass) fetch(p, nx);
     for (int i = p; i < npass; i += NBUF) {
       const int use = (qbase + i) / NBUF;
       DBG_T(s0_)
+#if defined(NBD_CC_ABL) && NBD_CC_ABL == 4          /* timing only: no gather at all, the consumers' own speed */
+      if (use > 0) CC_WAIT_ALL_DONE(L.done + p * CC_CONSUMERS, use);
+      if (lane < SUBR) L.rowmap[p * SUBR + lane] = lane;
+      CC_RELEASE_FENCE();
+      if (lane == 0) __hip_atomic_store(&L.full[p], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      continue;
+#endif
       const int4 r = uni4(L.st4[i]);
       const int2 pr = uni2(L.st2[i]);
-      const int cnt = (r.y >> 8) & 31, pb = pr.x, np = pr.y - pr.x;
-      const int2 rinfo = rinfo_n;
-      int psrc = psrc_n;
-      float pw = pw_n;
-      fetch(min(i + NBUF, npass - 1), rinfo_n, psrc_n, pw_n);      // unconditional (the last steps re-fetch themselves)
+      const int cnt = (r.x >> 8) & 31, pb = pr.x, np = pr.y - pr.x;
+      const int nb = (np + PB - 1) / PB;                           // batches of PB pairs in this step
+      const size_t e8 = (size_t)8 * r.w;
+      const Pre cu = nx;
+      const int2 rinfo = cu.rinfo;
+      fetch(min(i + NBUF, npass - 1), nx);                         // unconditional (the last steps re-fetch themselves)
       // the ring buffer is claimed only when the first feature rows are already on their way
       bool claimed = false;
       auto claim = [&]() {
         if (!claimed) {
           DBG_T(c0_)
-          if (use > 0) CC_WAIT(L.done[p], >= CC_CONSUMERS * use);  // the consumers are done with this buffer
+          if (use > 0) CC_WAIT_ALL_DONE(L.done + p * CC_CONSUMERS, use);   // the consumers are done with this buffer
           DBG_ACC(true, dbg[0], c0_)
           if (lane < SUBR) L.rowmap[p * SUBR + lane] = lane < cnt ? rinfo.x : -1;   // padding rows: no node
           claimed = true;
@@ -541,69 +602,97 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
         ++cur;
         next_begin = __builtin_amdgcn_readlane(rinfo.y, cur + 1);
       };
-      for (int c0 = 0; c0 < np; c0 += 64) {
-        const int npc = min(64, np - c0), nb = (npc + PB - 1) / PB;
-        if (c0 > 0) {
-          const size_t at = (size_t)8 * r.w + pb + c0 + min(lane, npc - 1);
-          psrc = A.pair_src[at];
-          pw = A.pair_w[at];
-        }
-        // slots behind the chunk's last pair: the last pair's row (a hot line) with weight 0
-        __builtin_amdgcn_wave_barrier();
-        my_scr[lane] = make_int2((int)((unsigned)psrc * ldb), lane < npc ? __float_as_int(pw) : 0);
-        __builtin_amdgcn_wave_barrier();
-        // NBF batches of PB rows in flight. EVERY stage issues exactly PB row loads (past the end: re-reads of the
-        // last pair's row, L1 hits): only then can hipcc count its s_waitcnt vmcnt() and let batch j be summed while
-        // the younger batches are in flight.
-        f2 fbuf[NBD_CC_NBF][PB];
-#define CC_ISSUE(J)                                                                                          \
-        {                                                                                                    \
+      // The pair records of 128 pairs ("segment") are parked in wave-private LDS -- for the first segment from the
+      // registers fetched a step ago -- and read back as broadcasts: no refill inside the stream of row loads, which
+      // therefore runs through a whole segment with four batches of 8 rows in flight (the first persistent version
+      // re-primed its pipeline every 64 pairs and fetched the next 64 records in between, synchronously: ~4 of the 9 us
+      // a D = 4 step of ~80 pairs took). Steps of more than 128 pairs (dense clumps) fetch the next segment's records
+      // between segments. (Refilling a ring from inside the loop was tried three ways -- registers, buffer loads,
+      // LDS-DMA: hipcc guarded each with vmcnt(1) / vmcnt(0) at the loop head, or, for the DMA, in front of every LDS
+      // read, draining the rows in flight once per 32 pairs.) Slots behind the step's last pair: the last pair's row
+      // (a hot line) with weight 0.
+      int rs0 = cu.s0, rs1 = cu.s1;
+      float rw0 = cu.w0, rw1 = cu.w1;
+      // NBF batches of PB rows in flight. EVERY stage issues exactly PB row loads (past the end: re-reads of the
+      // last pair's row, L1 hits): only then can hipcc count its s_waitcnt vmcnt() and let batch j be summed while
+      // the younger batches are in flight.
+      f2 fbuf[NBD_CC_NBF][PB];
+#define CC_ISSUE(SLOT, OFF)                                                                                  \
+      {                                                                                                      \
+        _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                                     \
+          const unsigned ro = (unsigned)my_scr[(OFF) + u].x;                                                 \
+          fbuf[SLOT][u] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(frs, (int)(ro + lane8), 0, 0)); \
+        }                                                                                                    \
+      }
+#define CC_SUM(SLOT, OFF, BJ)                                                                                \
+      {                                                                                                      \
+        const int valid = min(PB, np - PB * (BJ)), q0 = pb + PB * (BJ);                                      \
+        float wv[PB];                              /* the weights: broadcast reads of the parked records */  \
+        _Pragma("unroll") for (int u = 0; u < PB; ++u) wv[u] = __int_as_float(my_scr[(OFF) + u].y);          \
+        if (valid == PB) {                                                                                   \
           _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                                   \
-            const unsigned ro = (unsigned)my_scr[PB * (J) + u].x;                                            \
-            fbuf[(J) % NBD_CC_NBF][u] = __builtin_bit_cast(                                                  \
-                f2, __builtin_amdgcn_raw_buffer_load_b64(frs, (int)(ro + lane8), 0, 0));                     \
+            if (q0 + u == next_begin) flush();                         /* wave-uniform */                    \
+            const float w = wv[u];                                                                           \
+            acc = __builtin_elementwise_fma(f2{w, w}, fbuf[SLOT][u], acc);                                   \
           }                                                                                                  \
-        }
-#define CC_SUM(J)                                                                                            \
-        {                                                                                                    \
-          const int valid = min(PB, npc - PB * (J)), q0 = pb + c0 + PB * (J);                                \
-          float wv[PB];                            /* the weights: broadcast reads of the parked records */  \
-          _Pragma("unroll") for (int u = 0; u < PB; ++u) wv[u] = __int_as_float(my_scr[PB * (J) + u].y);     \
-          if (valid == PB) {                                                                                 \
-            _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                                 \
-              if (q0 + u == next_begin) flush();                       /* wave-uniform */                    \
+        } else {                                                                                             \
+          _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                                   \
+            if (u < valid) {                                           /* wave-uniform */                    \
+              if (q0 + u == next_begin) flush();                                                             \
               const float w = wv[u];                                                                         \
-              acc = __builtin_elementwise_fma(f2{w, w}, fbuf[(J) % NBD_CC_NBF][u], acc);                     \
-            }                                                                                                \
-          } else {                                                                                           \
-            _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                                 \
-              if (u < valid) {                                         /* wave-uniform */                    \
-                if (q0 + u == next_begin) flush();                                                           \
-                const float w = wv[u];                                                                       \
-                acc = __builtin_elementwise_fma(f2{w, w}, fbuf[(J) % NBD_CC_NBF][u], acc);                   \
-              }                                                                                              \
+              acc = __builtin_elementwise_fma(f2{w, w}, fbuf[SLOT][u], acc);                                 \
             }                                                                                                \
           }                                                                                                  \
+        }                                                                                                    \
+      }
+      // stage J of trip h (32 pairs): batch 4 h + J summed with three younger batches in flight, then batch
+      // 4 h + J + 4 requested into the slot just freed (the last trip of a segment only sums)
+#define CC_STAGE(J, ISSUE_NEXT)                                                                              \
+      CC_SUM(J, 32 * HQ + PB * (J), b0 + 4 * HQ + (J))                                                       \
+      if (b0 + 4 * HQ + (J) + 1 >= nb) { done = true; break; }                                               \
+      if (ISSUE_NEXT) CC_ISSUE(J, 32 * HQ + 32 + PB * (J))
+      static_assert(PB == 8 && NBD_CC_NBF == 4, "the slot rotation below is written out for four batches of 8 in flight");
+      bool done = false;
+      for (int b0 = 0; !done; b0 += 16) {                            // one segment = 16 batches = 128 pairs
+        if (b0 > 0) {
+          const size_t at0 = e8 + pb + min(PB * b0 + lane, np - 1), at1 = e8 + pb + min(PB * b0 + 64 + lane, np - 1);
+          rs0 = A.pair_src[at0]; rw0 = A.pair_w[at0];
+          rs1 = A.pair_src[at1]; rw1 = A.pair_w[at1];
         }
-        // stage J: rows of batch J + NBF - 1 on their way, batch J summed meanwhile (64 pairs = 8 batches)
-#define CC_STAGE(J)                                                                                          \
-        if ((J) + NBD_CC_NBF - 1 < 64 / PB) CC_ISSUE((J) + NBD_CC_NBF - 1)                                   \
-        CC_SUM(J)                                                                                            \
-        if ((J) + 1 >= nb) break;
-        static_assert(64 / PB == 8 && NBD_CC_NBF >= 2 && NBD_CC_NBF <= 5, "stages below are written out for 8 batches");
+        __builtin_amdgcn_wave_barrier();
+        my_scr[lane] = make_int2((int)((unsigned)rs0 * ldb), PB * b0 + lane < np ? __float_as_int(rw0) : 0);
+        my_scr[64 + lane] = make_int2((int)((unsigned)rs1 * ldb), PB * b0 + 64 + lane < np ? __float_as_int(rw1) : 0);
+        __builtin_amdgcn_wave_barrier();
+        CC_ISSUE(0, 0)
+        CC_ISSUE(1, PB)
+        CC_ISSUE(2, 2 * PB)
+        CC_ISSUE(3, 3 * PB)
+        claim();
         do {
-          CC_ISSUE(0)
-          if (NBD_CC_NBF > 2) CC_ISSUE(1)
-          if (NBD_CC_NBF > 3) CC_ISSUE(2)
-          if (NBD_CC_NBF > 4) CC_ISSUE(3)
-          claim();
-          CC_STAGE(0) CC_STAGE(1) CC_STAGE(2) CC_STAGE(3) CC_STAGE(4) CC_STAGE(5) CC_STAGE(6) CC_STAGE(7)
+#define HQ 0
+          CC_STAGE(0, true) CC_STAGE(1, true) CC_STAGE(2, true) CC_STAGE(3, true)
+#undef HQ
+#define HQ 1
+          CC_STAGE(0, true) CC_STAGE(1, true) CC_STAGE(2, true) CC_STAGE(3, true)
+#undef HQ
+#define HQ 2
+          CC_STAGE(0, true) CC_STAGE(1, true) CC_STAGE(2, true) CC_STAGE(3, true)
+#undef HQ
+#define HQ 3
+          CC_STAGE(0, false) CC_STAGE(1, false) CC_STAGE(2, false) CC_STAGE(3, false)
+#undef HQ
         } while (0);
+      }
 #undef CC_STAGE
 #undef CC_SUM
 #undef CC_ISSUE
-      }
-      claim();
+      // The loop leaves up to three batches in flight (issued past the step's end, never summed). They
+      // are "used" here so that hipcc retires them now: left pending, their registers -- reused as temporaries at the
+      // loop head -- made every wait there a vmcnt(0) that drained the row loads in flight (seen in the ISA).
+#pragma unroll
+      for (int sl = 0; sl < NBD_CC_NBF; ++sl)
+#pragma unroll
+        for (int u = 0; u < PB; ++u) asm volatile("" ::"v"(fbuf[sl][u]));
       *reinterpret_cast<f2*>(a_dst + cur * LDA + 2 * lane) = live ? acc : f2{0.f, 0.f};
       CC_RELEASE_FENCE();
       if (lane == 0) __hip_atomic_store(&L.full[p], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -614,18 +703,25 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
 }
 
 // ---------------- consumer: 16 output columns, all steps in order
-// Two consumer waves share a SIMD (waves w and w + 4): while one scatters its results or waits on a flag, the
-// other's MFMAs keep the matrix pipe busy. A step is ONE 16 x 16 tile per wave, the K = I contraction in two
-// independent accumulator chains; the MFMA takes the filter fragment as its first operand and the packed A rows as
-// its second, so the result comes out transposed -- lane l holds output columns 4 (l >> 4) .. + 3 of packed row
+// Two consumer waves share a SIMD (waves w and w + 4). A step is ONE 16 x 16 tile per wave, the K = I contraction in
+// two independent accumulator chains; the MFMA takes the filter fragment as its first operand and the packed A rows
+// as its second, so the result comes out transposed -- lane l holds output columns 4 (l >> 4) .. + 3 of packed row
 // l & 15 -- and the scatter into the node's accumulator row is one ds_read_b128 + ds_write_b128 per lane (with the
 // operands the other way round a lane held one column of four rows: eight 32-bit read-modify-writes per step).
 // The fragment (I / 16 dwordx4 per lane) sits in registers, the next cell's is fetched into a second set while
 // this one multiplies (the two sets alternate: no copies). When the range crosses into the next tile (and at its
 // end) the wave writes its 16 columns of the accumulator to partial slot (workgroup + tile) and zeroes them.
+//
+// SOFTWARE PIPELINE (round 3). In-kernel stamps of the first persistent version: a consumer wave spent 0.49 us of a
+// 1.83 us step issuing MFMAs and the rest in LDS round trips that nothing overlapped -- step record (tile), flag poll,
+// first fragment read, cell bookkeeping (2 dependent reads per cell), each 150-400 cycles with 16 waves on the LDS --
+// and with two waves per SIMD the pipe sat idle 47 % of the time. Now every control read is issued one step (or one
+// cell) before its value is used: while step i multiplies, the wave reads step i + 1's record and flag, and -- if that
+// step is already full, the normal case with the producers running ahead -- its row map and first two fragment
+// quads; the next cell's {cell, steps} come from a read issued a whole cell earlier.
 template <int KG>
 __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int g0, int g1, int tid, long long* dbg) {
-  const int lane = tid & 63, cw = tid >> 6;
+  const int lane = tid & 63, cw = UNI(tid >> 6);
   if (cw < CC_CONSUMERS / 2) __builtin_amdgcn_s_setprio(NBD_CC_PRIO_HI);
   else __builtin_amdgcn_s_setprio(NBD_CC_PRIO_LO);
   const int cb = blockIdx.z * CC_CONSUMERS + cw;                   // 16-column block of the output
@@ -633,107 +729,203 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
   const bool has_cols = cb < colblocks;
   int cur_tile = -1;
   auto flush_acc = [&](int tile) {
-    float* dst = A.partial + ((size_t)(blockIdx.x + tile) * TN) * A.OP + (size_t)blockIdx.z * 128 + cw * 16 + (lane & 3) * 4;
-    float* src = L.out_acc + cw * 16 + (lane & 3) * 4;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));     // opaque: keeps hipcc from hoisting this rare path's per-lane addresses out of the step
+                                     // loops, where they cost five VGPRs that then spilled (and every spill slot's
+                                     // s_waitcnt vmcnt(0) drained the fragment prefetch)
+    float* dst = A.partial + ((size_t)(blockIdx.x + tile) * TN) * A.OP + (size_t)blockIdx.z * 128 + cw * 16 + (ln & 3) * 4;
+    float* src = L.out_acc + cw * 16 + (ln & 3) * 4;
 #pragma unroll 4
     for (int r0 = 0; r0 < TN; r0 += 16) {
-      const int r = r0 + (lane >> 2);
+      const int r = r0 + (ln >> 2);
       f4* a = reinterpret_cast<f4*>(src + r * LDO);
       *reinterpret_cast<f4*>(dst + (size_t)r * A.OP) = *a;
       *a = f4{0.f, 0.f, 0.f, 0.f};
     }
-  };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores and loads retire out of order with each other: keep the
+  };                                                   // hand-counted vmcnt of the fragment prefetch among loads only
+  static_assert(KG == 8 || KG == 2, "CC_FRAGMENT_LANDED counts KG loads");
   f4 bf0[KG], bf1[KG];
-  // always exactly KG loads (clamped index, zeroed afterwards): a counted s_waitcnt vmcnt(KG) is only possible
-  // when the number of younger loads does not depend on the path taken
+  // The next cell's fragment is requested a whole cell ahead and must stay IN FLIGHT until that cell starts. hipcc
+  // cannot express that: with builtin loads its s_waitcnt insertion put vmcnt(7) .. vmcnt(0) in front of the first
+  // MFMAs of a cell -- counting the loads just issued for the NEXT cell as if they were the current one's -- so every
+  // cell change waited out the L2 / Infinity Cache latency of the prefetch it had just started (in-kernel stamps:
+  // 0.73 us per step outside the steps, 40 % of a consumer wave's time; round 2's kernel had the same vmcnt(5) ..
+  // vmcnt(0) ladder behind its `g < kq_count ? v : 0` select). So the loads are issued from inline asm, which the
+  // compiler's wait insertion does not track, and the wait is written here: vmcnt(KG) in front of a cell's first
+  // step = "everything but the KG loads just issued for the next cell has landed". The "+v" operands of the wait
+  // make every use of the fragment depend on it. tools/check_contconv_isa.py (run by the CPU tests) verifies in the
+  // disassembly that nothing touches a fragment register between its load and that wait. K-groups beyond I
+  // (g >= kq_count) re-read the last group: finite numbers that meet all-zero A columns (the producers write zeros
+  // beyond I). The consumers issue no other vector-memory loads; the stores of flush_acc are drained on the spot.
+  // Addressing: the wave's column block of cell 0 as a scalar base, the cell's byte offset + 16 * lane in one VGPR
+  // (the filter matrix is checked < 2 GiB on the host), the k-groups as immediate offsets of two loads bases.
+  const char* fbase = reinterpret_cast<const char*>(A.filt) + (size_t)min(cb, colblocks - 1) * kq_count * 1024;
+  const unsigned cell_stride = (unsigned)colblocks * (unsigned)kq_count * 1024u;      // bytes between cells
   auto load_b = [&](f4* dstv, int cell) {
-    const f4* src = A.filt + (((size_t)cell * colblocks + min(cb, colblocks - 1)) * kq_count) * 64 + lane;
+    const unsigned off0 = (unsigned)cell * cell_stride + (unsigned)lane * 16u;
+    if (KG == 8) {
+      const unsigned g4 = (unsigned)min(4, kq_count - 1) * 1024u;                       // I <= 64: groups 4-7 re-read group kq-1
+      const unsigned off1 = off0 + g4;
+      const unsigned d1 = kq_count > 1 ? 1024u : 0u, d2 = kq_count > 2 ? 2048u : d1, d3 = kq_count > 3 ? 3072u : d2;
+      const unsigned e1 = kq_count > 5 ? 1024u : 0u, e2 = kq_count > 6 ? 2048u : e1, e3 = kq_count > 7 ? 3072u : e2;
+      if (kq_count == 8) {            // the published shape: immediates
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dstv[0]) : "v"(off0), "s"(fbase) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(dstv[1]) : "v"(off0), "s"(fbase) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=&v"(dstv[2]) : "v"(off0), "s"(fbase) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=&v"(dstv[3]) : "v"(off0), "s"(fbase) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dstv[4]) : "v"(off1), "s"(fbase) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(dstv[5]) : "v"(off1), "s"(fbase) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=&v"(dstv[6]) : "v"(off1), "s"(fbase) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=&v"(dstv[7]) : "v"(off1), "s"(fbase) : "memory");
+      } else {
+        const unsigned o[8] = {off0, off0 + d1, off0 + d2, off0 + d3, off1, off1 + e1, off1 + e2, off1 + e3};
 #pragma unroll
-    for (int g = 0; g < KG; ++g) {
-      const f4 v = src[(size_t)min(g, kq_count - 1) * 64];
-      dstv[g] = (g < kq_count) ? v : f4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < 8; ++g)
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dstv[g]) : "v"(o[g]), "s"(fbase) : "memory");
+      }
+    } else {
+      const unsigned off1 = off0 + (kq_count > 1 ? 1024u : 0u);
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dstv[0]) : "v"(off0), "s"(fbase) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dstv[KG - 1]) : "v"(off1), "s"(fbase) : "memory");
     }
   };
+  const int a_lane = (lane & 15) * LDA + (lane >> 4) * 4;            // this lane's corner of a step's A tile
+  const int o_lane = cw * 16 + 4 * (lane >> 4);
   int qbase = 0;
   for (int p0 = g0; p0 < g1; p0 += CC_CAP) {
     const int p1 = min(g1, p0 + CC_CAP), npass = p1 - p0;
     DBG_T(t0_)
     cc_load_table(A, L, p0, p1, tid);
     DBG_ACC(true, dbg[2], t0_)
+    // pipeline registers: the first reads of the step about to run (when `have`), that step's tile
+    f4 a0n = {0.f, 0.f, 0.f, 0.f}, a1n = {0.f, 0.f, 0.f, 0.f};
+    int node_n = -1;
+    bool have = false;
+    int tile_n = UNI(L.st4[0].y);
+#define CC_FRAGMENT_LANDED(BC)                                                                               \
+    if (has_cols) {                                                                                          \
+      if (KG == 8)                                                                                           \
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(BC[0]), "+v"(BC[1]), "+v"(BC[2]), "+v"(BC[3]), "+v"(BC[4]), \
+                     "+v"(BC[5]), "+v"(BC[6]), "+v"(BC[7]));                                                 \
+      else                                                                                                   \
+        asm volatile("s_waitcnt vmcnt(2)" : "+v"(BC[0]), "+v"(BC[1]));                                       \
+    }
+#define CC_FIRST_READS(B)                                                                                    \
+    {                                                                                                        \
+      node_n = L.rowmap[(B) * SUBR + (lane & 15)];                                                           \
+      a0n = *reinterpret_cast<const f4*>(L.a_buf + (B) * SUBR * LDA + a_lane);                               \
+      if (KG > 1) a1n = *reinterpret_cast<const f4*>(L.a_buf + (B) * SUBR * LDA + a_lane + 16);              \
+    }
 #define CC_STEP(BC, IDX)                                                                                     \
     {                                                                                                        \
       const int q_ = qbase + (IDX), b = q_ & (NBUF - 1), use = q_ / NBUF;                                    \
-      const int tile_ = UNI(L.st4[IDX].z);                                                                   \
-      if (tile_ != cur_tile) {                         /* the range crosses into the next tile */          \
+      if (tile_n != cur_tile) {                        /* the range crosses into the next tile */          \
         if (cur_tile >= 0 && has_cols) flush_acc(cur_tile);                                                  \
-        cur_tile = tile_;                                                                                    \
+        cur_tile = tile_n;                                                                                   \
       }                                                                                                      \
-      DBG_T(c0_) CC_WAIT(L.full[b], >= use + 1);                                                             \
-      DBG_ACC(true, dbg[0], c0_)                                                                             \
+      if (!have) {                                     /* not prefetched: the step was not full yet */     \
+        DBG_T(c0_) CC_WAIT(L.full[b], >= use + 1);                                                           \
+        DBG_ACC(true, dbg[0], c0_)                                                                           \
+        if (has_cols) CC_FIRST_READS(b)                                                                      \
+      }                                                                                                      \
       DBG_T(w0_)                                                                                             \
-      if (has_cols) {                                                                                        \
+      /* control reads for step IDX + 1, issued now, used half a burst later */                             \
+      const int nidx_ = min((IDX) + 1, npass - 1), bn_ = (q_ + 1) & (NBUF - 1);                              \
+      const int tile_v_ = L.st4[nidx_].y;                                                                    \
+      const int flag_v_ = __hip_atomic_load(&L.full[bn_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
+      if (has_cols && !CC_ABL_NO_CONSUME) {                                                                  \
         f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};                                        \
-        const float* a_base = L.a_buf + (b * SUBR + (lane & 15)) * LDA + (lane >> 4) * 4;                    \
+        const float* a_base = L.a_buf + b * SUBR * LDA + a_lane;                                             \
+        const int node = node_n;                                                                             \
         f4 av[KG];                                                                                           \
-        /* Issue order (left alone, hipcc issued read, wait, 4 MFMAs, read, wait ...): the row map and two      \
-           fragment reads ahead; then one LDS read behind every four MFMAs -- the next-but-one fragment, last   \
-           the node's accumulator quad (padding rows: row 0, discarded; in program order behind the previous    \
-           step's write of this wave) -- so that each read's latency runs under 128 cycles of matrix work. */   \
-        const int node = L.rowmap[b * SUBR + (lane & 15)];                                                   \
-        av[0] = *reinterpret_cast<const f4*>(a_base);                                                        \
-        if (KG > 1) av[1] = *reinterpret_cast<const f4*>(a_base + 16);                                       \
+        av[0] = a0n;                                                                                         \
+        if (KG > 1) av[1] = a1n;                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
+        /* ALL the remaining fragment reads at once, then the first half of the burst: an LDS read takes 300-400 \
+           cycles with 16 waves on the array -- issued one MFMA group (128 cycles) ahead, as hipcc and the first \
+           persistent version did, every group waited out the difference */                                   \
         _Pragma("unroll") for (int g = 2; g < KG; ++g) av[g] = *reinterpret_cast<const f4*>(a_base + g * 16); \
-        f4* o = reinterpret_cast<f4*>(L.out_acc + max(node, 0) * LDO + cw * 16 + 4 * (lane >> 4));           \
-        const f4 old = *o;                                                                                   \
-        _Pragma("unroll") for (int g = 0; g < KG; ++g) {                                                     \
+        _Pragma("unroll") for (int g = 0; g < KG && g < 4; ++g) {                                            \
           CC_MFMA(acc0, BC[g][0], av[g][0]) CC_MFMA(acc1, BC[g][1], av[g][1])                                \
           CC_MFMA(acc0, BC[g][2], av[g][2]) CC_MFMA(acc1, BC[g][3], av[g][3])                                \
         }                                                                                                    \
         if (KG == 8) {                                                                                       \
-          _Pragma("unroll") for (int g = 0; g < 7; ++g) {                                                    \
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                               \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
-          }                                                                                                  \
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                 \
+          __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                                 \
+          __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                                \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        /* mid-burst: is step IDX + 1 already full? then its row map and first fragment quads come now */   \
+        tile_n = UNI(tile_v_);                                                                               \
+        have = (IDX) + 1 < npass && UNI(flag_v_) >= (q_ + 1) / NBUF + 1;                                     \
+        if (have) {                                                                                          \
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");                                    \
+          CC_FIRST_READS(bn_)                                                                                \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        /* second half, the node's accumulator quad requested in front of it (padding rows: row 0, discarded;  \
+           in program order behind the previous step's write of this wave) */                                \
+        f4* o = reinterpret_cast<f4*>(L.out_acc + max(node, 0) * LDO + o_lane);                              \
+        const f4 old = *o;                                                                                   \
+        _Pragma("unroll") for (int g = 4; g < KG; ++g) {                                                     \
+          CC_MFMA(acc0, BC[g][0], av[g][0]) CC_MFMA(acc1, BC[g][1], av[g][1])                                \
+          CC_MFMA(acc0, BC[g][2], av[g][2]) CC_MFMA(acc1, BC[g][3], av[g][3])                                \
+        }                                                                                                    \
+        if (KG == 8) {                                                                                       \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
+          __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                                \
         }                                                                                                    \
         /* the buffer can go back to its producer: A and the row map are in registers */                    \
         CC_RELEASE_FENCE();                                                                                  \
-        if (lane == 0) __hip_atomic_fetch_add(&L.done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\
+        if (lane == 0) __hip_atomic_store(&L.done[b * CC_CONSUMERS + cw], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
         if (node >= 0)                                                                                       \
           *o = f4{old[0] + (acc0[0] + acc1[0]), old[1] + (acc0[1] + acc1[1]), old[2] + (acc0[2] + acc1[2]),  \
                   old[3] + (acc0[3] + acc1[3])};                                                             \
-      } else if (lane == 0) {                                                                                \
-        __hip_atomic_fetch_add(&L.done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);               \
+      } else {                                                                                               \
+        tile_n = UNI(tile_v_);                                                                               \
+        have = false;                                                                                        \
+        if (lane == 0) __hip_atomic_store(&L.done[b * CC_CONSUMERS + cw], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
       }                                                                                                      \
       DBG_ACC(true, dbg[1], w0_)                                                                             \
     }
     // Cells two at a time: the even cell multiplies with fragment set 0 while set 1 is fetched for the odd cell
     // and vice versa. Written out like this (instead of a parity switch inside one loop) the loads of the NEXT
     // cell are the only ones younger than the current cell's, so the wait before the first MFMA is a counted
-    // vmcnt(KG) and the prefetch really stays in flight.
-    auto cell_of = [&](int i) { return UNI(L.st4[i].y) & 0xff; };
-    auto left_of = [&](int i) { return min((UNI(L.st4[i].y) >> 16) & 0xff, npass - i); };
+    // vmcnt(KG) and the prefetch really stays in flight. {cell, steps left} of the cell after the next one is read
+    // at the start of a cell and used at the start of the next.
+    auto meta_at = [&](int i) { return L.st4[min(i, npass - 1)].x; };      // cell | rows << 8 | steps left << 16
+    auto steps_of = [&](int meta, int i) { return min((meta >> 16) & 0xff, npass - i); };
     int i = 0;
-    if (has_cols) load_b(bf0, cell_of(0));
+    int meta = UNI(meta_at(0));
+    if (has_cols) { load_b(bf0, meta & 0xff); if (CC_ABL_ONE_FRAGMENT) load_b(bf1, meta & 0xff); }
+    int rem = steps_of(meta, 0);
+    int meta_nv = meta_at(rem);                                        // next cell's record, value still on its way
     while (i < npass) {
       {
-        const int rem = left_of(i), inext = i + rem;
-        if (has_cols) load_b(bf1, cell_of(min(inext, npass - 1)));   // the last cell re-fetches itself: never used
+        const int inext = i + rem;
+        const int meta_n = UNI(meta_nv), rem_n = steps_of(meta_n, inext);
+        if (has_cols && !CC_ABL_ONE_FRAGMENT) load_b(bf1, meta_n & 0xff);   // past the end: the last cell again, never used
+        meta_nv = meta_at(inext + rem_n);
+        CC_FRAGMENT_LANDED(bf0)
         CC_STEP(bf0, i)
         for (int u = 1; u < rem; ++u) CC_STEP(bf0, i + u)
-        i = inext;
+        i = inext; rem = rem_n;
       }
       if (i >= npass) break;
       {
-        const int rem = left_of(i), inext = i + rem;
-        if (has_cols) load_b(bf0, cell_of(min(inext, npass - 1)));
+        const int inext = i + rem;
+        const int meta_n = UNI(meta_nv), rem_n = steps_of(meta_n, inext);
+        if (has_cols && !CC_ABL_ONE_FRAGMENT) load_b(bf0, meta_n & 0xff);
+        meta_nv = meta_at(inext + rem_n);
+        CC_FRAGMENT_LANDED(bf1)
         CC_STEP(bf1, i)
         for (int u = 1; u < rem; ++u) CC_STEP(bf1, i + u)
-        i = inext;
+        i = inext; rem = rem_n;
       }
     }
 #undef CC_STEP
+#undef CC_FIRST_READS
+#undef CC_FRAGMENT_LANDED
     qbase += npass;
   }
   if (has_cols && cur_tile >= 0) flush_acc(cur_tile);
@@ -744,33 +936,80 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
   // f4-typed so that the dynamic region starts 16-byte aligned behind the static __shared__ variables (declared as
   // float[] it began at an 8-byte offset and every ds_read_b128 / ds_write_b64 took the unaligned path)
   extern __shared__ f4 lds_aligned[];
-  __shared__ int statics[48];                                      // s_red[16], s_nseg, full[8], done[8]
-  __shared__ int s_total;
+  __shared__ int statics[32 + NBUF * CC_CONSUMERS];                // s_red[16], s_nseg, full[8], done[8][8]
+  __shared__ int s_total, s_ctot, s_hit[4], s_red2[16];
   const CCLds L = cc_lds(reinterpret_cast<float*>(lds_aligned), statics);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = UNI(tid >> 6);
 #ifdef NBD_CC_TRACE
   const long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
   __shared__ long long s_dbg[16][4];
 #endif
   long long dbg_wait[4] = {0, 0, 0, 0};        // [0] time on the flags, [1] in the steps, [2] in the table loads, [3] whole role
 
-  // ---- this workgroup's range of the global step sequence: [T w / G, T (w + 1) / G)
+  // ---- this workgroup's range of the global step sequence. The sequence is cut where the running COST (per step:
+  // max(CC_COST_MIN, pairs)) crosses w / G of its total: equal matrix work where the tiles are sparse, equal gather work
+  // where they are dense (cut by step COUNT, the first persistent version left the densest workgroups running 1.4x the
+  // mean at D = 4: their producers, not their MFMAs, set the pace). cut(w) = first step whose cost-before is >= B_w.
   {
-    int loc = 0;
-    for (int t = tid; t < A.n_tiles; t += CC_THREADS) loc += A.tile_nsteps[t];
-    loc = wave_sum(loc);
-    if (lane == 0) L.s_red[wave] = loc;
+    int lc = 0, ls = 0;
+    for (int t = tid; t < A.n_tiles; t += CC_THREADS) { lc += A.tile_cost[t]; ls += A.tile_nsteps[t]; }
+    lc = wave_sum(lc); ls = wave_sum(ls);
+    if (lane == 0) { L.s_red[wave] = lc; s_red2[wave] = ls; }
     __syncthreads();
     if (tid == 0) {
-      int T = 0;
-      for (int i = 0; i < CC_THREADS / 64; ++i) T += L.s_red[i];
-      s_total = T;
+      int C = 0, T = 0;
+      for (int i = 0; i < CC_THREADS / 64; ++i) { C += L.s_red[i]; T += s_red2[i]; }
+      s_total = T; s_ctot = C;
     }
-    if (tid < NBUF) { L.full[tid] = 0; L.done[tid] = 0; }
+    if (tid < NBUF) L.full[tid] = 0;
+    if (tid < NBUF * CC_CONSUMERS) L.done[tid] = 0;
     __syncthreads();
   }
-  const long long T = UNI(s_total);
-  const int g0 = range_begin(T, blockIdx.x, gridDim.x), g1 = range_begin(T, blockIdx.x + 1, gridDim.x);
+  const int T = UNI(s_total);
+  const long long Ctot = UNI(s_ctot);
+  auto cut = [&](int w) -> int {                                   // all threads; a few barriers
+    if (w <= 0) return 0;
+    if (w >= (int)gridDim.x) return T;
+    const int B = (int)(Ctot * w / gridDim.x);
+    if (tid == 0) s_hit[0] = -1;
+    int cbase = 0, sbase = 0;
+    for (int c0 = 0; c0 < A.n_tiles; c0 += CC_THREADS) {
+      const int t = c0 + tid;
+      const int vc = t < A.n_tiles ? A.tile_cost[t] : 0, vs = t < A.n_tiles ? A.tile_nsteps[t] : 0;
+      const int ic = wave_incl_scan(vc, lane), is = wave_incl_scan(vs, lane);
+      __syncthreads();
+      if (lane == 63) { L.s_red[wave] = ic; s_red2[wave] = is; }
+      __syncthreads();
+      int oc = 0, os = 0, tc = 0, ts = 0;
+      for (int i = 0; i < CC_THREADS / 64; ++i) {
+        const int x = L.s_red[i], y = s_red2[i];
+        oc += i < wave ? x : 0; os += i < wave ? y : 0; tc += x; ts += y;
+      }
+      const int cb = cbase + oc + ic - vc;
+      if (vc > 0 && cb <= B && B < cb + vc) { s_hit[0] = t; s_hit[1] = B - cb; s_hit[2] = sbase + os + is - vs; s_hit[3] = vs; }
+      cbase += UNI(tc); sbase += UNI(ts);
+    }
+    __syncthreads();
+    const int t = UNI(s_hit[0]);
+    if (t < 0) return T;                                           // B beyond the last step's start (cannot happen for w < G)
+    const int rel = UNI(s_hit[1]), sb = UNI(s_hit[2]), ns = UNI(s_hit[3]);
+    if (rel == 0) return sb;
+    const int4* ts_ = A.steps + step_base(t, UNI(A.rowptr[t * TN]), A.n_cells);
+    int cnt = 0;
+    for (int i = tid; i < ns; i += CC_THREADS) cnt += ts_[i].w < rel ? 1 : 0;      // steps i + 1 that start before rel
+    cnt = wave_sum(cnt);
+    __syncthreads();
+    if (lane == 0) L.s_red[wave] = cnt;
+    __syncthreads();
+    int tot = 0;
+    for (int i = 0; i < CC_THREADS / 64; ++i) tot += L.s_red[i];
+    return sb + min(1 + UNI(tot), ns);
+  };
+  const int g0 = cut(blockIdx.x), g1 = cut(blockIdx.x + 1);
+  if (tid == 0 && blockIdx.z == 0) {
+    A.cuts[blockIdx.x] = g0;
+    if (blockIdx.x + 1 == gridDim.x) A.cuts[gridDim.x] = g1;
+  }
   if (g0 >= g1) return;                                            // uniform: the whole workgroup leaves
   for (int i = tid; i < TN * LDO / 4; i += CC_THREADS) reinterpret_cast<f4*>(L.out_acc)[i] = f4{0.f, 0.f, 0.f, 0.f};
   // (the first cc_load_table's barriers order the zeroing before any consumer's first scatter)
@@ -793,34 +1032,29 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
 }
 
 // out = act(scale * sum of the tile's partial slots), in workgroup order. grid (tiles, 4): 32 rows of a tile each.
+// cuts[w] = first step of workgroup w's range (written by the fused kernel): the workgroups whose ranges meet the
+// tile's steps [base, base + cnt) are the ones that wrote a slot for it.
 __global__ __launch_bounds__(256) void contconv_stream_finish_kernel(
-    const float* __restrict__ partial, const int* __restrict__ tile_nsteps, int n_tiles, int G,
-    const float* __restrict__ rowscale, int act, float* __restrict__ out, int ldo, int n, int O, int OP) {
-  __shared__ int s_lo[4], s_tot[4];
+    const float* __restrict__ partial, const int* __restrict__ tile_nsteps, const int* __restrict__ cuts, int n_tiles,
+    int G, const float* __restrict__ rowscale, int act, float* __restrict__ out, int ldo, int n, int O, int OP) {
+  __shared__ int s_lo[4];
+  __shared__ int s_cut[CC_GRID + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
-  int lo = 0, tot = 0;
-  for (int t = tid; t < n_tiles; t += 256) {
-    const int v = tile_nsteps[t];
-    tot += v;
-    lo += t < tile ? v : 0;
-  }
-  lo = wave_sum(lo); tot = wave_sum(tot);
-  if (lane == 0) { s_lo[wave] = lo; s_tot[wave] = tot; }
+  int lo = 0;
+  for (int t = tid; t < tile; t += 256) lo += tile_nsteps[t];
+  lo = wave_sum(lo);
+  if (lane == 0) s_lo[wave] = lo;
+  for (int w = tid; w <= G; w += 256) s_cut[w] = cuts[w];
   __syncthreads();
   const int base = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
-  const long long T = (long long)s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
   const int cnt = tile_nsteps[tile];
   int w_first = 0, w_last = -1;
   if (cnt > 0) {
-    // owner of step g: the workgroup w with range_begin(w) <= g < range_begin(w + 1)
-    auto owner = [&](int g) {
-      int w = (int)((long long)g * G / T);
-      while (w + 1 < G && range_begin(T, w + 1, G) <= g) ++w;
-      while (w > 0 && range_begin(T, w, G) > g) --w;
-      return w;
-    };
-    w_first = owner(base);
-    w_last = owner(base + cnt - 1);
+    int a = 0, b = G - 1;                                          // largest w with cut[w] <= base
+    while (a < b) { const int m = (a + b + 1) >> 1; if (s_cut[m] <= base) a = m; else b = m - 1; }
+    w_first = a;
+    w_last = a;
+    while (w_last + 1 < G && s_cut[w_last + 1] < base + cnt) ++w_last;
   }
   const int r0 = tile * TN + blockIdx.y * 32;
   for (int e = tid; e < 32 * OP / 4; e += 256) {
@@ -829,7 +1063,7 @@ __global__ __launch_bounds__(256) void contconv_stream_finish_kernel(
     if (row >= n || c >= O) continue;
     f4 v = {0.f, 0.f, 0.f, 0.f};
     for (int w = w_first; w <= w_last; ++w) {
-      if (range_begin(T, w, G) >= range_begin(T, w + 1, G)) continue;          // empty range: wrote nothing
+      if (s_cut[w] >= s_cut[w + 1]) continue;                                  // empty range: wrote nothing
       const f4 x = *reinterpret_cast<const f4*>(partial + ((size_t)(w + tile) * TN + (row - tile * TN)) * OP + c);
       v = f4{v[0] + x[0], v[1] + x[1], v[2] + x[2], v[3] + x[3]};
     }
@@ -862,7 +1096,7 @@ int nbd_contconv_fused_supported(int in_channels, int out_channels, int n_cells)
 }
 
 namespace {
-struct PairsLayout { size_t desc, rows, src, w, steps, nsteps, total; };
+struct PairsLayout { size_t desc, rows, src, w, steps, nsteps, cost, total; };
 PairsLayout pairs_layout(int n, int64_t edge_capacity, int n_cells) {
   const size_t tiles = (size_t)ceil_div(n, TN);
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -874,6 +1108,7 @@ PairsLayout pairs_layout(int n, int64_t edge_capacity, int n_cells) {
   L.w = at; at += up((size_t)8 * edge_capacity * sizeof(float));
   L.steps = at; at += up((step_base((int)tiles, (int)edge_capacity, n_cells) + 2) * sizeof(int4));
   L.nsteps = at; at += up(tiles * sizeof(int));
+  L.cost = at; at += up(tiles * sizeof(int));
   L.total = at + 256;
   return L;
 }
@@ -908,6 +1143,7 @@ int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int*
     j.desc = reinterpret_cast<int2*>(base + L.desc); j.rows = reinterpret_cast<int2*>(base + L.rows);
     j.pair_src = reinterpret_cast<int*>(base + L.src); j.pair_w = reinterpret_cast<float*>(base + L.w);
     j.steps = reinterpret_cast<int4*>(base + L.steps); j.tile_nsteps = reinterpret_cast<int*>(base + L.nsteps);
+    j.tile_cost = reinterpret_cast<int*>(base + L.cost);
     const int kc = (nc + 3) & ~3;
     if (kc > kc_max) kc_max = kc;
   }
@@ -932,10 +1168,12 @@ int nbd_contconv_pairs_f32(const float* pos, const int* rowptr, const int* centr
                                       &n_cells, lists, &pair_lists_bytes, stream);
 }
 
-// partial slots: (workgroup + tile) < CC_GRID + tiles, each TN rows x (column groups x 128) floats
+// [cuts: CC_GRID + 1 ints][partial slots: (workgroup + tile) < CC_GRID + tiles, each TN rows x (column groups x 128) floats]
+constexpr size_t CC_CUTS_BYTES = 4096;
+static_assert((CC_GRID + 1) * sizeof(int) <= CC_CUTS_BYTES, "cuts header");
 size_t nbd_contconv_fused_workspace_bytes(int n, int n_cells, int out_channels) {
   if (n <= 0 || n_cells <= 0 || out_channels <= 0) return 0;
-  return (size_t)(CC_GRID + ceil_div(n, TN)) * TN * (size_t)(ceil_div(out_channels, 128) * 128) * sizeof(float);
+  return CC_CUTS_BYTES + (size_t)(CC_GRID + ceil_div(n, TN)) * TN * (size_t)(ceil_div(out_channels, 128) * 128) * sizeof(float);
 }
 
 size_t nbd_contconv_filter_floats(int in_channels, int out_channels, int n_cells) {
@@ -965,13 +1203,15 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
   const float* pair_w = reinterpret_cast<const float*>(base + L.w);
   const int4* steps = reinterpret_cast<const int4*>(base + L.steps);
   const int* tile_nsteps = reinterpret_cast<const int*>(base + L.nsteps);
+  const int* tile_cost = reinterpret_cast<const int*>(base + L.cost);
   const int tiles = ceil_div(n, TN), colgroups = ceil_div(out_channels, 128), OP = colgroups * 128;
-  float* partial = static_cast<float*>(workspace);
+  int* cuts = static_cast<int*>(workspace);
+  float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + CC_CUTS_BYTES);
   const dim3 grid(CC_GRID, 1, colgroups);
   const int kq_count = ceil_div(in_channels, 16);
   CCArgs A;
   A.feat = feat; A.ldf = ldf; A.I = in_channels; A.rowptr = rowptr; A.n = n; A.n_tiles = tiles;
-  A.rows = rows; A.pair_src = pair_src; A.pair_w = pair_w; A.steps = steps; A.tile_nsteps = tile_nsteps;
+  A.rows = rows; A.pair_src = pair_src; A.pair_w = pair_w; A.steps = steps; A.tile_nsteps = tile_nsteps; A.tile_cost = tile_cost; A.cuts = cuts;
   A.filt = reinterpret_cast<const f4*>(filters_shuffled); A.n_cells = n_cells; A.kq_count = kq_count;
   A.colblocks = ceil_div(out_channels, 16); A.OP = OP; A.partial = partial;
 #define CC_LAUNCH(K)                                                                                                \
@@ -985,7 +1225,7 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
 #undef CC_LAUNCH
   int rc = status();
   if (rc) return rc;
-  contconv_stream_finish_kernel<<<dim3(tiles, 4), 256, 0, st>>>(partial, tile_nsteps, tiles, CC_GRID, rowscale, act, out,
+  contconv_stream_finish_kernel<<<dim3(tiles, 4), 256, 0, st>>>(partial, tile_nsteps, cuts, tiles, CC_GRID, rowscale, act, out,
                                                                  ldo, n, out_channels, OP);
   return status();
 }

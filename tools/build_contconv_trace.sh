@@ -10,7 +10,7 @@ cd "$(dirname "$0")/../nbody-deep-sim_amd/csrc"
 make -s
 mkdir -p ../../tools/_trace
 OUT=${NBD_TRACE_OUT:-libnbd_hip_trace.so}
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DNBD_CC_TRACE "$@" -c contconv_fused.hip -o /tmp/contconv_fused_trace.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off ${NBD_NO_TRACE:--DNBD_CC_TRACE} "$@" -c contconv_fused.hip -o /tmp/contconv_fused_trace.o
 objs=$(ls *.o | grep -v contconv_fused.o)
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 /tmp/contconv_fused_trace.o $objs -o ../../tools/_trace/$OUT
 echo built tools/_trace/$OUT
