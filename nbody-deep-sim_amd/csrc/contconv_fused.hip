@@ -391,6 +391,13 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
 #ifndef NBD_CC_PRIO_LO
 #define NBD_CC_PRIO_LO 1
 #endif
+// ... and (NBD_CC_TOKEN = 1, off: it bought nothing) they can take turns on the matrix pipe explicitly: turn[simd] counts the bursts started on that SIMD -- wave w's
+// burst of step q is number 2 q, wave w + 4's 2 q + 1 -- and a wave starts its burst when the one before it is three
+// quarters issued (the handover then lands about when that burst ends). Without it both waves' MFMAs interleave, both
+// bursts take twice their length and both waves do their bookkeeping together with the pipe idle.
+#ifndef NBD_CC_TOKEN
+#define NBD_CC_TOKEN 0    // measured (round 3, N = 16 384): consumers alone 0.336 ms with, 0.324 without; whole layer 0.413 / 0.420
+#endif
 #ifndef NBD_CC_NBF
 #define NBD_CC_NBF 4               // batches of PB gathered rows in flight per producer wave
 #endif
@@ -790,6 +797,7 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
       asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dstv[KG - 1]) : "v"(off1), "s"(fbase) : "memory");
     }
   };
+  int* turn = L.done + NBUF * CC_CONSUMERS + (cw & 3);               // this SIMD's burst counter (waves w and w + 4)
   const int a_lane = (lane & 15) * LDA + (lane >> 4) * 4;            // this lane's corner of a step's A tile
   const int o_lane = cw * 16 + 4 * (lane >> 4);
   int qbase = 0;
@@ -799,7 +807,7 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
     cc_load_table(A, L, p0, p1, tid);
     DBG_ACC(true, dbg[2], t0_)
     // pipeline registers: the first reads of the step about to run (when `have`), that step's tile
-    f4 a0n = {0.f, 0.f, 0.f, 0.f}, a1n = {0.f, 0.f, 0.f, 0.f};
+    f4 a0n = {0.f, 0.f, 0.f, 0.f};
     int node_n = -1;
     bool have = false;
     int tile_n = UNI(L.st4[0].y);
@@ -815,7 +823,6 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
     {                                                                                                        \
       node_n = L.rowmap[(B) * SUBR + (lane & 15)];                                                           \
       a0n = *reinterpret_cast<const f4*>(L.a_buf + (B) * SUBR * LDA + a_lane);                               \
-      if (KG > 1) a1n = *reinterpret_cast<const f4*>(L.a_buf + (B) * SUBR * LDA + a_lane + 16);              \
     }
 #define CC_STEP(BC, IDX)                                                                                     \
     {                                                                                                        \
@@ -840,19 +847,30 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
         const int node = node_n;                                                                             \
         f4 av[KG];                                                                                           \
         av[0] = a0n;                                                                                         \
-        if (KG > 1) av[1] = a1n;                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        /* ALL the remaining fragment reads at once, then the first half of the burst: an LDS read takes 300-400 \
-           cycles with 16 waves on the array -- issued one MFMA group (128 cycles) ahead, as hipcc and the first \
-           persistent version did, every group waited out the difference */                                   \
-        _Pragma("unroll") for (int g = 2; g < KG; ++g) av[g] = *reinterpret_cast<const f4*>(a_base + g * 16); \
+        /* Four fragment quads at once, the last three one behind each of the first groups of MFMAs -- every   \
+           read four groups (512 cycles) ahead of its use: an LDS read takes 300-400 cycles with 16 waves on the \
+           array, and issued one group (128 cycles) ahead, as hipcc and the first persistent version did, every  \
+           group waited out the difference. (All seven at once cost 12 more VGPRs: spills.) */                \
+        _Pragma("unroll") for (int g = 1; g < KG && g < 5; ++g) av[g] = *reinterpret_cast<const f4*>(a_base + g * 16); \
+        if (NBD_CC_TOKEN) {                          /* my turn on this SIMD's matrix pipe? */               \
+          __builtin_amdgcn_sched_barrier(0);                                                                 \
+          const int my_turn_ = 2 * q_ + (cw >= CC_CONSUMERS / 2 ? 1 : 0);                                    \
+          while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < my_turn_)          \
+            __builtin_amdgcn_s_sleep(1);                                                                     \
+          __builtin_amdgcn_sched_barrier(0);                                                                 \
+        }                                                                                                    \
+        _Pragma("unroll") for (int g = 5; g < KG; ++g) av[g] = *reinterpret_cast<const f4*>(a_base + g * 16); \
         _Pragma("unroll") for (int g = 0; g < KG && g < 4; ++g) {                                            \
           CC_MFMA(acc0, BC[g][0], av[g][0]) CC_MFMA(acc1, BC[g][1], av[g][1])                                \
           CC_MFMA(acc0, BC[g][2], av[g][2]) CC_MFMA(acc1, BC[g][3], av[g][3])                                \
         }                                                                                                    \
         if (KG == 8) {                                                                                       \
-          __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                                 \
-          __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                                \
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                 \
+          _Pragma("unroll") for (int g = 0; g < 3; ++g) {                                                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                               \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
+          }                                                                                                  \
         }                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         /* mid-burst: is step IDX + 1 already full? then its row map and first fragment quads come now */   \
@@ -867,13 +885,21 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
            in program order behind the previous step's write of this wave) */                                \
         f4* o = reinterpret_cast<f4*>(L.out_acc + max(node, 0) * LDO + o_lane);                              \
         const f4 old = *o;                                                                                   \
-        _Pragma("unroll") for (int g = 4; g < KG; ++g) {                                                     \
+        _Pragma("unroll") for (int g = 4; g < KG && g < 6; ++g) {                                            \
           CC_MFMA(acc0, BC[g][0], av[g][0]) CC_MFMA(acc1, BC[g][1], av[g][1])                                \
           CC_MFMA(acc0, BC[g][2], av[g][2]) CC_MFMA(acc1, BC[g][3], av[g][3])                                \
         }                                                                                                    \
         if (KG == 8) {                                                                                       \
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
-          __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                                \
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                 \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (NBD_CC_TOKEN && lane == 0)               /* three quarters issued: the sibling may start */      \
+          __hip_atomic_store(turn, 2 * q_ + (cw >= CC_CONSUMERS / 2 ? 2 : 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        _Pragma("unroll") for (int g = 6; g < KG; ++g) {                                                     \
+          CC_MFMA(acc0, BC[g][0], av[g][0]) CC_MFMA(acc1, BC[g][1], av[g][1])                                \
+          CC_MFMA(acc0, BC[g][2], av[g][2]) CC_MFMA(acc1, BC[g][3], av[g][3])                                \
         }                                                                                                    \
         /* the buffer can go back to its producer: A and the row map are in registers */                    \
         CC_RELEASE_FENCE();                                                                                  \
@@ -882,6 +908,12 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
           *o = f4{old[0] + (acc0[0] + acc1[0]), old[1] + (acc0[1] + acc1[1]), old[2] + (acc0[2] + acc1[2]),  \
                   old[3] + (acc0[3] + acc1[3])};                                                             \
       } else {                                                                                               \
+        if (NBD_CC_TOKEN) {                                                                                  \
+          const int my_turn_ = 2 * q_ + (cw >= CC_CONSUMERS / 2 ? 1 : 0);                                    \
+          while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < my_turn_)          \
+            __builtin_amdgcn_s_sleep(1);                                                                     \
+          if (lane == 0) __hip_atomic_store(turn, my_turn_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        }                                                                                                    \
         tile_n = UNI(tile_v_);                                                                               \
         have = false;                                                                                        \
         if (lane == 0) __hip_atomic_store(&L.done[b * CC_CONSUMERS + cw], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
@@ -936,7 +968,7 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
   // f4-typed so that the dynamic region starts 16-byte aligned behind the static __shared__ variables (declared as
   // float[] it began at an 8-byte offset and every ds_read_b128 / ds_write_b64 took the unaligned path)
   extern __shared__ f4 lds_aligned[];
-  __shared__ int statics[32 + NBUF * CC_CONSUMERS];                // s_red[16], s_nseg, full[8], done[8][8]
+  __shared__ int statics[32 + NBUF * CC_CONSUMERS + 4];            // s_red[16], s_nseg, full[8], done[8][8], turn[4]
   __shared__ int s_total, s_ctot, s_hit[4], s_red2[16];
   const CCLds L = cc_lds(reinterpret_cast<float*>(lds_aligned), statics);
   const int tid = threadIdx.x, lane = tid & 63, wave = UNI(tid >> 6);
@@ -962,7 +994,7 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
       s_total = T; s_ctot = C;
     }
     if (tid < NBUF) L.full[tid] = 0;
-    if (tid < NBUF * CC_CONSUMERS) L.done[tid] = 0;
+    if (tid < NBUF * CC_CONSUMERS + 4) L.done[tid] = 0;             // and turn[4] behind it
     __syncthreads();
   }
   const int T = UNI(s_total);
