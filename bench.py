@@ -6,7 +6,9 @@
          --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one LeapFrogSimulator.step() (kick-drift, one all-pairs force evaluation, kick) on a
-seeded Plummer sphere already resident in HBM. Workload: 65 536 particles PER GPU, i.e.
+seeded Plummer sphere already resident in HBM. EXACTLY --steps steps are timed per window (barrier +
+synchronize on both sides, MAX over ranks); the window is repeated >= --repeats times (>= 1 s of timed
+steps in all) and `value` / `ms_per_step` are the MEDIAN window's. Workload: 65 536 particles PER GPU, i.e.
 BASELINE.json configs[1] at N=1 (65 536 bodies, one MI355X) and configs[4] at N=8 (524 288 bodies
 range-sharded over 8 GPUs with one RCCL all-gather of positions per step). pairs/step = n_total^2
 (the reference evaluates every (i,j) incl. i=j, simulation.py:80-88), one force evaluation per step.
@@ -127,6 +129,9 @@ def main():
                     help="CPU baseline budget for the N = 65 536 leg (one whole step if it fits 0.75 x this, else a row sample); 0 disables")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5,
                     help="untimed steps run for this long before --warmup (clock ramp); 0 disables")
+    ap.add_argument("--repeats", type=int, default=5, help="minimum number of timed windows of --steps steps each")
+    ap.add_argument("--min-timed-seconds", type=float, default=1.0,
+                    help="keep adding windows until this much time has been spent in timed steps (<= 400 windows)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-surrogates", action="store_true", help="skip the secondary GNN / ContConv rollout timings")
     args = ap.parse_args()
@@ -187,16 +192,29 @@ def main():
     pre_steps, pre_s = prewarm(sim, args.prewarm_seconds) if args.prewarm_seconds > 0 else (0, 0.0)
     for _ in range(args.warmup):
         sim.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sim.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if group is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+
+    def timed_windows(s_, min_repeats, min_total_s):
+        """EXACTLY --steps steps per window, each window bracketed by barrier + synchronize on both sides and the MAX
+        over ranks taken per window; repeated (median of >= 5 repeats) until >= min_total_s of timed
+        steps have run -- one 20 ms window is inside the 4 % box-to-box / clock noise it cannot report."""
+        def one():
+            barrier()
+            t_ = time.perf_counter()
+            for _ in range(args.steps):
+                s_.step()
+            barrier()
+            return time.perf_counter() - t_
+        first = one()
+        rep = torch.tensor([max(min_repeats, min(int(min_total_s / max(first, 1e-6)) + 1, 400))], dtype=torch.int64, device="cuda")
+        if group is not None:                      # every rank must run the same number of windows
+            dist.all_reduce(rep, op=dist.ReduceOp.MAX)
+        ts = [first] + [one() for _ in range(int(rep.item()) - 1)]
+        t = torch.tensor(ts, dtype=torch.float64, device="cuda")
+        if group is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return sorted(t.tolist())
+    windows = timed_windows(sim, args.repeats, args.min_timed_seconds)
+    elapsed = windows[len(windows) // 2] if len(windows) % 2 else 0.5 * (windows[len(windows) // 2 - 1] + windows[len(windows) // 2])
 
     # roofline leg (every rank runs it to stay in lock-step; rank 0 reports): HIP events on the
     # launch stream around the force kernel of K further steps
@@ -241,17 +259,10 @@ def main():
         prewarm(sim2, min(args.prewarm_seconds, 0.2))
         for _ in range(args.warmup):
             sim2.step()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            sim2.step()
-        barrier()
-        el2 = time.perf_counter() - t1
-        t = torch.tensor([el2], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el2 = t.item()
+        w2 = timed_windows(sim2, args.repeats, min(args.min_timed_seconds, 0.5))
+        el2 = w2[len(w2) // 2]
         strong_leg = {"n_particles": n_s, "value": float(n_s) * float(n_s) * args.steps / el2,
-                      "unit": "pair-interactions/s", "ms_per_step": el2 / args.steps * 1e3, "scaling": "strong",
+                      "unit": "pair-interactions/s", "ms_per_step": el2 / args.steps * 1e3, "scaling": "strong", "repeats": len(w2),
                       "launch_plan": direct.shard_plan(n_s, sim2.part.lo, sim2.part.n_local),
                       "note": "same run, the single-GPU problem size split over all ranks (one all-gather per step, "
                               "overlapped with the own-bodies force block)"}
@@ -275,7 +286,10 @@ def main():
         "value": value, "unit": "pair-interactions/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "prewarm": {"seconds": pre_s, "steps": pre_steps,
                                            "why": "clock ramp: untimed steps run by time before --warmup"},
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "ms_per_step": elapsed / args.steps * 1e3, "repeats": len(windows),
+        "ms_per_step_min_median_max": [windows[0] / args.steps * 1e3, elapsed / args.steps * 1e3, windows[-1] / args.steps * 1e3],
+        "timed_seconds_total": sum(windows), "ranks_seen": (dist.get_world_size() if group is not None else 1),
+        "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"Plummer sphere, {n_total} particles, direct all-pairs leapfrog step "

@@ -1151,6 +1151,14 @@ size_t nbd_contconv_pairs_bytes(int n, int64_t edge_capacity, int n_cells) {
   return pairs_layout(n, edge_capacity, n_cells).total;
 }
 
+int nbd_contconv_pairs_layout(int n, int64_t edge_capacity, int n_cells, size_t* offsets) {
+  if (n <= 0 || edge_capacity < 0 || n_cells <= 0 || !offsets) return NBD_E_BADARG;
+  const PairsLayout L = pairs_layout(n, edge_capacity, n_cells);
+  offsets[0] = L.desc; offsets[1] = L.rows; offsets[2] = L.src; offsets[3] = L.w; offsets[4] = L.steps;
+  offsets[5] = L.nsteps; offsets[6] = L.cost; offsets[7] = L.total;
+  return 0;
+}
+
 int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int* centres, int n, int64_t edge_capacity,
                                  float radius_sq, int n_res, const int* filter_resolutions, const int* const* cell_maps,
                                  const int* n_cells, void* const* pair_lists, const size_t* pair_lists_bytes,

@@ -135,6 +135,7 @@ SIGNATURES = {
     "nbd_contconv_bin_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "nbd_contconv_fused_supported": (c_int, [c_int, c_int, c_int]),
+    "nbd_contconv_pairs_layout": (c_int, [c_int, c_int64, c_int, POINTER(c_size_t)]),
     "nbd_contconv_pairs_bytes": (c_size_t, [c_int, c_int64, c_int]),
     "nbd_contconv_pairs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_int,
                                        c_void_p, c_size_t, c_void_p]),

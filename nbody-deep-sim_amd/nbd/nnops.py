@@ -232,6 +232,19 @@ def contconv_pairs_batch(pos, rowptr, centres, edge_capacity: int, radius_sq: fl
     return [(b, edge_capacity) for b in bufs]
 
 
+def contconv_pairs_stats(pair_buf, n: int, edge_capacity: int, n_cells: int) -> dict:
+    """{"steps": 16-row MFMA steps the fused kernel will run over this graph, "cost": the weight its workgroup split
+    balances (sum over steps of max(96, pairs))} -- one host read-back: for reports (bench.py's executed-flop figure),
+    not for the rollout loop."""
+    L = _lib.lib()
+    off = (ctypes.c_size_t * 8)()
+    _lib.check(L.nbd_contconv_pairs_layout(int(n), int(edge_capacity), int(n_cells), off), "nbd_contconv_pairs_layout")
+    tiles = (n + 127) // 128
+    steps = pair_buf[off[5]:off[5] + 4 * tiles].view(torch.int32).sum()
+    cost = pair_buf[off[6]:off[6] + 4 * tiles].view(torch.int32).to(torch.int64).sum()
+    return {"steps": int(steps.item()), "cost": int(cost.item())}
+
+
 def contconv_fused(feat, rowptr, pair_buf, edge_capacity: int, filt_shuffled, n_cells: int, o_ch: int, rowscale=None,
                    act=None, out=None):
     """out (n, o_ch) = act(rowscale * sum_cells A[n][cell] . F[cell]): the block-sparse fused ContinuousConv."""

@@ -111,12 +111,43 @@ def rollout_with_trained_gnn(n=500, steps=200, seed=777):
             "reference_published_at_step_999": {"pos": 1.24e-12, "vel": 5.37e-10, "acc": 1.63e-8}}
 
 
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak (= fp32 vector peak)
+
+
+def time_rollout(step_fn, steps, warm=3):
+    """ms of GPU time per step of a rollout that ADVANCES: step_fn() moves the state on by one step per call."""
+    for _ in range(warm):
+        step_fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        step_fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps, (time.perf_counter() - t0) / steps * 1e3
+
+
+def roofline_block(kernel, kernel_ms, alg_flop, exec_flop, alg_bytes, note):
+    ach = alg_flop / (kernel_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_flop": alg_flop,
+            "executed_flop": exec_flop, "achieved": ach, "achieved_executed": exec_flop / (kernel_ms * 1e-3) / 1e12,
+            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+            "frac_executed": exec_flop / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "algorithmic_bytes": alg_bytes, "note": note}
+
+
 def run(iters=20):
+    from nbd import nnops
+    from nbd.data import Data
     out = {}
+    rollout_steps = max(2 * iters, 40)
     torch.manual_seed(0)
     model = gnn.GraphModel(input_dim=4, node_encoder_dims=None, gnn_dim=64, message_passing_steps=2, aggr="mean",
                            output_hiddens=None, device="cuda", neighbors=10, scale_factor=1e6)
-    tr = trainer.Trainer(model, None, device="cuda", dt=1e-4)
+    DT = 0.01                                    # the class default (simulation.py:30): the state really moves
+    tr = trainer.Trainer(model, None, device="cuda", dt=DT)
     pos, vel, m1 = state(4096, 1234)
     _trace("gnn model built")
     for k in (32, 50):
@@ -125,23 +156,42 @@ def run(iters=20):
         def step():
             p_, v_ = st[0].clone(), st[1].clone()
             from nbd import direct
-            direct.kick_drift(p_, v_, st[2], None, direct.f32(0.5e-4), direct.f32(1e-4))
+            direct.kick_drift(p_, v_, st[2], None, direct.f32(0.5 * DT), direct.f32(DT))
             a_ = model.predict(p_, torch.cat([v_, m1], 1), neighbors=k)
-            direct.kick(v_, a_, direct.f32(0.5e-4))
+            direct.kick(v_, a_, direct.f32(0.5 * DT))
             st[:] = [p_, v_, a_]
-        g_ms, w_ms = timeit(step, iters)
+        g_ms, w_ms = time_rollout(step, rollout_steps)
         kn_ms, _ = timeit(lambda: graphops.knn_graph(pos, k), iters)
         out[f"gnn_n4096_k{k}"] = {"rollout_step_ms_gpu": g_ms, "rollout_step_ms_wall": w_ms, "knn_graph_ms": kn_ms,
-                                 "edges": 4096 * k}
+                                 "edges": 4096 * k, "dt": DT, "advancing_steps_timed": rollout_steps}
     _trace("gnn k loops done")
     acc = model.predict(pos, torch.cat([vel, m1], 1))
-    g_ms, w_ms = timeit(lambda: tr.step(pos, vel, m1, acc, 1e-4), iters)
+    st = [pos, vel, acc]
+    def tstep():
+        st[:] = list(tr.step(st[0], st[1], m1, st[2], DT))
+    g_ms, w_ms = time_rollout(tstep, rollout_steps)
     _trace("gnn trainer step timed")
-    out["gnn_n4096_trainer_step_k50"] = {"ms_gpu": g_ms, "ms_wall": w_ms}
-    adv = tr._capture_step(pos, vel, m1, acc, 1e-4)
+    out["gnn_n4096_trainer_step_k50"] = {"ms_gpu": g_ms, "ms_wall": w_ms, "dt": DT, "advancing_steps_timed": rollout_steps}
+    adv = tr._capture_step(pos, vel, m1, acc, DT)
     if adv is not None:
-        g_ms, w_ms = timeit(lambda: adv(clone=False), iters)
-        out["gnn_n4096_trainer_step_k50_hipgraph"] = {"ms_gpu": g_ms, "ms_wall": w_ms}
+        g_ms, w_ms = time_rollout(lambda: adv(clone=False), rollout_steps)
+        out["gnn_n4096_trainer_step_k50_hipgraph"] = {"ms_gpu": g_ms, "ms_wall": w_ms, "dt": DT,
+                                                      "advancing_steps_timed": rollout_steps}
+    # roofline of configs[2]: the two fused EdgeConv layers on a given k = 50 graph (one launch each)
+    with torch.no_grad():
+        ei = graphops.knn_graph(pos, 50)
+        data = Data(x=torch.cat([pos, vel, m1], 1), edge_index=ei)
+        model.eval()
+        f_ms, _ = timeit(lambda: model(data), max(iters, 20))
+    n_, e_, h_ = 4096, 4096 * 50, 64
+    alg = sum(2.0 * e_ * (2 * f * h_ + h_ * h_) for f in (4, 64))            # 2 E (2 F H + H H) per layer
+    exe = sum(2.0 * n_ * (2 * f * h_ + h_ * h_) for f in (4, 64)) + 2 * 5.0 * e_ * h_   # per-node Linears + ~5 flop per edge-channel tanh
+    out["gnn_n4096_k50"]["roofline"] = roofline_block(
+        "gnn_layer_kernel x2 (one fused launch per EdgeConv layer, graph given)", f_ms, alg, exe,
+        4.0 * (n_ * 7 + n_ * 3) + 8.0 * e_,
+        "algorithmic = the reference's per-edge formulation 2 E (2 F H + H H) (gnn.py:75-93); executed = first Linear "
+        "factored per node (P_i + Q_j), second Linear once per node after the aggregation, E H tanh evaluations "
+        "(fp32 VALU, no MFMA in this kernel): latency-bound at 4096 waves of work, far below any throughput roofline")
 
     _trace("gnn graph timed")
     torch.manual_seed(0)
@@ -155,18 +205,57 @@ def run(iters=20):
     _trace("degree scale found")
     pos, vel, m1 = state(n, 1234, scale)
     lists = graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32)
-    tr2 = trainer.Trainer(cc, None, device="cuda", dt=1e-4)
+    tr2 = trainer.Trainer(cc, None, device="cuda", dt=DT)
     acc = cc.predict(pos, torch.cat([vel, m1], 1))
     _trace("contconv first predict")
-    g_ms, w_ms = timeit(lambda: tr2.step(pos, vel, m1, acc, 1e-4), max(iters // 2, 3))
+    cc_steps = max(iters, 40)
+    st2 = [pos, vel, acc]
+    def cstep():
+        st2[:] = list(tr2.step(st2[0], st2[1], m1, st2[2], DT))
+    rb0 = cc._radius_cache.rebuilds()
+    g_ms, w_ms = time_rollout(cstep, cc_steps)
+    rb_eager = cc._radius_cache.rebuilds() - rb0
     _trace("contconv step timed")
-    adv = tr2._capture_step(pos, vel, m1, acc, 1e-4)
-    cc_graph = timeit(lambda: adv(clone=False), max(iters // 2, 3)) if adv is not None else (None, None)
+    adv = tr2._capture_step(pos, vel, m1, acc, DT)
+    cc_graph, rb_graph = (None, None), None
+    if adv is not None:
+        rb0 = cc._radius_cache.rebuilds()
+        cc_graph = time_rollout(lambda: adv(clone=False), cc_steps)
+        rb_graph = cc._radius_cache.rebuilds() - rb0
     _trace("contconv graph timed")
     r_ms, _ = timeit(lambda: graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32), max(iters // 2, 3))
-    out["contconv_n16384"] = {"rollout_step_ms_gpu": g_ms, "rollout_step_ms_wall": w_ms, "rollout_step_ms_gpu_hipgraph": cc_graph[0], "radius_lists_ms": r_ms,
-                              "position_scale": scale, "mean_uncapped_degree": deg,
-                              "edges_capped": int(lists.rowptr[-1]), "max_in_degree": int((lists.rowptr[1:] - lists.rowptr[:-1]).max())}
+    edges = int(lists.rowptr[-1])
+    out["contconv_n16384"] = {"rollout_step_ms_gpu": g_ms, "rollout_step_ms_wall": w_ms,
+                              "rollout_step_ms_gpu_hipgraph": cc_graph[0], "dt": DT, "advancing_steps_timed": cc_steps,
+                              "radius_cache_rebuilds_per_step": {"eager": rb_eager / (cc_steps + 3),
+                                                                 "hipgraph": None if rb_graph is None else rb_graph / (cc_steps + 3),
+                                                                 "skin": graphops.RadiusCache.SKIN, "rebuild_at": graphops.RadiusCache.MARGIN},
+                              "radius_lists_ms": r_ms, "position_scale": scale, "mean_uncapped_degree": deg,
+                              "edges_capped": edges, "max_in_degree": int((lists.rowptr[1:] - lists.rowptr[:-1]).max())}
+    # roofline of configs[3]: the two fused ContinuousConv layers (D = 6, D = 4; 128 -> 128) on the initial graph
+    with torch.no_grad():
+        feat = torch.randn(n, 128, device="cuda")
+        inv_deg = nnops.degree_scale(lists.rowptr, n, 0, pos.device)
+        layers_ms, steps_total, cells = [], 0, []
+        for layer in cc.contconv:
+            _, cmap, n_cells = layer.cells()
+            pairs = nnops.contconv_pairs(pos, lists.rowptr, lists.centres, lists.centres.numel(), layer.filter_resolution,
+                                         1.0, cmap, n_cells)
+            wf = layer.weight_fused()
+            ms, _ = timeit(lambda: layer(pos, feat, lists=lists, act="tanh", wt=wf, pairs=pairs, scale=inv_deg), max(iters, 20))
+            layers_ms.append(ms)
+            steps_total += nnops.contconv_pairs_stats(pairs[0], n, pairs[1], n_cells)["steps"]
+            cells.append(n_cells)
+    alg = 2 * 2.0 * edges * 128 * 128                                        # 2 E I O per layer
+    exe = 2.0 * 16 * 128 * 128 * steps_total
+    out["contconv_n16384"]["roofline"] = roofline_block(
+        "contconv_stream_kernel<8> x2 (+ finishing kernel), D = 6 and D = 4", sum(layers_ms), alg, exe,
+        2 * (4.0 * n * 128 * 2) + 4.0 * 128 * 128 * sum(cells),
+        "algorithmic = the einsum's 2 E I O per layer (contconv.py:92); executed = 16-row fp32 MFMA steps x 2 x 16 x I x O "
+        "over the touched (node, cell) blocks (the per-(node, cell) binning floor is 2 I O x blocks = 38.1 GFLOP per step "
+        "at this graph); layer times " + ", ".join(f"{x:.3f} ms" for x in layers_ms))
+    out["contconv_n16384"]["roofline"]["layers_ms"] = layers_ms
+    out["contconv_n16384"]["roofline"]["mfma_steps"] = steps_total
     _trace("radius lists timed")
     out["gnn_n4096_rollout_mse_vs_direct"] = rollout_mse_vs_direct(model, 4096, None, 10)
     _trace("random-weight rollout done")
