@@ -116,7 +116,7 @@ class RadiusCache:
     """State of nbd_radius_cached_search_f32 for ONE sequence of similar configurations (a rollout): candidate lists
     of the first `wide_cap` indices within r + skin of every centre and the positions they were built at. The search
     result does not depend on it (it is exact either way); it only decides how often the O(n^2) scan runs."""
-    SKIN = 0.05          # in units of r
+    SKIN = float(__import__("os").environ.get("NBD_RADIUS_SKIN", "0.15"))          # in units of r
     MARGIN = 0.45        # rebuild when a body has moved MARGIN * skin (0.5 would be the exact bound)
 
     def __init__(self, wide_cap: int = 192):      # measured on the ContinuousConv rollout step (N = 16 384): 128 / 192 / 256 -> 1.021 / 1.006 / 1.096 ms
