@@ -208,6 +208,13 @@ int nbd_radius_search_f32(const float* pos, int n, float radius_sq, int loop, in
                           const int* seg_lo, const int* seg_hi, int* nbr, int* deg, int* last, int* indeg,
                           nbd_stream_t stream);
 
+/* radius_graph(loop = False) as torch_cluster 1.6.3 computes it (contconv.py:225 with self_loops = False): search with
+ * self as a candidate and max_num_neighbors + 1 slots (the calls here with loop = 1), THEN drop row == col -- a centre
+ * with >= max_num_neighbors + 1 lower-indexed hits keeps all max_num_neighbors + 1. This entry point does the drop on
+ * lists of `cap` slots per centre: the self entry is removed, deg / last / indeg (optional) follow. (The `loop = 0`
+ * mode of the search entry points -- self excluded BEFORE the cap -- is kept for callers that want that rule.) */
+int nbd_radius_drop_self_i32(int* nbr, int* deg, int* last, int* indeg, int n, int cap, nbd_stream_t stream);
+
 /* The same search in streaming form (lane = centre, sources broadcast through LDS, the source range cut
  * into slices whose per-centre hit lists are concatenated in index order by a second kernel): identical
  * outputs, ~10x faster at N = 16 384. Needs nbd_radius_search_workspace_bytes(n, max_num_neighbors). */

@@ -884,6 +884,38 @@ int nbd_radius_cached_transpose_f32(const float* pos, int n, float radius_sq, in
   return status();
 }
 
+}  // extern "C"
+namespace {
+// radius_graph(loop = False) as torch_cluster 1.6.3 computes it: the search ran WITH self as a candidate and a cap of
+// max_num_neighbors + 1 ("first cap hits in index order, self included"); now row == col is dropped. One thread per
+// centre (lists hold <= 33 entries here); the in-degree the search counted for the self entry is taken back.
+__global__ __launch_bounds__(256) void radius_drop_self_kernel(int* __restrict__ nbr, int* __restrict__ deg,
+                                                               int* __restrict__ last, int* __restrict__ indeg, int n,
+                                                               int cap) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int* row = nbr + (size_t)i * cap;
+  const int d = deg[i];
+  int at = -1;
+  for (int t = 0; t < d; ++t)
+    if (row[t] == i) { at = t; break; }
+  if (at < 0) return;                       // >= cap lower-indexed hits: self never made the list, all cap entries stay
+  for (int t = at; t + 1 < d; ++t) row[t] = row[t + 1];
+  deg[i] = d - 1;
+  last[i] = d > 1 ? row[d - 2] : -1;
+  if (indeg) indeg[i] -= 1;                 // only this thread touches indeg[i] here (the search's atomics are done)
+}
+}  // namespace
+extern "C" {
+
+int nbd_radius_drop_self_i32(int* nbr, int* deg, int* last, int* indeg, int n, int cap, nbd_stream_t stream) {
+  if (n < 0 || cap <= 0) return NBD_E_BADARG;
+  if (n == 0) return 0;
+  if (!nbr || !deg || !last) return NBD_E_BADARG;
+  radius_drop_self_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(nbr, deg, last, indeg, n, cap);
+  return status();
+}
+
 int nbd_radius_transpose_lists(const int* nbr, const int* deg, int n, int cap, const int* rowptr, int* cursor,
                                int* scratch, int* centres, nbd_stream_t stream) {
   if (n < 0 || cap < 0) return NBD_E_BADARG;

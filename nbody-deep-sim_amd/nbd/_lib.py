@@ -114,6 +114,7 @@ SIGNATURES = {
     "nbd_radius_search_workspace_bytes": (c_size_t, [c_int, c_int]),
     "nbd_radius_search_ws_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nbd_radius_drop_self_i32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "nbd_radius_transpose_lists": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p]),
     "nbd_radius_transpose_count_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,

@@ -61,6 +61,15 @@ def knn_graph(x: torch.Tensor, k: int, batch: torch.Tensor | None = None, loop: 
     if x.dim() != 2 or x.shape[1] != 3:
         raise _lib.NbdError(f"knn_graph: this build searches 3-D positions (n,3) as the reference does "
                             f"(gnn.py:13), got {tuple(x.shape)}")
+    if not loop and hint is None and out is None and not torch.cuda.is_current_stream_capturing():
+        # torch_cluster 1.6.3: knn(x, x, k + 1) with self as a candidate, then row == col dropped. One boolean
+        # compaction (a host sync), so only outside the rollout's fast path (hint / out given, or inside a graph
+        # capture), which masks the diagonal in the kernel instead: the two rules differ only for a centre with
+        # >= k + 1 LOWER-indexed bodies at distance exactly 0, which then keeps k + 1 neighbours here.
+        ei1 = knn_graph(x, k + 1, batch, loop=True)
+        ei = ei1[:, ei1[0] != ei1[1]].contiguous()
+        mark(ei, "_nbd_grouped")
+        return ei
     pos = x.contiguous()
     _chk(pos, (n, 3), "x")
     dev = pos.device
@@ -107,9 +116,9 @@ class RadiusLists:
 
 
 def radius_r2(r: float) -> float:
-    """torch_cluster compares against r*r in fp32."""
-    r32 = np.float32(r)
-    return float(np.float32(r32 * r32))
+    """torch_cluster 1.6.3 hands its kernel r * r computed in double and cast to fp32 (0.7 -> 0.49000001; the fp32
+    product of the fp32 radius would be 0.48999998)."""
+    return float(np.float32(float(r) * float(r)))
 
 
 class RadiusCache:
@@ -145,7 +154,11 @@ def radius_lists(pos: torch.Tensor, r: float, batch=None, loop: bool = False, ma
     n = pos.shape[0]
     _chk(pos, (n, 3), "pos")
     dev = pos.device
-    cap = int(max_num_neighbors) if loop else int(max_num_neighbors)
+    # torch_cluster 1.6.3: radius(x, x, r, ..., max_num_neighbors if loop else max_num_neighbors + 1) with self as a
+    # candidate, THEN row == col is dropped -- so without self loops a centre with >= 33 lower-indexed hits keeps 33
+    drop_self = not loop
+    cap = int(max_num_neighbors) + (1 if drop_self else 0)
+    search_loop = 1
     lo, hi = _segments(batch, n, dev)
     nbr = torch.empty((n, max(cap, 1)), dtype=torch.int32, device=dev)
     deg = torch.empty(n, dtype=torch.int32, device=dev)
@@ -157,7 +170,6 @@ def radius_lists(pos: torch.Tensor, r: float, batch=None, loop: bool = False, ma
     # very large caps (its early exit at `cap` hits does not need them)
     need = L.nbd_radius_search_workspace_bytes(n, cap)
     stream_ok = 0 < need <= (1 << 29)
-    ws = torch.empty(need if stream_ok else 1, dtype=torch.uint8, device=dev)
 
     use_cache = cache is not None and batch is None and cap > 0 and n > 0 and stream_ok
     if use_cache:       # the rebuild's slice lists grow with the wide cap: keep them under 1 GiB or search plainly
@@ -170,18 +182,22 @@ def radius_lists(pos: torch.Tensor, r: float, batch=None, loop: bool = False, ma
             rw = np.float32(r) + skin
             moved = np.float32(RadiusCache.MARGIN) * skin
             _lib.check(L.nbd_radius_cached_search_f32(pos.data_ptr(), n, r2, float(np.float32(rw * rw)),
-                                                      float(np.float32(moved * moved)), int(loop), cap, wide,
+                                                      float(np.float32(moved * moved)), search_loop, cap, wide,
                                                       state.data_ptr(), state.numel(), nbr.data_ptr(), deg.data_ptr(),
                                                       last.data_ptr(), indeg_ptr, cws.data_ptr(), cws.numel(), st),
                        "nbd_radius_cached_search_f32")
         elif stream_ok:
-            _lib.check(L.nbd_radius_search_ws_f32(pos.data_ptr(), n, r2, int(loop), cap, _lib.ptr(lo), _lib.ptr(hi),
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)      # only this branch needs it (up to 512 MiB)
+            _lib.check(L.nbd_radius_search_ws_f32(pos.data_ptr(), n, r2, search_loop, cap, _lib.ptr(lo), _lib.ptr(hi),
                                                   nbr.data_ptr(), deg.data_ptr(), last.data_ptr(), indeg_ptr,
                                                   ws.data_ptr(), need, st), "nbd_radius_search_ws_f32")
         else:
-            _lib.check(L.nbd_radius_search_f32(pos.data_ptr(), n, r2, int(loop), cap, _lib.ptr(lo), _lib.ptr(hi),
+            _lib.check(L.nbd_radius_search_f32(pos.data_ptr(), n, r2, search_loop, cap, _lib.ptr(lo), _lib.ptr(hi),
                                                nbr.data_ptr(), deg.data_ptr(), last.data_ptr(), indeg_ptr, st),
                        "nbd_radius_search_f32")
+        if drop_self and n > 0 and cap > 0:
+            _lib.check(L.nbd_radius_drop_self_i32(nbr.data_ptr(), deg.data_ptr(), last.data_ptr(), indeg_ptr, n, cap, st),
+                       "nbd_radius_drop_self_i32")
     with _lib.on_device(dev):
         if not transpose:
             search(None)

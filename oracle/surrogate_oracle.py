@@ -18,15 +18,24 @@ published semantics of the third-party calls it makes, written down here as the 
 the HIP path is tested against:
 
   knn_graph(x, k, batch, loop=False)   [gnn.py:13, datautils.py:36]
-      for every centre i the k nearest other nodes j of the same batch segment; squared distance
-      d2 = (dx*dx + dy*dy) + dz*dz in fp32; ties -> lower index; edges grouped by centre in
-      ascending centre index and, inside a group, ascending (d2, j).
-      edge_index[0] = j (neighbour/source), edge_index[1] = i (centre/target)  ("source_to_target")
+      torch_cluster 1.6.3 `knn_graph`: `knn(x, x, k if loop else k + 1, batch, batch)` -- for every centre i the
+      k (+1) nearest nodes j of the same batch segment, ITSELF INCLUDED as a candidate at distance 0 -- and then,
+      if not loop, the entries with row == col are dropped. Squared distance d2 = (dx*dx + dy*dy) + dz*dz in fp32;
+      ties -> lower index (the CUDA kernel scans candidates in index order and replaces its current worst only on
+      a strictly smaller distance); edges grouped by centre in ascending centre index and, inside a group,
+      ascending (d2, j). edge_index[0] = j (neighbour/source), edge_index[1] = i (centre/target)
+      ("source_to_target"). Consequence of "search k + 1, then drop self" (as opposed to masking the diagonal,
+      which this oracle did until round 3): a centre with at least k + 1 lower-indexed bodies at distance exactly
+      0 never sees itself among its k + 1 nearest and KEEPS ALL k + 1. Everywhere else the two rules agree and
       E = sum_i min(k, segment_size_i - 1).
   radius_graph(x, r, batch, loop, max_num_neighbors=32)   [contconv.py:225]
-      for every centre i the first max_num_neighbors nodes j (ascending index, same segment) with
-      d2 < r*r strictly (fp32; r*r = the fp32 product of the fp32 radius), j == i included iff
-      loop; same edge_index orientation and grouping.
+      torch_cluster 1.6.3 `radius_graph`: `radius(x, x, r, batch, batch, max_num_neighbors if loop else
+      max_num_neighbors + 1)` -- for every centre i the first max_num_neighbors (+1) nodes j (ascending index,
+      same segment, ITSELF INCLUDED) with d2 < r2 strictly -- and then, if not loop, row == col is dropped. So
+      without self loops a centre with >= max_num_neighbors + 1 lower-indexed hits returns max_num_neighbors + 1
+      neighbours (33), any other centre at most max_num_neighbors. r2 = float(double(r) * double(r)): the kernel
+      receives r * r computed in double and cast to fp32 (0.7 -> 0.49000001; the fp32 product of the fp32 radius,
+      this oracle's rule until round 3, is 0.48999998). Same edge_index orientation and grouping.
       (torch_cluster's CUDA kernel scans in index order and keeps the first hits; its CPU path
       returns a kd-tree-ordered arbitrary subset when the cap binds -- only the former is
       reproducible)
@@ -80,37 +89,44 @@ def knn_graph(pos: torch.Tensor, k: int, batch=None, loop: bool = False) -> torc
     for lo, hi in _segments(n, batch):
         m = hi - lo
         d2 = _d2(pos, lo, hi)
-        if not loop:
-            d2 = d2.clone()
-            d2.fill_diagonal_(float("inf"))
-        kk = min(k, m if loop else m - 1)
+        kk = min(k if loop else k + 1, m)             # self is a candidate (distance 0) either way
         if kk <= 0:
             continue
         # stable sort on d2 keeps lower indices first among ties
         order = torch.sort(d2, dim=1, stable=True).indices[:, :kk]
-        src.append((order + lo).reshape(-1))
-        dst.append((torch.arange(lo, hi).unsqueeze(1).expand(m, kk)).reshape(-1))
+        j = (order + lo).reshape(-1)
+        i = (torch.arange(lo, hi).unsqueeze(1).expand(m, kk)).reshape(-1)
+        if not loop:                                  # torch_cluster: mask = row != col
+            keep = j != i
+            j, i = j[keep], i[keep]
+        src.append(j)
+        dst.append(i)
     if not src:
         return torch.zeros((2, 0), dtype=torch.int64)
     return torch.stack([torch.cat(src), torch.cat(dst)]).to(torch.int64)
 
 
+def radius_r2(r: float) -> float:
+    """r * r in double, then cast to fp32 (what torch_cluster's kernel is handed)."""
+    return torch.tensor(float(r) * float(r), dtype=torch.float64).to(torch.float32).item()
+
+
 def radius_graph(pos: torch.Tensor, r: float, batch=None, loop: bool = False,
                  max_num_neighbors: int = 32) -> torch.Tensor:
     n = pos.shape[0]
-    r32 = torch.tensor(r, dtype=torch.float32)
-    r2 = (r32 * r32).item()
+    r2 = radius_r2(r)
+    cap = max_num_neighbors if loop else max_num_neighbors + 1      # self counts towards the cap either way
     src, dst = [], []
     for lo, hi in _segments(n, batch):
         m = hi - lo
         for b0 in range(lo, hi, _ROW_BLOCK):
             b1 = min(b0 + _ROW_BLOCK, hi)
             ok = _d2(pos, lo, hi, b0, b1) < r2
-            if not loop:
+            rank = torch.cumsum(ok.to(torch.int32), dim=1)          # 1-based rank in index order
+            ok = ok & (rank <= cap)
+            if not loop:                                            # ... and only then is row == col dropped
                 rows = torch.arange(b1 - b0)
                 ok[rows, rows + (b0 - lo)] = False
-            rank = torch.cumsum(ok.to(torch.int32), dim=1)          # 1-based rank in index order
-            ok = ok & (rank <= max_num_neighbors)
             i_idx, j_idx = torch.nonzero(ok, as_tuple=True)         # row-major: grouped by centre, j ascending
             src.append(j_idx + lo)
             dst.append(i_idx + b0)

@@ -93,6 +93,71 @@ def test_radius_graph_batched(gpu_device):
         assert torch.equal(graphops.radius_graph(pos.cuda(), 0.9, batch=b.cuda(), loop=loop, max_num_neighbors=cap).cpu(), ref)
 
 
+def test_radius_graph_without_self_loops_searches_cap_plus_one_then_drops_self(gpu_device):
+    """torch_cluster 1.6.3 (contconv.py:225 with self_loops=False): radius(x, x, r, max_num_neighbors + 1) with self as
+    a candidate, then row == col dropped. A centre with >= 33 lower-indexed hits never meets itself and returns 33."""
+    from nbd import graphops
+    from oracle import surrogate_oracle as so
+    g = torch.Generator().manual_seed(5)
+    pos = torch.rand(80, 3, generator=g) * 0.2                     # everything within r = 1 of everything
+    ref = so.radius_graph(pos, 1.0, loop=False, max_num_neighbors=32)
+    deg = torch.bincount(ref[1], minlength=80)
+    assert deg[:33].eq(32).all() and deg[33:].eq(33).all()          # centres 33.. have >= 33 lower-indexed hits
+    for cache in (None, graphops.RadiusCache()):
+        lists = graphops.radius_lists(pos.cuda(), 1.0, loop=False, max_num_neighbors=32, cache=cache)
+        assert torch.equal(lists.deg.cpu().to(torch.int64), deg)
+        e = ref.shape[1]
+        order = torch.sort(ref[0], stable=True).indices
+        assert int(lists.rowptr[-1]) == e
+        assert torch.equal(lists.centres[:e].cpu().to(torch.int64), ref[1][order])
+    assert torch.equal(graphops.radius_graph(pos.cuda(), 1.0, loop=False, max_num_neighbors=32).cpu(), ref)
+    # a clump inside a larger system, both loop modes, odd caps
+    pos2, _, _ = _plummer_pos(700, 77)
+    pos2[100:180] = pos2[100] + (torch.rand(80, 3, generator=g) - 0.5) * 0.05
+    for loop, cap in ((False, 32), (False, 5), (True, 32)):
+        assert torch.equal(graphops.radius_graph(pos2.cuda(), 0.6, loop=loop, max_num_neighbors=cap).cpu(),
+                           so.radius_graph(pos2, 0.6, loop=loop, max_num_neighbors=cap))
+
+
+def test_radius_squared_is_the_double_product_cast_to_fp32(gpu_device):
+    """r = 0.7: float(0.7 * 0.7) = 0.49000001 is one ulp above fp32(0.7)^2 = 0.48999998. A body at distance exactly
+    fp32(0.7) (d2 = 0.48999998) is a neighbour under torch_cluster's rule and was not under the fp32 product."""
+    from nbd import graphops
+    from oracle import surrogate_oracle as so
+    x = float(np.float32(0.7))
+    assert np.float32(x) * np.float32(x) < np.float32(0.7 * 0.7)
+    pos = torch.tensor([[0., 0, 0], [x, 0, 0], [0, 5, 0], [0, 5 + x, 0], [9, 9, 9]])
+    ref = so.radius_graph(pos, 0.7, loop=False)
+    assert ref.tolist() == [[1, 0, 3, 2], [0, 1, 2, 3]]
+    assert torch.equal(graphops.radius_graph(pos.cuda(), 0.7, loop=False).cpu(), ref)
+    assert graphops.radius_r2(0.7) == float(np.float32(0.7 * 0.7)) == so.radius_r2(0.7)
+    lists = graphops.radius_lists(pos.cuda(), 0.7, loop=True)
+    assert lists.deg.cpu().tolist() == [2, 2, 2, 2, 1]
+
+
+def test_knn_graph_with_coincident_bodies(gpu_device):
+    """torch_cluster 1.6.3: knn(x, x, k + 1) with self as a candidate, then row == col dropped. With coincident bodies
+    the ties go to the lower index; a centre with >= k + 1 lower-indexed bodies at distance 0 keeps k + 1 neighbours."""
+    from nbd import graphops
+    from oracle import surrogate_oracle as so
+    pos, _, _ = _plummer_pos(300, 31)
+    pos[40:46] = pos[40]                     # six coincident bodies
+    pos[200] = pos[7]; pos[250] = pos[7]     # and a triple far apart in index
+    for k in (1, 2, 5, 10, 50):
+        ref = so.knn_graph(pos, k)
+        got = graphops.knn_graph(pos.cuda(), k).cpu()
+        assert torch.equal(got, ref), k
+        if k >= 5:                           # no centre has k + 1 coincident lower-indexed bodies: regular degree
+            assert ref.shape[1] == 300 * k
+            # ... and then the rollout's fast path (diagonal masked in the kernel, hint / out buffers) is the same graph
+            buf = graphops.knn_graph(pos.cuda(), k, loop=False, hint=got.cuda(), out=got.cuda().clone())
+            assert torch.equal(buf.cpu(), ref)
+    assert so.knn_graph(pos, 1).shape[1] > 300          # the corner really occurs at k = 1 (bodies 42-45, 250)
+    b = _batch(300, [60, 140, 100])
+    for k in (2, 7):
+        assert torch.equal(graphops.knn_graph(pos.cuda(), k, batch=b.cuda()).cpu(), so.knn_graph(pos, k, batch=b))
+
+
 # ------------------------------------------------------------------ dense blocks
 @pytest.mark.parametrize("n,k,m", [(1, 4, 3), (100, 4, 128), (4096, 8, 64), (333, 7, 5), (1000, 68, 3), (257, 64, 64),
                                    (700, 128, 128), (129, 1000, 130), (64, 256, 32),

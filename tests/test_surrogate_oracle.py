@@ -38,8 +38,27 @@ def test_radius_graph_known_answer_cap_and_strictness():
     assert e.tolist() == [[0, 1, 0, 1, 2, 1, 2, 3, 2, 3], [0, 0, 1, 1, 1, 2, 2, 2, 3, 3]]
     e = so.radius_graph(x, 10.0, loop=True, max_num_neighbors=2)          # first 2 by index
     assert e.tolist() == [[0, 1, 0, 1, 0, 1, 0, 1], [0, 0, 1, 1, 2, 2, 3, 3]]
+    # torch_cluster 1.6.3: without self loops the search runs with cap + 1 slots and self as a candidate, THEN drops
+    # row == col: centres 0-2 find themselves among their first 3 hits and keep 2 others; centre 3 has three
+    # lower-indexed hits, never sees itself, and keeps all 3
     e = so.radius_graph(x, 10.0, loop=False, max_num_neighbors=2)
-    assert e.tolist() == [[1, 2, 0, 2, 0, 1, 0, 1], [0, 0, 1, 1, 2, 2, 3, 3]]
+    assert e.tolist() == [[1, 2, 0, 2, 0, 1, 0, 1, 2], [0, 0, 1, 1, 2, 2, 3, 3, 3]]
+    # r2 = float(double(r) * double(r)): for r = 0.7 that is 0.49000001, one ulp above fp32(0.7)^2 = 0.48999998 -- a
+    # body at distance exactly fp32(0.7) (d2 = 0.48999998) is inside
+    assert np.float32(0.7) * np.float32(0.7) < np.float32(0.7 * 0.7) == np.float32(so.radius_r2(0.7))
+    y = torch.tensor([[0., 0, 0], [float(np.float32(0.7)), 0, 0]])
+    assert so.radius_graph(y, 0.7, loop=False).tolist() == [[1, 0], [0, 1]]
+
+
+def test_knn_graph_is_search_k_plus_one_then_drop_self():
+    # three coincident bodies then two others; k = 1: bodies 0 and 1 find themselves among their 2 nearest (ties ->
+    # lower index: 0, 1) and keep one neighbour; body 2 has two lower-indexed bodies at distance 0, its 2 nearest
+    # are 0 and 1, row == col drops nothing: TWO neighbours (masking the diagonal would give one)
+    x = torch.tensor([[1., 1, 1], [1, 1, 1], [1, 1, 1], [2, 1, 1], [5, 1, 1]])
+    ei = so.knn_graph(x, 1)
+    assert ei.tolist() == [[1, 0, 0, 1, 0, 3], [0, 1, 2, 2, 3, 4]]
+    # with k = 2 every body sees itself within its 3 nearest: two neighbours each, as with a masked diagonal
+    assert so.knn_graph(x, 2).tolist() == [[1, 2, 0, 2, 0, 1, 0, 1, 3, 0], [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]]
 
 
 def test_edgeconv_matches_loop_restatement():
