@@ -602,13 +602,29 @@ int nbd_accel_tuned_f32(const float* posm_src, int n_src, int exclude_lo, int ex
 //            acc = G * sum, and the second kick fused (finish_kernel), as in nbd_leapfrog_step_f32.
 struct ShardPlan { AccelPlan local, remote; };
 
-ShardPlan plan_shard(int n_total, int lo, int n_local) {
+ShardPlan plan_shard_uncached(int n_total, int lo, int n_local) {
   ShardPlan sp;
   sp.local = plan_chunks(ceil_div(n_local, kChunk), n_local);
   const int rc = excluded_view(n_total, lo, lo + n_local, nullptr);
   sp.remote = plan_chunks(rc > 0 ? rc : 1, n_local);
   if (rc == 0) { sp.remote.slabs = 0; sp.remote.n_chunks = 0; }
   return sp;
+}
+
+// A sharded step asks for its plan four times (two launches, each sizing its workspace first) and every plan is two
+// searches of up to 64 cost evaluations -- host time on the critical path of a ~140 us rank step. The plan is a pure
+// function of (n_total, lo, n_local): memoised per calling thread (a rank steps ONE partition; no locks, no shared state).
+ShardPlan plan_shard(int n_total, int lo, int n_local) {
+  struct Memo { int n_total, lo, n_local; ShardPlan sp; };
+  thread_local Memo memo[4] = {{-1, 0, 0, {}}, {-1, 0, 0, {}}, {-1, 0, 0, {}}, {-1, 0, 0, {}}};
+  thread_local int next = 0;
+  for (const Memo& m : memo)
+    if (m.n_total == n_total && m.lo == lo && m.n_local == n_local) return m.sp;
+  Memo& m = memo[next];
+  next = (next + 1) & 3;
+  m.n_total = n_total; m.lo = lo; m.n_local = n_local;
+  m.sp = plan_shard_uncached(n_total, lo, n_local);
+  return m.sp;
 }
 
 int nbd_shard_plan(int n_total, int lo, int n_local, int* slabs_local, int* cpw_local, int* slabs_remote,

@@ -3,6 +3,8 @@ real reference produced and (ii) the pinned CPU oracle on seeded inputs; plus si
 properties at BASELINE.json's full size. Tolerance (BASELINE.json north_star): positions and
 velocities within 1e-5 relative after one step, measured per particle on vector norms
 (SURVEY 8c); accelerations are held to the same bound and to 1e-6 globally."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -282,6 +284,43 @@ def test_two_rank_range_partition_on_gpu_matches_single_rank(n, tmp_path, gpu_de
         assert row_rel(got[key], _np(ref)) < 2e-6, key
     u, k = sim.compute_energies()
     assert abs(got["u"] - u) < 1e-6 * abs(u) and abs(got["k"] - k) < 1e-6 * abs(k)
+
+
+def test_bench_py_multi_rank_json_end_to_end(gpu_device, tmp_path):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank), on THIS box:
+    the ranks share the one GPU and talk over gloo (NBD_BENCH_SHARE_GPU / NBD_DIST_BACKEND; RCCL needs distinct
+    devices). Four ranks, not eight: the GPU boxes of this pool kill a run with more than six processes on the card
+    (the eight-rank control flow is covered on CPU stand-ins in test_dist_gloo.py). Checks the ONE JSON line: rank
+    count as launched and as seen by the collective, weak-scaling bookkeeping, the strong leg, sane numbers."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world, per = 4, 2048
+    env = dict(os.environ, NBD_BENCH_SHARE_GPU="1", NBD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world),
+           "--steps", "5", "--warmup", "2", "--particles-per-gpu", str(per), "--prewarm-seconds", "0.05",
+           "--min-timed-seconds", "0.05", "--repeats", "3", "--cpu-seconds", "0", "--no-surrogates"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]                     # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["ranks_seen"] == world
+    assert out["scaling"] == "weak" and out["steps"] == 5 and out["warmup"] == 2 and out["repeats"] >= 3
+    assert out["config"]["n_particles"] == world * per and out["config"]["particles_per_gpu"] == per
+    assert out["value"] > 0 and abs(out["value"] - (world * per) ** 2 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    lo, med, hi = out["ms_per_step_min_median_max"]
+    assert lo <= med <= hi and med == out["ms_per_step"]
+    strong = out["strong_scaling_n65536"]                          # the single-GPU problem size split over all ranks
+    assert strong["n_particles"] == per and strong["scaling"] == "strong" and strong["value"] > 0
+    assert out["roofline"]["pairs_per_launch"] == per * world * per and 0 < out["roofline"]["frac"] < 1
+    assert out["cpu_baseline"] is None
 
 
 def test_full_size_all_rows_against_c_oracle_f64(gpu_device):

@@ -1,4 +1,4 @@
-"""world_size-2 (and 3, ragged) gloo runs of the range-partitioned direct-force path on CPU.
+"""world_size-2 (and 3 and 8, ragged) gloo runs of the range-partitioned direct-force path on CPU.
 
 What is exercised is the PRODUCT's distributed control flow -- nbd/dist.py (partition, the one
 all-gather per step) and the sharded branches of galaxify.simulation (local kick-drift-pack ->
@@ -127,7 +127,11 @@ def _worker(rank, world, port, n, steps, integrator, out_dir):
 
 @pytest.mark.parametrize("world,n,integrator", [(2, 512, "LeapFrogSimulator"), (2, 301, "LeapFrogSimulator"),
                                                 (3, 200, "LeapFrogSimulator"), (2, 256, "EulerSimulator"),
-                                                (3, 2, "LeapFrogSimulator"), (2, 255, "EulerSimulator")])
+                                                (3, 2, "LeapFrogSimulator"), (2, 255, "EulerSimulator"),
+                                                # BASELINE configs[4]'s rank count: equal shards (one
+                                                # all_gather_into_tensor straight into place) and ragged ones
+                                                # (padded sends + index_select compaction, 1001 = 8 x 125 + 1)
+                                                (8, 512, "LeapFrogSimulator"), (8, 1001, "LeapFrogSimulator")])
 def test_sharded_steps_match_unsharded_oracle(world, n, integrator, tmp_path):
     from nbd.plummer import generate_plummer
     from oracle import galaxify_oracle as go
