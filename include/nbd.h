@@ -424,7 +424,9 @@ int nbd_layernorm_bwd_f32(const float* x, int ldx, int c, const float* gamma, fl
  *   filters_shuffled = the (cell, in, out) filters in MFMA fragment order (v_mfma_f32_16x16x4_f32): float index
  *   ((((cell * ceil(O/16) + cb) * ceil(I/16) + g) * 64 + lane) * 4 + j) holds F[cell][16 g + 4 (lane >> 4) + j][16 cb +
  *   (lane & 15)], zero beyond I / O (nbd_contconv_filter_floats floats in all). act: 0 none, 1 tanh.
- *   rowscale may be NULL. Deterministic. */
+ *   rowscale may be NULL. Deterministic.
+ * Limit: a node with more than 65 535 edges (the pair kernel counts pairs per (node, cell) in 16 bits) is not
+ *   processed -- its whole tile of NBD_CC_TILE nodes comes out as NaN, loudly, instead of being summed wrongly. */
 int nbd_contconv_fused_supported(int in_channels, int out_channels, int n_cells);
 size_t nbd_contconv_pairs_bytes(int n, int64_t edge_capacity, int n_cells);
 int nbd_contconv_pairs_f32(const float* pos, const int* rowptr, const int* centres, int n, int64_t edge_capacity,

@@ -69,7 +69,15 @@ class ContinuousConv(nn.Module):
         return nnops.contconv_shuffle_filters(self.filters, idx)
 
     def fused_ok(self) -> bool:
-        return self.use_fused and nnops.contconv_fused_supported(self.in_channels, self.out_channels, self.cells()[2])
+        ok = self.use_fused and nnops.contconv_fused_supported(self.in_channels, self.out_channels, self.cells()[2])
+        if self.use_fused and not ok and not getattr(self, "_warned_fallback", False):
+            import warnings
+            self._warned_fallback = True          # once per layer: the other path is ~2.5x slower and forms A in HBM
+            warnings.warn(f"ContinuousConv({self.in_channels} -> {self.out_channels}, D = {self.filter_resolution}, "
+                          f"{self.cells()[2]} reachable cells): outside the fused block-sparse kernel's shapes "
+                          f"(in_channels % 4 == 0, <= 128; <= 160 cells) -- using the binned-matrix + GEMM path, which "
+                          f"materialises A (nodes x cells x in_channels fp32) in HBM")
+        return ok
 
     use_fused = True         # block-sparse fused kernels (csrc/contconv_fused.hip) where the shape allows
 

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   __shared__ int seg_pairs[NSEG][MAXC], seg_rows[NSEG][MAXC];
   __shared__ int rp[TN + 1];
   __shared__ int cmap[216];                                 // D <= 6
-  __shared__ int next_node, s_tile_steps;
+  __shared__ int next_node, s_tile_steps, s_over;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x, n0 = tile * TN, n_here = min(TN, n - n0);
   const float half = (float)(D - 1) / 2.0f;
@@ -185,10 +185,16 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   PT(0)
   if (tid <= TN) rp[tid] = rowptr[min(n0 + tid, n)];
   if (tid < D * D * D) cmap[tid] = job.cell_map ? job.cell_map[tid] : tid;
-  if (tid == 0) next_node = 0;
+  if (tid == 0) { next_node = 0; s_over = 0; }
   for (int i = tid; i < TN * kc / 2; i += PAIR_THREADS) cnt32[i] = 0;
   __syncthreads();
-  const int e_t = rp[0], e_end = rp[n_here];
+  // The (node, cell) pair counters are 16 bits wide (two per LDS word: at D = 6 the tables fill the LDS as it is). A
+  // row can only overflow one with more than 65 535 edges (a hub of a > 65 536-body clump under the search's "first 32
+  // by index" rule): such a tile is marked instead of counted wrongly -- tile_nsteps = -1, which the fused kernel skips
+  // and the finishing kernel turns into NaN outputs for the tile's nodes. Loud, not silent.
+  if (tid < n_here && rp[tid + 1] - rp[tid] > 65535) s_over = 1;
+  __syncthreads();
+  const int e_t = rp[0], e_end = s_over ? rp[0] : rp[n_here];
   const size_t row_base = (size_t)8 * e_t + tile, pair_base = (size_t)8 * e_t;
   int4* __restrict__ t_steps = job.steps + step_base(tile, e_t, n_cells);
 
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
     if (lane == 0) {
       rows[row_base + row_carry] = make_int2(0, pair_carry);      // sentinel: end of the last row
       t_steps[step_carry] = make_int4(0, 0, pair_carry, 0);      // terminal record: end of the last step
-      job.tile_nsteps[tile] = step_carry;
+      job.tile_nsteps[tile] = s_over ? -1 : step_carry;
       s_tile_steps = step_carry;
     }
   }
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
     int nl = 0;
     if (hl == 0) nl = atomicAdd(&next_node, 1);
     nl = __shfl(nl, lane & 32);                            // broadcast inside the half-wave
-    if (nl >= n_here) break;
+    if (nl >= n_here || s_over) break;
     const int node = n0 + nl;
     const float xn = pos[3 * node], yn = pos[3 * node + 1], zn = pos[3 * node + 2];
     const int e0 = rp[nl], e1 = rp[nl + 1];
@@ -501,7 +507,7 @@ __device__ __forceinline__ void cc_load_table(const CCArgs& A, const CCLds& L, i
   int carry = 0;
   for (int c0 = 0; c0 < A.n_tiles && carry < p1; c0 += CC_THREADS) {
     const int t = c0 + tid;
-    const int v = t < A.n_tiles ? A.tile_nsteps[t] : 0;
+    const int v = t < A.n_tiles ? max(A.tile_nsteps[t], 0) : 0;      // -1: a tile the pair kernel refused (see there)
     const int incl = wave_incl_scan(v, lane);
     if (lane == 63) L.s_red[wave] = incl;
     __syncthreads();
@@ -984,7 +990,7 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
   // mean at D = 4: their producers, not their MFMAs, set the pace). cut(w) = first step whose cost-before is >= B_w.
   {
     int lc = 0, ls = 0;
-    for (int t = tid; t < A.n_tiles; t += CC_THREADS) { lc += A.tile_cost[t]; ls += A.tile_nsteps[t]; }
+    for (int t = tid; t < A.n_tiles; t += CC_THREADS) { lc += A.tile_cost[t]; ls += max(A.tile_nsteps[t], 0); }
     lc = wave_sum(lc); ls = wave_sum(ls);
     if (lane == 0) { L.s_red[wave] = lc; s_red2[wave] = ls; }
     __syncthreads();
@@ -1007,7 +1013,7 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
     int cbase = 0, sbase = 0;
     for (int c0 = 0; c0 < A.n_tiles; c0 += CC_THREADS) {
       const int t = c0 + tid;
-      const int vc = t < A.n_tiles ? A.tile_cost[t] : 0, vs = t < A.n_tiles ? A.tile_nsteps[t] : 0;
+      const int vc = t < A.n_tiles ? A.tile_cost[t] : 0, vs = t < A.n_tiles ? max(A.tile_nsteps[t], 0) : 0;
       const int ic = wave_incl_scan(vc, lane), is = wave_incl_scan(vs, lane);
       __syncthreads();
       if (lane == 63) { L.s_red[wave] = ic; s_red2[wave] = is; }
@@ -1073,7 +1079,7 @@ __global__ __launch_bounds__(256) void contconv_stream_finish_kernel(
   __shared__ int s_cut[CC_GRID + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
   int lo = 0;
-  for (int t = tid; t < tile; t += 256) lo += tile_nsteps[t];
+  for (int t = tid; t < tile; t += 256) lo += max(tile_nsteps[t], 0);
   lo = wave_sum(lo);
   if (lane == 0) s_lo[wave] = lo;
   for (int w = tid; w <= G; w += 256) s_cut[w] = cuts[w];
@@ -1094,6 +1100,7 @@ __global__ __launch_bounds__(256) void contconv_stream_finish_kernel(
     const int row = r0 + rl;
     if (row >= n || c >= O) continue;
     f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (cnt < 0) v = f4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};   // refused tile
     for (int w = w_first; w <= w_last; ++w) {
       if (s_cut[w] >= s_cut[w + 1]) continue;                                  // empty range: wrote nothing
       const f4 x = *reinterpret_cast<const f4*>(partial + ((size_t)(w + tile) * TN + (row - tile * TN)) * OP + c);

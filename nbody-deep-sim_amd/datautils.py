@@ -22,8 +22,10 @@ def read_rows(csv_path):
     try:
         import pyarrow  # noqa: F401
         df = pd.read_csv(csv_path, usecols=_COLS, engine="pyarrow")
-    except ImportError:
-        df = pd.read_csv(csv_path, usecols=_COLS)
+    except (ImportError, ValueError):       # no pyarrow, or a pandas that rejects this usecols / engine combination
+        # round_trip: the C parser's default fast path can be one fp64 ulp off the correctly rounded value pyarrow
+        # gives; with it both engines return the same numbers, so the dataset does not depend on the environment
+        df = pd.read_csv(csv_path, usecols=_COLS, float_precision="round_trip")
     return df
 
 

@@ -355,6 +355,26 @@ def test_contconv_extreme_aggregations_match_oracle(agg, D, I, O, gpu_device):
         layer(pos.cuda(), feat.cuda().requires_grad_(True), edge_index=ei.cuda())
 
 
+def test_contconv_fused_refuses_a_row_beyond_its_16_bit_counters_loudly(gpu_device):
+    """The pair kernel counts pairs per (node, cell) in 16 bits: a node with more than 65 535 edges cannot be binned.
+    Its tile is refused -- NaN for the tile's 128 nodes -- and every other tile is computed as usual."""
+    import contconv
+    n = 70000
+    g = torch.Generator().manual_seed(3)
+    pos = torch.rand(n, 3, generator=g) * 0.3
+    feat = torch.randn(n, 4, generator=g)
+    hub_src = torch.arange(1, 66001)
+    row = torch.cat([torch.zeros(66000, dtype=torch.int64), torch.arange(200, 400)])       # node 0: 66 000 edges
+    col = torch.cat([hub_src, torch.arange(5000, 5200)])
+    ei = torch.stack([row, col]).cuda()
+    layer = contconv.ContinuousConv(4, 8, 4, radius=1.0, agg="sum").cuda()
+    with torch.no_grad():
+        out = layer(pos.cuda(), feat.cuda(), edge_index=ei).cpu()
+        ok = layer(pos.cuda(), feat.cuda(), edge_index=ei[:, 66000:]).cpu()
+    assert torch.isnan(out[:128]).all()
+    assert torch.isfinite(out[128:]).all() and torch.equal(out[128:], ok[128:])
+
+
 def test_contconv_model_matches_oracle(gpu_device):
     import contconv
     from oracle import surrogate_oracle as so

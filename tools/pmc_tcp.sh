@@ -1,11 +1,14 @@
 #!/bin/bash
-# Vector-memory-path counters (L1 / TA / TLB) of one command, each set in its own rocprofv3 run:
+# Vector-memory-path counters (L1 / TA / TLB) of one command, each set in its own rocprofv3 run (the TA block takes at
+# most three of its counters per pass: six in one set aborted rocprofv3 with "error code 38: Request exceeds the
+# capabilities of the hardware to collect" in round 2 -- gpurun_out/r02f_tcp_cc_2.log -- and the later passes never ran):
 #   tools/pmc_tcp.sh <out prefix under gpurun_out> <kernel substring> -- python3 <script> [args]
 prefix=$1; kern=$2; shift; shift; shift
 sets=(
  "GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum"
  "GRBM_GUI_ACTIVE TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_PENDING_STALL_CYCLES_sum"
- "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum TCP_GATE_EN1_sum"
+ "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
+ "GRBM_GUI_ACTIVE TA_TOTAL_WAVEFRONTS_sum TCP_GATE_EN1_sum"
  "GRBM_GUI_ACTIVE TCP_TCR_TCP_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
  "GRBM_GUI_ACTIVE SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 )
