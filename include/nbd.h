@@ -347,6 +347,21 @@ typedef struct nbd_gnn_layer_args {
 } nbd_gnn_layer_args;
 int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream);
 
+/* GraphModel.predict (gnn.py:205-215: transform_to_graph :11-22, then forward :130-148) as ONE call: the kNN graph of
+ * `pos` (k nearest, ascending (d2, j), self excluded unless loop -- nbd_knn_graph_hint_f32's rule) into edge_index
+ * [2][n * min(k, n - 1 + loop)], then layers[0 .. n_layers) through nbd_gnn_layer_f32 on that graph (the callee sets
+ * each layer's rowptr / src / fixed_k / n). use_hint: edge_index's previous content (an earlier result for a similar
+ * configuration, e.g. the previous rollout step) bounds the search; the result does not depend on it. */
+#define NBD_GNN_MAX_LAYERS 8
+typedef struct nbd_gnn_forward_args {
+  const float* pos;       /* [n][3] */
+  int n, k, loop, use_hint;
+  int64_t* edge_index;    /* [2][n * kk] */
+  int n_layers;
+  nbd_gnn_layer_args layers[NBD_GNN_MAX_LAYERS];
+} nbd_gnn_forward_args;
+int nbd_gnn_forward_f32(const nbd_gnn_forward_args* args, nbd_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Backward kernels: what `loss.backward()` executes in the reference's training step
  * (gnn.py:163-191 train_batch / train_graph_batch, contconv.py:242-247, driven by trainer.py:60-72)

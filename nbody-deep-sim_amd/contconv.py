@@ -150,10 +150,32 @@ class ContinuousConv(nn.Module):
         """agg = "max" / "min" (scatter's other reductions, contconv.py:95-97): the feature-side binning needs a
         LINEAR aggregation, so the per-edge messages are materialised -- every edge becomes a row of its own in
         a virtual graph (row N + e at the position of the edge's aggregation target, one edge, sum aggregation)
-        through the same kernels -- and reduced per target by nbd_segment_reduce_f32. Inference only."""
-        if torch.is_grad_enabled() and (self.filters.requires_grad or features.requires_grad):
-            raise NotImplementedError("ContinuousConv(agg='max'/'min') has no backward kernels; use torch.no_grad()")
+        through the same kernels -- and reduced per target by nbd_segment_reduce_f32. Under autograd the same construction
+        runs through the differentiable layer and ag.SegmentMaxFn (below)."""
         n, dev = positions.shape[0], positions.device
+        if torch.is_grad_enabled() and (self.filters.requires_grad or features.requires_grad):
+            # Training (contconv.py:95-97 hands `agg` straight to scatter, so the reference trains through max / min too):
+            # the same virtual one-edge-per-row graph, through the differentiable sum-aggregation layer (ag.ContConvFn:
+            # gradients reach the filters and, through the concatenation, the features), then the segment maximum whose
+            # backward sends a row's gradient to the first message attaining it (ag.SegmentMaxFn, as EdgeConv's max).
+            e = int(rowptr[-1])
+            if e == 0:
+                red = torch.zeros((n, self.out_channels), dtype=torch.float32, device=dev) + 0.0 * self.filters.sum()
+            else:
+                tgt = torch.repeat_interleave(torch.arange(n, device=dev), (rowptr[1:] - rowptr[:-1]).to(torch.int64), output_size=e)
+                pos_v = torch.cat([positions, positions[tgt]]).contiguous()
+                feat_v = torch.cat([features, torch.zeros((e, features.shape[1]), dtype=features.dtype, device=dev)])
+                ei_v = torch.stack([n + torch.arange(e, device=dev), centres[:e].to(torch.int64)])
+                agg, self.agg = self.agg, "sum"
+                try:
+                    msgs = self.forward(pos_v, feat_v, edge_index=ei_v)[n:]
+                finally:
+                    self.agg = agg
+                red = ag.SegmentMaxFn.apply((-msgs if agg == "min" else msgs).contiguous(), rowptr, n)
+                red = -red if agg == "min" else red
+            if out is not None:
+                raise NbdError("ContinuousConv.forward: out= is an inference-only option")
+            return torch.tanh(red) if act == "tanh" else red
         e = int(centres.numel()) if rowptr is None else int(rowptr[-1])       # one read-back: this path is not the hot one
         tgt = torch.repeat_interleave(torch.arange(n, device=dev), (rowptr[1:] - rowptr[:-1]).to(torch.int64),
                                       output_size=e)

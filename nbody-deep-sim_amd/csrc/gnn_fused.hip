@@ -353,4 +353,29 @@ int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
   return status();
 }
 
+// GraphModel.predict's device work in ONE call (gnn.py:205-215 -> transform_to_graph :11-22 -> forward :130-148): the
+// kNN search (hinted by the buffer's previous content when asked) and the fused layers on its result. The host side of
+// an eager rollout step was five ctypes calls, each marshalling a 30-field struct, around 66 us of kernels; now it fills
+// this struct once per (model, n, k) and patches a handful of pointers per call.
+int nbd_gnn_forward_f32(const nbd_gnn_forward_args* args, nbd_stream_t stream) {
+  if (!args) return NBD_E_BADARG;
+  const nbd_gnn_forward_args& a = *args;
+  if (a.n < 0 || a.k < 0 || a.n_layers < 1 || a.n_layers > NBD_GNN_MAX_LAYERS) return NBD_E_BADARG;
+  if (a.n == 0) return 0;
+  if (!a.pos || !a.edge_index) return NBD_E_BADARG;
+  const int avail = a.n - (a.loop ? 0 : 1);
+  const int kk = a.k < avail ? a.k : (avail > 0 ? avail : 0);
+  const int64_t e = (int64_t)a.n * kk;
+  int rc = nbd_knn_graph_hint_f32(a.pos, a.n, a.k, a.loop, nullptr, nullptr, nullptr, e, a.edge_index,
+                                  a.use_hint ? a.edge_index : nullptr, stream);
+  if (rc) return rc;
+  for (int l = 0; l < a.n_layers; ++l) {
+    nbd_gnn_layer_args la = a.layers[l];
+    la.rowptr = nullptr; la.src = a.edge_index; la.fixed_k = kk; la.n = a.n;      // edge_index[0]: the sources, kk per node
+    rc = nbd_gnn_layer_f32(&la, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -18,6 +18,7 @@ torch.optim optimiser steps on the `.grad` fields.
 """
 from __future__ import annotations
 
+import ctypes
 import time
 
 import torch
@@ -155,6 +156,8 @@ class GraphModel(torch.nn.Module):
         self._out_hint = None
         self._brs_const = None
         self._knn_buf = None
+        self._one_call = None          # cached nbd_gnn_forward_args of predict() (see _one_call_plan)
+        self.use_one_call = True       # predict(): search + layers through ONE C-ABI call when the configuration allows
         self.to(device)
 
     def get_config(self):
@@ -334,6 +337,90 @@ class GraphModel(torch.nn.Module):
         return True
 
     # ------------------------------------------------------------------ inference API
+    # ------------------------------------------------------------------ predict() as ONE C-ABI call
+    def _one_call_plan(self, w, n, kk, k, dev, ldx):
+        """nbd_gnn_forward_args for (these weights, n, k): every pointer that does not change from call to call filled
+        in once -- weights, the intermediate [P | Q] buffers, LayerNorm / head -- or None when the configuration is not
+        the all-fused one (no encoder, input_dim <= 8, sum / mean, single-Linear head of <= 8 outputs)."""
+        from nbd import _lib
+        layers, head = w["layers"], w["head"]
+        h, e, n_layers = self.gnn_dim, self.input_dim, len(layers)
+        if (not self.use_fused or self.aggr == "max" or w["enc"] is not None or e > 8 or h > 128
+                or n_layers > _lib.GNN_MAX_LAYERS or len(head) != 1 or head[0][0].shape[0] > 8):
+            return None
+        aggr = "mean" if self.aggr == "mean" else "sum"
+        fa = _lib.GnnForwardArgs()
+        keep = [w]
+        dummy_x = torch.empty((1, ldx), dtype=torch.float32, device=dev)        # layout carrier; pointers patched per call
+        dummy_out = torch.empty((1, head[0][0].shape[0]), dtype=torch.float32, device=dev)
+        pq = None
+        for li, (wpq, bpq, w2, b2) in enumerate(layers):
+            kw = dict(n=n, h=h, aggr=aggr, rowptr=None, src=None, fixed_k=kk, w2t=w["fused_t"][li][1], b2=b2)
+            if pq is not None:
+                kw["pq"] = pq
+            else:
+                bp = layers[li][1][:h].contiguous()
+                keep.append(bp)
+                kw.update(x=dummy_x, f=e, wpq=wpq, bpq=bp)
+            if li < n_layers - 1:
+                nxt = torch.empty((n, 2 * h), dtype=torch.float32, device=dev)
+                keep.append(nxt)
+                m_t, c = w["folded"][li]
+                a = nnops.gnn_layer_args(epilogue="next_pq_folded", w_ep=m_t, b_ep=layers[li + 1][1], ep_out=2 * h, out=nxt,
+                                         **dict(kw, w2t=None, b2=c))
+                pq = nxt
+            else:
+                a = nnops.gnn_layer_args(epilogue="final_head", w_ep=head[0][0], b_ep=head[0][1], ep_out=head[0][0].shape[0],
+                                         enc=dummy_x, e=e, ln_g=self.layer_norm.weight.detach(),
+                                         ln_b=self.layer_norm.bias.detach(), ln_eps=self.layer_norm.eps, out=dummy_out, **kw)
+            if a is None:
+                return None
+            a.ldx = ldx if a.x else a.ldx
+            fa.layers[li] = a
+        fa.n, fa.k, fa.loop, fa.n_layers = n, k, 0, n_layers
+        fa.layers[n_layers - 1].ldenc = ldx
+        fa.layers[n_layers - 1].ldout = head[0][0].shape[0]
+        return {"fa": fa, "keep": keep, "out_dim": head[0][0].shape[0]}
+
+    def _predict_one_call(self, x_in, pos, k, out=None, kick=None):
+        """kNN graph + all fused layers through nbd_gnn_forward_f32, or None when this call cannot go that way (first
+        call of a sequence: no previous graph to reuse as buffer and hint; configuration not all-fused)."""
+        from nbd import _lib
+        n, dev = pos.shape[0], pos.device
+        kk = max(min(k, n - 1), 0)
+        buf = self._knn_buf
+        if (not self.use_one_call or n == 0 or kk == 0 or buf is None or buf.shape != (2, n * kk) or buf.device != dev or x_in.dtype != torch.float32
+                or x_in.stride(1) != 1 or pos.dtype != torch.float32 or not pos.is_contiguous()):
+            return None
+        w = self._cache.get(self._build_weights)
+        ldx = x_in.stride(0)
+        key = (id(w), n, kk, k, str(dev), ldx)
+        plan = self._one_call
+        if plan is None or plan["key"] != key:
+            plan = self._one_call_plan(w, n, kk, k, dev, ldx)
+            if plan is None:
+                return None
+            plan["key"] = key
+            self._one_call = plan
+        fa, od = plan["fa"], plan["out_dim"]
+        if out is None or tuple(out.shape) != (n, od) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+            out = torch.empty((n, od), dtype=torch.float32, device=dev)
+        last = fa.layers[fa.n_layers - 1]
+        fa.pos, fa.edge_index, fa.use_hint = pos.data_ptr(), buf.data_ptr(), 1
+        fa.layers[0].x = x_in.data_ptr()
+        last.enc, last.out = x_in.data_ptr(), out.data_ptr()
+        if kick is not None:
+            if kick[0].shape != (n, od) or kick[0].dtype != torch.float32 or not kick[0].is_contiguous():
+                return None
+            last.kick_vel, last.kick_c = kick[0].data_ptr(), float(kick[1])
+        else:
+            last.kick_vel, last.kick_c = None, 0.0
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().nbd_gnn_forward_f32(ctypes.byref(fa), _lib.current_stream(dev)), "nbd_gnn_forward_f32")
+        self._kick_done = kick is not None
+        graphops.mark(buf, "_nbd_grouped")
+        return out
+
     def predict(self, pos, feat, neighbors=None):
         """gnn.py:205-215. The reference never forwards `self.neighbors` here, so the graph uses
         transform_to_graph's default k = 50; `neighbors=` is this build's optional override."""
@@ -347,13 +434,17 @@ class GraphModel(torch.nn.Module):
             # the previous call's graph (same n, k) is both the hint and the output buffer of this search: in a
             # rollout consecutive configurations are close, and the search result does not depend on the hint
             kk = max(min(k, pos.shape[0] - 1), 0)
+            x_in = torch.cat((pos, feat[:, 3:]), dim=-1) if self.input_dim == 4 else torch.cat((pos, feat), dim=-1)
+            x_in = x_in.to(torch.float32)
+            pred = self._predict_one_call(x_in, pos.contiguous(), k)       # search + layers in one C-ABI call
+            if pred is not None:
+                return pred
             buf = self._knn_buf
             if buf is not None and (buf.shape != (2, pos.shape[0] * kk) or buf.device != pos.device):
                 buf = None
             ei = graphops.knn_graph(pos, k=k, batch=None, loop=False, hint=buf, out=buf)
             self._knn_buf = ei
-            x_in = torch.cat((pos, feat[:, 3:]), dim=-1) if self.input_dim == 4 else torch.cat((pos, feat), dim=-1)
-            pred = self._forward_inference(x_in.to(torch.float32), ei, max(min(k, pos.shape[0] - 1), 0))
+            pred = self._forward_inference(x_in, ei, max(min(k, pos.shape[0] - 1), 0))
         return pred
 
     def _predict_posm(self, posm, pos, k=50, out=None, kick=None):
@@ -374,6 +465,9 @@ class GraphModel(torch.nn.Module):
         with torch.no_grad():
             n = pos.shape[0]
             kk = max(min(k, n - 1), 0)
+            pred = self._predict_one_call(posm[:n], pos, k, out=out, kick=self._kick_hint)
+            if pred is not None:
+                return pred
             buf = self._knn_buf
             if buf is not None and (buf.shape != (2, n * kk) or buf.device != pos.device):
                 buf = None

@@ -48,6 +48,15 @@ class GnnLayerArgs(ctypes.Structure):
                 ("ln_eps", c_float), ("out", c_void_p), ("ldout", c_int), ("kick_vel", c_void_p), ("kick_c", c_float)]
 
 
+GNN_MAX_LAYERS = 8
+
+
+class GnnForwardArgs(ctypes.Structure):
+    """Mirror of `nbd_gnn_forward_args` (include/nbd.h), field for field."""
+    _fields_ = [("pos", c_void_p), ("n", c_int), ("k", c_int), ("loop", c_int), ("use_hint", c_int),
+                ("edge_index", c_void_p), ("n_layers", c_int), ("layers", GnnLayerArgs * GNN_MAX_LAYERS)]
+
+
 # name -> (restype, argtypes); mirrors include/nbd.h one to one (tests check the two agree)
 _F = POINTER(c_float)
 SIGNATURES = {
@@ -148,6 +157,7 @@ SIGNATURES = {
     "nbd_contconv_fused_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_int,
                                        c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "nbd_degree_scale_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "nbd_gnn_forward_f32": (c_int, [c_void_p, c_void_p]),
     "nbd_gnn_layer_f32": (c_int, [POINTER(GnnLayerArgs), c_void_p]),
     # --- backward kernels (csrc/train.hip) and the transposed adjacency they gather over
     "nbd_csr_by_key_i64": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

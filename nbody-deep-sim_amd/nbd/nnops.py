@@ -281,21 +281,20 @@ def degree_scale(rowptr, n, mode, device):
 EPILOGUE = {"write_x": 0, "next_pq": 1, "final_head": 2, "final_ln": 3, "next_pq_folded": 4}
 
 
-def gnn_layer(*, n, h, aggr, rowptr, src, fixed_k, w2t, b2, epilogue, out, pq=None, x=None, f=0, wpq=None, bpq=None,
-              w_ep=None, b_ep=None, ep_out=0, enc=None, e=0, ln_g=None, ln_b=None, ln_eps=1e-5, kick_vel=None, kick_c=0.0):
-    """One fused EdgeConv layer (nbd_gnn_layer_f32). Returns False (nothing launched) when the shape is
-    outside what the fused kernel supports, so the caller can take the general multi-kernel path.
-    kick_vel (n, ep_out), final_head only: vel += kick_c * out in the epilogue (Trainer.step's second half-kick)."""
+def gnn_layer_args(*, n, h, aggr, rowptr, src, fixed_k, w2t, b2, epilogue, out, pq=None, x=None, f=0, wpq=None, bpq=None,
+                   w_ep=None, b_ep=None, ep_out=0, enc=None, e=0, ln_g=None, ln_b=None, ln_eps=1e-5, kick_vel=None, kick_c=0.0):
+    """The `nbd_gnn_layer_args` struct of one fused EdgeConv layer, or None when the shape is outside what the fused
+    kernel supports (the caller then takes the general multi-kernel path)."""
     a = _lib.GnnLayerArgs()
     dev = out.device
     kp = 64 * ((h + 63) // 64)
     lds_floats = kp * ep_out if epilogue == "next_pq_folded" else kp * h + kp * (ep_out if epilogue == "next_pq" else 0)
     if h > 128 or (pq is None and f > 8) or lds_floats * 4 > 64 * 1024:
-        return False
+        return None
     if epilogue == "final_head" and ep_out > 8:
-        return False
+        return None
     if epilogue in ("final_head", "final_ln") and e > 256:
-        return False
+        return None
     for t in (w2t, b2, wpq, bpq, w_ep, b_ep, ln_g, ln_b):
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda):
             raise _lib.NbdError("gnn_layer: weights must be contiguous fp32 CUDA tensors")
@@ -313,6 +312,17 @@ def gnn_layer(*, n, h, aggr, rowptr, src, fixed_k, w2t, b2, epilogue, out, pq=No
                 not kick_vel.is_contiguous() or kick_vel.device != dev:
             raise _lib.NbdError("gnn_layer: kick_vel must be a contiguous fp32 (n, ep_out) tensor on the layer's device")
         a.kick_vel, a.kick_c = kick_vel.data_ptr(), float(kick_c)
+    return a
+
+
+def gnn_layer(**kw):
+    """One fused EdgeConv layer (nbd_gnn_layer_f32). Returns False (nothing launched) when the shape is
+    outside what the fused kernel supports, so the caller can take the general multi-kernel path.
+    kick_vel (n, ep_out), final_head only: vel += kick_c * out in the epilogue (Trainer.step's second half-kick)."""
+    a = gnn_layer_args(**kw)
+    if a is None:
+        return False
+    dev = kw["out"].device
     with _lib.on_device(dev):
         _lib.check(_lib.lib().nbd_gnn_layer_f32(ctypes.byref(a), _lib.current_stream(dev)), "nbd_gnn_layer_f32")
     return True

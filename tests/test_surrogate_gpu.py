@@ -351,8 +351,33 @@ def test_contconv_extreme_aggregations_match_oracle(agg, D, I, O, gpu_device):
     assert float(got[torch.bincount(ei[0], minlength=300) == 0].abs().max()) == 0.0
     with pytest.raises(NotImplementedError):
         contconv.ContinuousConv(I, O, D, agg="mul")
-    with pytest.raises(NotImplementedError):
-        layer(pos.cuda(), feat.cuda().requires_grad_(True), edge_index=ei.cuda())
+    # (training through max / min: tests/test_train_gpu.py::test_contconv_extreme_aggregations_train)
+
+
+def test_gnn_predict_through_one_cabi_call_equals_the_per_kernel_path(gpu_device):
+    """predict() enqueues the kNN search and the fused layers through nbd_gnn_forward_f32 (one ctypes call) from its
+    second call on: same graph, same kernels, same bits as the per-kernel calls, over a drifting sequence."""
+    import gnn
+    torch.manual_seed(4)
+    pos, vel, m = _plummer_pos(700, 12)
+    pos, vel, m1 = pos.cuda(), vel.cuda(), (m * 700)[:, None].cuda()
+    a = gnn.GraphModel(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", device="cuda")
+    b = gnn.GraphModel(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", device="cuda")
+    b.load_state_dict(a.state_dict())
+    b.use_one_call = False
+    for step in range(5):
+        feat = torch.cat([vel, m1], 1)
+        ya, yb = a.predict(pos, feat), b.predict(pos, feat)
+        assert torch.equal(ya, yb), step
+        assert torch.equal(a._knn_buf, b._knn_buf)
+        if step:
+            assert a._one_call is not None and b._one_call is None
+        pos = pos + 0.01 * vel
+    # k override and a changed n re-plan instead of reusing stale pointers
+    assert torch.equal(a.predict(pos[:300].contiguous(), feat[:300].contiguous(), neighbors=7),
+                       b.predict(pos[:300].contiguous(), feat[:300].contiguous(), neighbors=7))
+    assert torch.equal(a.predict(pos[:300].contiguous(), feat[:300].contiguous(), neighbors=7),
+                       b.predict(pos[:300].contiguous(), feat[:300].contiguous(), neighbors=7))
 
 
 def test_contconv_fused_refuses_a_row_beyond_its_16_bit_counters_loudly(gpu_device):

@@ -336,6 +336,40 @@ def test_contconv_layer_gradients_match_oracle(agg, D, I, O, gpu_device):
     assert torch.equal(g1, layer.filters.grad) or global_rel(g1.cpu(), layer.filters.grad.cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("agg", ["max", "min"])
+@pytest.mark.parametrize("D,I,O", [(3, 8, 6), (4, 70, 12)])
+def test_contconv_extreme_aggregations_train(agg, D, I, O, gpu_device):
+    """contconv.py:95-97 hands `agg` straight to scatter, so the reference trains through max / min as well: feature and
+    filter gradients against autograd on the oracle (scatter_reduce amax / amin), by edge list and by the search's lists;
+    rows without edges get no gradient."""
+    import contconv
+    from nbd import graphops
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(D + len(agg))
+    n = 150
+    pos, _, _ = _plummer(n, 8)
+    feat = torch.randn(n, I)
+    dout = torch.randn(n, O)
+    ora = so.ContinuousConvOracle(I, O, D, radius=1.0, agg=agg)
+    layer = contconv.ContinuousConv(I, O, D, radius=1.0, agg=agg).cuda()
+    layer.load_state_dict(ora.state_dict())
+    ei = so.radius_graph(pos, 1.0, loop=False, max_num_neighbors=32)              # isolated nodes exist
+    fr = feat.clone().requires_grad_()
+    ref = torch.tanh(ora(pos, fr, ei))
+    ref.backward(dout)
+    fg = feat.clone().cuda().requires_grad_()
+    out = layer(pos.cuda(), fg, edge_index=ei.cuda(), act="tanh")
+    assert global_rel(out.detach().cpu(), ref.detach()) < TOL
+    out.backward(dout.cuda())
+    assert global_rel(fg.grad.cpu(), fr.grad) < TOL
+    assert global_rel(layer.filters.grad.cpu(), ora.filters.grad) < TOL
+    layer.filters.grad = None
+    fg2 = feat.clone().cuda().requires_grad_()
+    lists = graphops.radius_lists(pos.cuda(), 1.0, None, loop=False, max_num_neighbors=32)
+    layer(pos.cuda(), fg2, lists=lists, act="tanh").backward(dout.cuda())
+    assert global_rel(fg2.grad.cpu(), fr.grad) < TOL and global_rel(layer.filters.grad.cpu(), ora.filters.grad) < TOL
+
+
 CC_CFGS = [
     dict(in_channels=4, out_channels=3, filter_resolution=[4, 3], radius=1.0, agg="mean", self_loops=True,
          continuous_conv_layers=2, continuous_conv_dim=16, encoder_hiddens=[8, 12], decoder_hiddens=[10, 6]),
