@@ -456,7 +456,9 @@ int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int*
 /* Byte offsets of the sections of a pair-list buffer (for reports and tests; the layout is otherwise opaque):
  * [0] per-(tile, cell) descriptors, [1] rows, [2] pair sources, [3] pair weights, [4] step records (int4 per 16-row
  * step), [5] steps per tile (int32 [tiles], tiles = ceil(n / NBD_CC_TILE)), [6] cost per tile (int32 [tiles]),
- * [7] total bytes. The fused kernel multiplies 16 x in x out per step. */
+ * [7] total bytes, [8] float [n]: 1 / max(in-degree, 1), the row scale of a mean aggregation (what
+ * nbd_degree_scale_f32 mode 0 returns, written by the pair kernel as a by-product). offsets: 9 entries. The fused
+ * kernel multiplies 16 x in x out per step. */
 int nbd_contconv_pairs_layout(int n, int64_t edge_capacity, int n_cells, size_t* offsets);
 size_t nbd_contconv_fused_workspace_bytes(int n, int n_cells, int out_channels);
 size_t nbd_contconv_filter_floats(int in_channels, int out_channels, int n_cells);

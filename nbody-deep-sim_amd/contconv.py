@@ -312,7 +312,13 @@ class ContinuousConvModel(nn.Module):
                 got = nnops.contconv_pairs_batch(pos, lists.rowptr, lists.centres, lists.centres.numel(),
                                                  float(np.float32(self.radius ** 2)), jobs[lo:lo + 4])
                 pair_cache.update(zip(keys[lo:lo + 4], got))
-        inv_deg = nnops.degree_scale(lists.rowptr, n, 0, x7.device) if n > 0 else None     # once for all layers
+        # 1 / in-degree, once for all layers: a by-product of the pair kernel when there are pair lists at all
+        inv_deg = None
+        if n > 0 and pair_cache:
+            pb, cap_e = pair_cache[keys[0]]
+            inv_deg = nnops.contconv_pairs_inv_degree(pb, n, cap_e, jobs[0][2])
+        elif n > 0:
+            inv_deg = nnops.degree_scale(lists.rowptr, n, 0, x7.device)
         if side is not None:
             cur.wait_stream(side)                                                          # the layers read the encoder's output
         for li, layer in enumerate(self.contconv):
@@ -322,7 +328,35 @@ class ContinuousConvModel(nn.Module):
                       scale=inv_deg)
         ln = nnops.layernorm(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
                              self.layer_norm.eps)
-        return run_chain(ln, w["head"])
+        out = getattr(data, "_out", None)          # _predict_posm(): the caller's acceleration buffer, written directly
+        if out is not None and (tuple(out.shape) != (n, self.out_channels) or out.dtype != torch.float32
+                                or not out.is_contiguous() or out.device != x7.device):
+            out = None
+        return run_chain(ln, w["head"], out_last=out)
+
+    @property
+    def input_dim(self):
+        """The model input's width ([pos | mass] = 4 as published, contconv.py:219-220): what Trainer's captured step asks
+        to decide whether the packed {x, y, z, m} rows of its kick-drift kernel ARE the model input."""
+        return self.in_channels
+
+    def _predict_posm(self, posm, pos, k=50, out=None, kick=None):
+        """predict() for a caller that already holds the packed rows {x, y, z, mass} the kick-drift kernel writes
+        (Trainer's captured rollout step): with in_channels == 4 that IS the model input, so neither [vel | mass] nor
+        [pos | mass] is concatenated and the prediction lands in the caller's buffer (three launches fewer per step).
+        The second half-kick stays with the caller (`_kick_done` False)."""
+        from nbd.data import Data
+        self.eval()
+        self._kick_done = False
+        with torch.no_grad():
+            if getattr(self, "_radius_cache", None) is None:
+                self._radius_cache = graphops.RadiusCache()
+            n = pos.shape[0]
+            data = Data(x=pos, batch=None)
+            data._x_pos = (posm[:n], pos)
+            data._out = out
+            data._radius_cache = self._radius_cache if self.use_radius_cache else None
+            return self.forward(data)
 
     def predict(self, pos, feat):
         """contconv.py:261-271. (The reference also builds a k=50 kNN graph here that forward() then

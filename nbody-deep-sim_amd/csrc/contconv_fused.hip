@@ -146,6 +146,7 @@ struct PairJob {
   float* pair_w;        // ... and its window * trilinear weight
   int4* steps;          // per tile (at step_base): {first row, cell | rows << 8 | steps left in the cell << 16, first pair, 0}
   int* tile_nsteps;     // [tiles]
+  float* inv_deg;       // [n] 1 / max(in-degree, 1): the row scale of a mean aggregation, a by-product (saves a launch)
   int* tile_cost;       // [tiles] sum of the tile's step costs (each step: max(CC_COST_MIN, its pairs)); the running
                         // (inclusive) sum inside the tile is the step records' .w
 };
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   // by index" rule): such a tile is marked instead of counted wrongly -- tile_nsteps = -1, which the fused kernel skips
   // and the finishing kernel turns into NaN outputs for the tile's nodes. Loud, not silent.
   if (tid < n_here && rp[tid + 1] - rp[tid] > 65535) s_over = 1;
+  if (tid < n_here) job.inv_deg[n0 + tid] = 1.0f / (float)max(rp[tid + 1] - rp[tid], 1);      // = nbd_degree_scale_f32 mode 0
   __syncthreads();
   const int e_t = rp[0], e_end = s_over ? rp[0] : rp[n_here];
   const size_t row_base = (size_t)8 * e_t + tile, pair_base = (size_t)8 * e_t;
@@ -1135,7 +1137,7 @@ int nbd_contconv_fused_supported(int in_channels, int out_channels, int n_cells)
 }
 
 namespace {
-struct PairsLayout { size_t desc, rows, src, w, steps, nsteps, cost, total; };
+struct PairsLayout { size_t desc, rows, src, w, steps, nsteps, cost, scale, total; };
 PairsLayout pairs_layout(int n, int64_t edge_capacity, int n_cells) {
   const size_t tiles = (size_t)ceil_div(n, TN);
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -1148,6 +1150,7 @@ PairsLayout pairs_layout(int n, int64_t edge_capacity, int n_cells) {
   L.steps = at; at += up((step_base((int)tiles, (int)edge_capacity, n_cells) + 2) * sizeof(int4));
   L.nsteps = at; at += up(tiles * sizeof(int));
   L.cost = at; at += up(tiles * sizeof(int));
+  L.scale = at; at += up((size_t)n * sizeof(float));
   L.total = at + 256;
   return L;
 }
@@ -1162,7 +1165,7 @@ int nbd_contconv_pairs_layout(int n, int64_t edge_capacity, int n_cells, size_t*
   if (n <= 0 || edge_capacity < 0 || n_cells <= 0 || !offsets) return NBD_E_BADARG;
   const PairsLayout L = pairs_layout(n, edge_capacity, n_cells);
   offsets[0] = L.desc; offsets[1] = L.rows; offsets[2] = L.src; offsets[3] = L.w; offsets[4] = L.steps;
-  offsets[5] = L.nsteps; offsets[6] = L.cost; offsets[7] = L.total;
+  offsets[5] = L.nsteps; offsets[6] = L.cost; offsets[7] = L.total; offsets[8] = L.scale;
   return 0;
 }
 
@@ -1191,6 +1194,7 @@ int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int*
     j.pair_src = reinterpret_cast<int*>(base + L.src); j.pair_w = reinterpret_cast<float*>(base + L.w);
     j.steps = reinterpret_cast<int4*>(base + L.steps); j.tile_nsteps = reinterpret_cast<int*>(base + L.nsteps);
     j.tile_cost = reinterpret_cast<int*>(base + L.cost);
+    j.inv_deg = reinterpret_cast<float*>(base + L.scale);
     const int kc = (nc + 3) & ~3;
     if (kc > kc_max) kc_max = kc;
   }

@@ -408,11 +408,16 @@ __global__ __launch_bounds__(256) void radius_stream_kernel(
 __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_merge_kernel(
     const int* __restrict__ tmp_list, const int* __restrict__ tmp_cnt, int n, int n_slices, int cap,
     int* __restrict__ nbr, int* __restrict__ deg, int* __restrict__ last, int* __restrict__ indeg,
-    const int* __restrict__ run_flag) {
+    const int* __restrict__ run_flag, const float* __restrict__ snap_pos = nullptr, float* __restrict__ snap_ref = nullptr,
+    int* __restrict__ snap_flags = nullptr) {
   if (run_flag && *run_flag == 0) return;
   const int i = blockIdx.x * kWavesPerBlock + wave_id();
   if (i >= n) return;
   const int lane = threadIdx.x & 63;
+  // cached search, rebuild step: the reference positions of this build and its bookkeeping ride along (a launch of its
+  // own -- radius_snapshot_kernel -- cost ~6 us on every step of a captured rollout, rebuild or not)
+  if (snap_ref && lane < 3) snap_ref[3 * i + lane] = snap_pos[3 * i + lane];
+  if (snap_flags && i == 0 && lane == 0) { snap_flags[1] = 1; snap_flags[2] = n; snap_flags[3] += 1; }
   const int c = lane < n_slices ? tmp_cnt[(size_t)lane * n + i] : 0;
   int incl = c;
 #pragma unroll
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_merge_kernel(
 // continues with a plain scan behind the list's last index. The result is exactly that of nbd_radius_search_f32.
 //   radius_disp_kernel      flags[0] = rebuild needed (never built, or some |pos - ref| too large)
 //   stream + merge (above)  the wide lists; they return at once unless flags[0]
-//   radius_snapshot_kernel  ref = pos, flags[1] = built; only when flags[0]
+//   (merge, on a rebuild)   ref = pos, flags[1] = built, flags[3] += 1
 //   radius_refresh_kernel   one wave per centre: the wide list re-tested against r
 __global__ __launch_bounds__(256) void radius_disp_kernel(const float* __restrict__ pos, const float* __restrict__ ref,
                                                           int n, float thr2, int* __restrict__ flags,
@@ -462,14 +467,6 @@ __global__ __launch_bounds__(256) void radius_disp_kernel(const float* __restric
   const float dx = pos[3 * i] - ref[3 * i], dy = pos[3 * i + 1] - ref[3 * i + 1], dz = pos[3 * i + 2] - ref[3 * i + 2];
   const float d2 = (dx * dx + dy * dy) + dz * dz;
   if (!(d2 <= thr2)) flags[0] = 1;                                 // NaN counts as moved
-}
-
-__global__ __launch_bounds__(256) void radius_snapshot_kernel(const float* __restrict__ pos, float* __restrict__ ref, int n,
-                                                              int* __restrict__ flags) {
-  if (flags[0] == 0) return;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < 3 * n) ref[i] = pos[i];
-  if (i == 0) { flags[1] = 1; flags[2] = n; flags[3] += 1; }        // [3]: builds so far (read by RadiusCache.rebuilds())
 }
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_refresh_kernel(
@@ -499,15 +496,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_refresh_kernel(
     }
     hits = total;
   };
-  for (int base = 0; base < wd && hits < cap; base += 64) {
-    const int t = base + lane;
-    int j = -1;
-    bool ok = false;
-    if (t < wd) {
-      j = wnbr[(size_t)i * wcap + t];
-      ok = dist2(pos, j, xi, yi, zi) < r2 && (loop || j != i);
+  // 256 candidates per trip, index loads together, then positions together (see the transposing kernel below)
+  for (int base = 0; base < wd && hits < cap; base += 256) {
+    int j[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = base + 64 * q + lane;
+      j[q] = t < wd ? wnbr[(size_t)i * wcap + t] : -1;
     }
-    take(j, ok);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int jj = max(j[q], 0);
+      ok[q] = j[q] >= 0 && dist2(pos, jj, xi, yi, zi) < r2 && (loop || jj != i);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (hits < cap) take(j[q], ok[q]);                     // wave-uniform: the list is full, later batches are not listed
   }
   if (hits < cap && wd >= wcap) {                                  // truncated list, not enough hits inside: scan on
     const int from = wnbr[(size_t)i * wcap + wcap - 1] + 1;
@@ -539,15 +544,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_transpose_cached_k
     if (ok) row[cnt + __popcll(m & ((1ull << lane) - 1ull))] = c;
     cnt += __popcll(m);
   };
-  for (int base = 0; base < wd; base += 64) {
-    const int t = base + lane;
-    int c = -1;
-    bool ok = false;
-    if (t < wd) {
-      c = wnbr[(size_t)j * wcap + t];
-      ok = dist2(pos, c, xj, yj, zj) < r2 && (loop || c != j) && j <= last[c];
+  // the candidate list, 256 entries per trip: the four index loads together, then their positions and `last` together
+  // (two memory round trips per trip; one 64-entry batch at a time made it six for a 192-entry list, and with one wave
+  // per node the kernel is nothing but those round trips: 28 us at N = 16 384)
+  for (int base = 0; base < wd; base += 256) {
+    int c[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = base + 64 * q + lane;
+      c[q] = t < wd ? wnbr[(size_t)j * wcap + t] : -1;
     }
-    take(c, ok);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cc = max(c[q], 0);
+      ok[q] = c[q] >= 0 && dist2(pos, cc, xj, yj, zj) < r2 && (loop || cc != j) && j <= last[cc];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) take(c[q], ok[q]);
   }
   if (wd >= wcap) {
     for (int base = wnbr[(size_t)j * wcap + wcap - 1] + 1; base < n; base += 64) {
@@ -626,17 +640,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sort_rows_kernel(const in
 // trip and three barriers, 19 us for n = 16 384; this one 10 us).
 __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int* __restrict__ cnt, int n,
                                                               int* __restrict__ ptr) {
+  // 16 counts per thread and trip (four int4 loads in flight): n = 16 384 -- the transposed radius lists of a
+  // ContinuousConv rollout step -- is ONE trip, one memory round trip, one wave scan, two barriers (round 2: 4096 per
+  // trip, four dependent trips, 10-11 us in the rollout's kernel trace).
   __shared__ int wave_sum[16];
   __shared__ int carry_s;
+  constexpr int PER = 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  for (int base = 0; base < n; base += 4096) {
-    const int i = base + 4 * threadIdx.x;
-    int v[4];
+  const bool vec = (reinterpret_cast<uintptr_t>(cnt) & 15) == 0 && (reinterpret_cast<uintptr_t>(ptr) & 15) == 0;
+  for (int base = 0; base < n; base += 1024 * PER) {
+    const int i = base + PER * threadIdx.x;
+    int v[PER];
+    if (vec && i + PER <= n) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = i + q < n ? cnt[i + q] : 0;
-    const int mine = (v[0] + v[1]) + (v[2] + v[3]);
+      for (int q = 0; q < PER; q += 4) {
+        const int4 t = *reinterpret_cast<const int4*>(cnt + i + q);
+        v[q] = t.x; v[q + 1] = t.y; v[q + 2] = t.z; v[q + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < PER; ++q) v[q] = i + q < n ? cnt[i + q] : 0;
+    }
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) mine += v[q];
     int s = mine;
     for (int off = 1; off < 64; off <<= 1) {
       const int t = __shfl_up(s, off);
@@ -648,10 +677,19 @@ __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int* __restr
     for (int w = 0; w < wave; ++w) wave_off += wave_sum[w];
     const int carry = carry_s;
     int run = carry + wave_off + s - mine;
+    if (vec && i + PER <= n) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (i + q < n) ptr[i + q] = run;
-      run += v[q];
+      for (int q = 0; q < PER; q += 4) {
+        int4 o;
+        o.x = run; run += v[q]; o.y = run; run += v[q + 1]; o.z = run; run += v[q + 2]; o.w = run; run += v[q + 3];
+        *reinterpret_cast<int4*>(ptr + i + q) = o;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        if (i + q < n) ptr[i + q] = run;
+        run += v[q];
+      }
     }
     __syncthreads();
     if (threadIdx.x == 1023) carry_s = run;
@@ -860,8 +898,7 @@ int nbd_radius_cached_search_f32(const float* pos, int n, float radius_sq, float
   radius_stream_kernel<false><<<ceil_div(waves, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
       pos, n, wide_radius_sq, 1, wide_cap, nullptr, nullptr, p.slices, p.slice_len, tmp_list, tmp_cnt, flags);
   radius_merge_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(
-      tmp_list, tmp_cnt, n, p.slices, wide_cap, wnbr, wdeg, wlast, nullptr, flags);
-  radius_snapshot_kernel<<<ceil_div(3 * n, 256), 256, 0, st>>>(pos, ref, n, flags);
+      tmp_list, tmp_cnt, n, p.slices, wide_cap, wnbr, wdeg, wlast, nullptr, flags, pos, ref, flags);
   int rc = status();
   if (rc) return rc;
   radius_refresh_kernel<<<ceil_div(n, kWavesPerBlock), 64 * kWavesPerBlock, 0, st>>>(

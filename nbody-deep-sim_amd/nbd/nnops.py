@@ -232,12 +232,21 @@ def contconv_pairs_batch(pos, rowptr, centres, edge_capacity: int, radius_sq: fl
     return [(b, edge_capacity) for b in bufs]
 
 
+def contconv_pairs_inv_degree(pair_buf, n: int, edge_capacity: int, n_cells: int) -> torch.Tensor:
+    """float32 [n] view into the pair-list buffer: 1 / max(in-degree, 1), the mean aggregation's row scale, which the
+    pair kernel writes as a by-product (no degree_scale launch)."""
+    L = _lib.lib()
+    off = (ctypes.c_size_t * 9)()
+    _lib.check(L.nbd_contconv_pairs_layout(int(n), int(edge_capacity), int(n_cells), off), "nbd_contconv_pairs_layout")
+    return pair_buf[off[8]:off[8] + 4 * n].view(torch.float32)
+
+
 def contconv_pairs_stats(pair_buf, n: int, edge_capacity: int, n_cells: int) -> dict:
     """{"steps": 16-row MFMA steps the fused kernel will run over this graph, "cost": the weight its workgroup split
     balances (sum over steps of max(96, pairs))} -- one host read-back: for reports (bench.py's executed-flop figure),
     not for the rollout loop."""
     L = _lib.lib()
-    off = (ctypes.c_size_t * 8)()
+    off = (ctypes.c_size_t * 9)()
     _lib.check(L.nbd_contconv_pairs_layout(int(n), int(edge_capacity), int(n_cells), off), "nbd_contconv_pairs_layout")
     tiles = (n + 127) // 128
     steps = pair_buf[off[5]:off[5] + 4 * tiles].view(torch.int32).sum()
