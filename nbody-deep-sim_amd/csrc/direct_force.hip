@@ -126,28 +126,10 @@ __device__ __forceinline__ void interact_block(const f4* __restrict__ buf, const
 // Wave jw = blockIdx.y*4 + w handles the logical source chunks [jw*q + min(jw, r), ... + q (+1 if jw < r)):
 // all chunks are spread over all waves to within one chunk (no idle tail waves).
 // KU = 8: 90 VGPRs, 5 waves/SIMD. KU = 4: capped at 64 VGPRs, 8 waves/SIMD.
-// Optional epilogue of a force launch (the range-sharded step's remote block): the workgroup that stores the LAST slab
-// of a target group sums all slabs of that group -- in finish_kernel's fixed association, so the result does not
-// depend on which workgroup it is -- and applies acc = g * sum and the second kick. One launch and its ~5 us of
-// latency less per rank step. counters[group] counts the slabs stored; it is zeroed by the launch BEFORE this one on the
-// same workspace (the own-bodies block, zero_counters = 1), never by this launch.
-struct Fin {
-  int* counters;
-  int zero_counters;
-  const float* slabs;
-  int n_slabs;
-  size_t stride;
-  float g;
-  float* acc;
-  float* vel;
-  float c_kick;
-};
-
 template <bool MASKED, int KU>
 __global__ __launch_bounds__(64 * kWaves, KU == 4 ? 8 : 5) void accel_kernel(
     const f4* __restrict__ src, const SrcView sv, const f4* __restrict__ tgt,
-    int n_tgt, int tgt_off, float eps2, float scale, float* __restrict__ out, const Fin fin) {
-  if (fin.zero_counters && blockIdx.y == 0 && threadIdx.x == 0) fin.counters[blockIdx.x] = 0;
+    int n_tgt, int tgt_off, float eps2, float scale, float* __restrict__ out) {
   // [wave][buffer][64] staging + [wave][6][64] partials, ONE object (keeps hipcc's waits sane)
   __shared__ f4 lds[kWaves * 2 * kChunk + kWaves * 6 * 64 / 4];
   const int lane = threadIdx.x & 63;
@@ -206,24 +188,6 @@ __global__ __launch_bounds__(64 * kWaves, KU == 4 ? 8 : 5) void accel_kernel(
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) sum += red[w * 6 * 64 + idx];
     dst[o] = __fmul_rn(scale, sum);
-  }
-  if (fin.acc) {
-    __shared__ int s_last;
-    __threadfence();                                   // this workgroup's slab is visible before its arrival is counted
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&fin.counters[blockIdx.x], 1) == (int)gridDim.y - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();                                   // ... and the others' slabs before they are read
-    for (int o = threadIdx.x; o < n_valid; o += 64 * kWaves) {
-      const size_t i = (size_t)t_base * 3 + o;
-      float p[4] = {0.f, 0.f, 0.f, 0.f};               // finish_kernel's association: slabs s = w (mod 4) in order, then
-      for (int sl = 0; sl < fin.n_slabs; ++sl)         // (p0 + p1) + (p2 + p3)
-        p[sl & 3] += __builtin_nontemporal_load(fin.slabs + (size_t)sl * fin.stride + i);
-      const float a = __fmul_rn(fin.g, (p[0] + p[1]) + (p[2] + p[3]));
-      fin.acc[i] = a;
-      if (fin.vel) fin.vel[i] = __fadd_rn(fin.vel[i], __fmul_rn(fin.c_kick, a));
-    }
   }
 }
 
@@ -507,14 +471,14 @@ int excluded_view(int n_src, int ex_lo, int ex_hi, SrcView* v) {
 // force into slabs (or straight into acc_out when one slab), no finishing pass
 int launch_accel(const float* posm_src, SrcView sv, const float* posm_tgt, int n_tgt, int off,
                  float eps2, float direct_scale, float* slabs_or_acc, const AccelPlan& p,
-                 hipStream_t st, const Fin fin = Fin{nullptr, 0, nullptr, 0, 0, 0.f, nullptr, nullptr, 0.f}) {
+                 hipStream_t st) {
   dim3 grid(p.groups, p.slabs), block(64 * kWaves);
   const f4* s = reinterpret_cast<const f4*>(posm_src);
   const f4* t = reinterpret_cast<const f4*>(posm_tgt);
   sv.n_chunks = p.n_chunks;
   sv.cpw_q = p.n_chunks / (p.slabs * kWaves); sv.cpw_r = p.n_chunks % (p.slabs * kWaves);
   const bool masked = eps2 < kEps2Masked;
-#define NBD_LAUNCH(M, K) accel_kernel<M, K><<<grid, block, 0, st>>>(s, sv, t, n_tgt, off, eps2, direct_scale, slabs_or_acc, fin)
+#define NBD_LAUNCH(M, K) accel_kernel<M, K><<<grid, block, 0, st>>>(s, sv, t, n_tgt, off, eps2, direct_scale, slabs_or_acc)
   if (p.variant == 1) { if (masked) NBD_LAUNCH(true, 4); else NBD_LAUNCH(false, 4); }
   else                { if (masked) NBD_LAUNCH(true, 8); else NBD_LAUNCH(false, 8); }
 #undef NBD_LAUNCH
@@ -663,10 +627,6 @@ ShardPlan plan_shard(int n_total, int lo, int n_local) {
   return m.sp;
 }
 
-static size_t shard_slab_bytes(const ShardPlan& sp, int n_local) {
-  return (((size_t)(sp.local.slabs + sp.remote.slabs) * n_local * 3 * sizeof(float)) + 15) & ~(size_t)15;
-}
-
 int nbd_shard_plan(int n_total, int lo, int n_local, int* slabs_local, int* cpw_local, int* slabs_remote,
                    int* cpw_remote) {
   if (n_total <= 0 || lo < 0 || n_local <= 0 || lo + n_local > n_total) return NBD_E_BADARG;
@@ -681,8 +641,7 @@ int nbd_shard_plan(int n_total, int lo, int n_local, int* slabs_local, int* cpw_
 size_t nbd_shard_workspace_bytes(int n_total, int lo, int n_local) {
   if (n_total <= 0 || lo < 0 || n_local <= 0 || lo + n_local > n_total) return 0;
   const ShardPlan sp = plan_shard(n_total, lo, n_local);
-  // [slabs of the own-bodies block | slabs of the remote block | one arrival counter per target group of 128]
-  return shard_slab_bytes(sp, n_local) + (size_t)ceil_div(n_local, kTgtPerWG) * sizeof(int);
+  return (size_t)(sp.local.slabs + sp.remote.slabs) * n_local * 3 * sizeof(float);
 }
 
 int nbd_shard_force_local_f32(const float* posm_local, int n_local, float softening_sq, void* workspace,
@@ -692,12 +651,9 @@ int nbd_shard_force_local_f32(const float* posm_local, int n_local, float soften
   if (!posm_local || misaligned16(posm_local)) return NBD_E_BADARG;
   if (!workspace || workspace_bytes < nbd_shard_workspace_bytes(n_total, lo, n_local)) return NBD_E_WORKSPACE;
   const ShardPlan sp = plan_shard(n_total, lo, n_local);
-  // targets and sources are the same array: the diagonal is at j == i (offset 0). This launch also zeroes the
-  // arrival counters the remote block's epilogue counts in (same target groups, next launch on this workspace).
-  Fin fin{reinterpret_cast<int*>(static_cast<char*>(workspace) + shard_slab_bytes(sp, n_local)), 1, nullptr, 0, 0, 0.f,
-          nullptr, nullptr, 0.f};
+  // targets and sources are the same array: the diagonal is at j == i (offset 0)
   return launch_accel(posm_local, full_view(n_local, sp.local), posm_local, n_local, 0, softening_sq, 1.0f,
-                      static_cast<float*>(workspace), sp.local, (hipStream_t)stream, fin);
+                      static_cast<float*>(workspace), sp.local, (hipStream_t)stream);
 }
 
 int nbd_shard_force_remote_f32(const float* posm_all, int n_total, const float* posm_local, int n_local, int lo,
@@ -715,11 +671,9 @@ int nbd_shard_force_remote_f32(const float* posm_all, int n_total, const float* 
     SrcView sv;
     excluded_view(n_total, lo, lo + n_local, &sv);
     // the diagonal never occurs here (every j in [lo, lo + n_local) is excluded); lo keeps the index meaning
-    // slab sum + acc = G * sum + second kick in the epilogue of the workgroup that stores a target group's last slab
-    Fin fin{reinterpret_cast<int*>(static_cast<char*>(workspace) + shard_slab_bytes(sp, n_local)), 0, slabs,
-            sp.local.slabs + sp.remote.slabs, (size_t)n3, g_const, acc_out, vel, c_kick};
-    return launch_accel(posm_all, sv, posm_local, n_local, lo, softening_sq, 1.0f,
-                        slabs + (size_t)sp.local.slabs * n3, sp.remote, st, fin);
+    int rc = launch_accel(posm_all, sv, posm_local, n_local, lo, softening_sq, 1.0f,
+                          slabs + (size_t)sp.local.slabs * n3, sp.remote, st);
+    if (rc) return rc;
   }
   finish_kernel<<<ceil_div(n3, 64), 256, 0, st>>>(slabs, sp.local.slabs + sp.remote.slabs, (size_t)n3, g_const,
                                                    acc_out, vel, c_kick, n3);
