@@ -675,6 +675,9 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
           rs1 = A.pair_src[at1]; rw1 = A.pair_w[at1];
         }
         __builtin_amdgcn_wave_barrier();
+#if defined(NBD_CC_ABL) && NBD_CC_ABL == 2          /* timing only: every row from a 64 KiB table (L1 / L2 hits) */
+        rs0 &= 127; rs1 &= 127;
+#endif
         my_scr[lane] = make_int2((int)((unsigned)rs0 * ldb), PB * b0 + lane < np ? __float_as_int(rw0) : 0);
         my_scr[64 + lane] = make_int2((int)((unsigned)rs1 * ldb), PB * b0 + 64 + lane < np ? __float_as_int(rw1) : 0);
         __builtin_amdgcn_wave_barrier();

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round-3 evidence in one gpurun call (output under gpurun_out/r03f_*; the summaries are copied into profiles/ by hand):
+#   headline bench line; kernel trace of the same command; ContinuousConv layer timings, counters and rollout trace.
+R=$GRAFT_REPO_ROOT
+cd $R
+python bench.py --steps 20 --warmup 5 > gpurun_out/r03f_bench_n1.json 2> gpurun_out/r03f_bench_n1.err
+echo bench done
+python tools/bench_contconv.py 20 > gpurun_out/r03f_contconv_layers.json 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03f_prof_bench -o run -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-surrogates > $R/gpurun_out/r03f_prof_bench.log 2>&1
+echo bench trace done
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03f_prof_cc -o run -- python3 $R/tools/cc_rollout.py 100 > $R/gpurun_out/r03f_prof_cc.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03f_prof_gnn -o run -- python3 $R/tools/bench_gnn.py 50 > $R/gpurun_out/r03f_prof_gnn.log 2>&1
+echo traces done
+cd $R
+tools/pmc_run.sh r03f_pmc_cc -- python3 $R/tools/bench_contconv.py 4
+tools/pmc_lds.sh r03f_pmclds_cc -- python3 $R/tools/bench_contconv.py 4
+python tools/summarize_pmc_kernels.py "gpurun_out/r03f_pmc" gpurun_out/r03f_pmc_cc_summary.json contconv_stream_kernel contconv_pairs contconv_stream_finish > /dev/null
+for t in bench cc gnn; do
+  f=$(find gpurun_out/r03f_prof_$t -name "*kernel_trace.csv" | head -1)
+  python tools/summarize_trace.py $f gpurun_out/r03f_${t}_trace_summary.json > /dev/null
+  cp $(find gpurun_out/r03f_prof_$t -name "*kernel_stats.csv" | head -1) gpurun_out/r03f_${t}_kernel_stats.csv
+done
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r03f_pmc_cc_summary.json"))
+for k, v in d.items():
+    print(k[:70], v.get("mean_seconds_in_pmc_passes"), {a: v["derived"].get(a) for a in ("mfma_pipe_busy_frac", "valu_issue_busy_frac", "effective_clock_GHz")})
+b = json.loads(open("gpurun_out/r03f_bench_n1.json").read().strip().splitlines()[-1])
+print({k: b[k] for k in ("value", "ms_per_step", "repeats")}, b["roofline"]["frac"])
+print(json.dumps(b["secondary"]["contconv_n16384"])[:600])
+PY
