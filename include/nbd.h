@@ -427,8 +427,9 @@ int nbd_layernorm_bwd_f32(const float* x, int ldx, int c, const float* gamma, fl
 
 /* ---- ContinuousConv.forward (contconv.py:80-98), block-sparse and fused: only the (node, filter cell) blocks
  * some edge touches are multiplied, and the binned features never reach HBM (csrc/contconv_fused.hip).
- * Inference path for in_channels % 4 == 0, in_channels <= 128 (nbd_contconv_fused_supported); other shapes and
- * the training path use nbd_contconv_bin_f32 + nbd_linear_f32.
+ * For in_channels % 4 == 0, in_channels <= 128 (nbd_contconv_fused_supported), inference and training alike (the
+ * backward pass: nbd_contconv_pairs_jobs_f32 + nbd_contconv_filter_grad_f32 below); other shapes use
+ * nbd_contconv_bin_f32 + nbd_linear_f32.
  *
  * nbd_contconv_pairs_f32: the per-(tile of NBD_CC_TILE nodes, cell) lists of (edge corner) pairs {source node,
  *   window * trilinear weight}, grouped by node -- geometry of contconv.py:84-90 evaluated once per edge and
@@ -453,6 +454,33 @@ int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int*
                                  float radius_sq, int n_res, const int* filter_resolutions, const int* const* cell_maps,
                                  const int* n_cells, void* const* pair_lists, const size_t* pair_lists_bytes,
                                  nbd_stream_t stream);
+/* The general form: up to NBD_CC_MAX_RES pair-list jobs over the same n nodes in ONE launch, each with its own
+ * grouping of the edges -- what a training step needs (contconv.py:236-247): the FORWARD lists (rows = aggregation
+ * targets edge_index[0], listed nodes = feature sources edge_index[1]) and the ADJOINT lists (rows = feature sources,
+ * listed nodes = aggregation targets; adjoint = 1 negates the relative position, which is exact, so an edge gets
+ * bit-identical cells and weights in both groupings). With the adjoint lists the gradient with respect to the
+ * features is the forward kernel itself: dfeat = nbd_contconv_fused_f32(g, adjoint lists, filters transposed per
+ * cell), g = scale * act'(out) * dout. rowptr [n + 1] gives every row's first edge; deg NULL = rows end where the next
+ * begins (CSR), else rows are padded (ELL: rowptr[i] = i * cap, deg[i] valid entries -- the radius search's own
+ * per-centre lists, unchanged). */
+typedef struct nbd_cc_pairs_job {
+  const int* rowptr; const int* centres; const int* deg;
+  int64_t edge_capacity;
+  int filter_resolution; const int* cell_map; int n_cells;
+  int adjoint;
+  void* pair_lists; size_t pair_lists_bytes;
+} nbd_cc_pairs_job;
+int nbd_contconv_pairs_jobs_f32(const float* pos, int n, float radius_sq, int n_jobs, const nbd_cc_pairs_job* jobs,
+                                nbd_stream_t stream);
+/* Gradient of ContinuousConv.forward with respect to `filters` (contconv.py:92-98 under loss.backward()) over the
+ * forward pair lists: dfilters[cell][i][o] = sum over the touched (node, cell) blocks of A[node][cell][i] * g[node][o]
+ * (cells = the n_cells kept ones, compact order; row-major in x out per cell). fp32 MFMA, the binned matrix is not
+ * formed, partial sums per slab of tiles added in fixed order: deterministic. in_channels even, <= 128;
+ * out_channels <= 128. */
+size_t nbd_contconv_filter_grad_workspace_bytes(int n, int n_cells, int in_channels, int out_channels);
+int nbd_contconv_filter_grad_f32(const float* feat, int ldf, int in_channels, const float* g, int ldg, int out_channels,
+                                 const int* rowptr, int n, int64_t edge_capacity, const void* pair_lists, int n_cells,
+                                 float* dfilters, void* workspace, size_t workspace_bytes, nbd_stream_t stream);
 /* Byte offsets of the sections of a pair-list buffer (for reports and tests; the layout is otherwise opaque):
  * [0] per-(tile, cell) descriptors, [1] rows, [2] pair sources, [3] pair weights, [4] step records (int4 per 16-row
  * step), [5] steps per tile (int32 [tiles], tiles = ceil(n / NBD_CC_TILE)), [6] cost per tile (int32 [tiles]),

@@ -81,12 +81,20 @@ class ContinuousConv(nn.Module):
 
     use_fused = True         # block-sparse fused kernels (csrc/contconv_fused.hip) where the shape allows
 
+    def trains_fused(self) -> bool:
+        """Whether the training step of this layer runs on the pair lists (forward, filter gradient, feature gradient --
+        the last is the forward kernel with in / out channels swapped, hence the second shape check)."""
+        k = self.cells()[2]
+        return (self.fused_ok() and self.in_channels <= 128 and self.out_channels <= 128 and
+                nnops.contconv_fused_supported(self.out_channels, self.in_channels, k))
+
     def forward(self, positions, features, edge_index=None, lists=None, act=None, out=None, wt=None, pairs=None,
-                scale=None):
+                scale=None, graph=None):
         """contconv.py:80-98. Give either the sync-free `lists` (graphops.radius_lists) or a PyG-style
         edge_index [2,E] (row 0 = aggregation target, row 1 = feature source). `pairs`: the pair lists of
         this graph and filter resolution when the caller already has them (layers of one model that share D);
-        `scale`: the 1/in-degree row scale of mean aggregation when the caller already has it."""
+        `scale`: the 1/in-degree row scale of mean aggregation when the caller already has it; `graph`: the
+        ag.ConvGraph of this forward pass when the caller built one for all its layers (training)."""
         n = positions.shape[0]
         if lists is not None:
             rowptr, centres = lists.rowptr, lists.centres
@@ -103,19 +111,32 @@ class ContinuousConv(nn.Module):
             return self._forward_extreme(positions, features, rowptr, centres, act, out)
         if self.agg != "mean":
             scale = None
-        elif scale is None:
+        training_path = torch.is_grad_enabled() and (self.filters.requires_grad or features.requires_grad)
+        if self.agg == "mean" and scale is None and not training_path:
             scale = nnops.degree_scale(rowptr, n, 0, positions.device)
         if torch.is_grad_enabled() and (self.filters.requires_grad or features.requires_grad):
+            if out is not None:
+                raise NbdError("ContinuousConv.forward: out= is an inference-only option")
+            if self.trains_fused() and n > 0:
+                # forward AND backward on the pair lists (ag.ContConvFusedFn): A is formed in neither
+                if graph is None:
+                    graph = (ag.ConvGraph.from_lists(positions.contiguous(), r2, lists) if lists is not None else
+                             ag.ConvGraph.from_edge_index(positions.contiguous(), r2, rowptr, centres, edge_index))
+                if self.agg == "mean" and scale is None:
+                    _, cmap, n_cells = self.cells()
+                    pb, cap_e = graph.pairs(self.filter_resolution, cmap, n_cells)
+                    scale = nnops.contconv_pairs_inv_degree(pb, n, cap_e, n_cells)
+                return ag.ContConvFusedFn.apply(features, self.filters, graph, self.filter_resolution, scale, act,
+                                                self.cells())
+            if self.agg == "mean" and scale is None:
+                scale = nnops.degree_scale(rowptr, n, 0, positions.device)
             if lists is not None:            # the radius search's per-centre lists ARE the by-source grouping
                 bwd = dict(tgt_s=lists.nbr, deg=lists.deg, cap=lists.nbr.shape[1])
             else:
                 rp, tg = graphops.csr_by_key(edge_index[1], edge_index[0], n)
                 bwd = dict(rowptr_s=rp, tgt_s=tg if tg.numel() else torch.zeros(1, dtype=torch.int32, device=tg.device))
-            res = ag.ContConvFn.apply(features, self.filters, positions.contiguous(), (rowptr, centres), bwd,
-                                      self.filter_resolution, r2, scale, act, self.cells())
-            if out is not None:
-                raise NbdError("ContinuousConv.forward: out= is an inference-only option")
-            return res
+            return ag.ContConvFn.apply(features, self.filters, positions.contiguous(), (rowptr, centres), bwd,
+                                       self.filter_resolution, r2, scale, act, self.cells())
         if self.fused_ok() and n > 0:
             # block-sparse path: pair lists -> fused gather + MFMA + per-node accumulation; A stays on chip
             _, cmap, n_cells = self.cells()
@@ -427,8 +448,22 @@ class ContinuousConvModel(nn.Module):
                                       max_num_neighbors=self.max_num_neighbors)
         enc = self._encoder_autograd(x) if isinstance(self.node_encoder, MLP) else x
         h = enc
+        # one graph object for all layers: forward lists of every resolution and the adjoint lists of the layers whose
+        # input carries a gradient, four jobs per launch
+        graph = None
+        if x7.shape[0] > 0 and any(l.trains_fused() and l.agg not in ("max", "min") for l in self.contconv):
+            graph = ag.ConvGraph.from_lists(pos, float(np.float32(self.radius ** 2)), lists)
+            wants, needs_grad = [], enc.requires_grad
+            for layer in self.contconv:
+                if layer.trains_fused() and layer.agg not in ("max", "min"):
+                    _, cmap, n_cells = layer.cells()
+                    wants.append((layer.filter_resolution, cmap, n_cells, False))
+                    if needs_grad:
+                        wants.append((layer.filter_resolution, cmap, n_cells, True))
+                needs_grad = True
+            graph.prebuild(wants)
         for layer in self.contconv:
-            h = layer(pos, h, lists=lists, act="tanh")
+            h = layer(pos, h, lists=lists, act="tanh", graph=graph if layer.agg not in ("max", "min") else None)
             if self.training and self.continuous_conv_dropout > 0:
                 h = torch.nn.functional.dropout(h, p=self.continuous_conv_dropout, training=True)
         z = ag.LayerNormFn.apply(torch.cat((enc, h), dim=-1), self.layer_norm.weight, self.layer_norm.bias,

@@ -79,10 +79,14 @@ struct Geo { int ix, iy, iz; float tx, ty, tz, window; };
 
 // window, ball_to_cube and trilinear coordinates of one edge (contconv.py:30-33,84-90); same arithmetic as
 // nn.hip's edge_geometry (the binning kernel the training path still uses)
+// sign = +1: rows are aggregation targets, the listed node c is the feature source (the forward lists);
+// sign = -1: rows are feature sources and c the aggregation target (the adjoint lists of the backward pass): the
+// same edge, the same relative position pos[source] - pos[target] -- negation is exact, so both groupings see
+// bit-identical cells and weights.
 __device__ __forceinline__ Geo edge_geo(const float* __restrict__ pos, int c, float xn, float yn, float zn, float r2max,
-                                        float half) {
+                                        float half, float sign = 1.0f) {
   Geo g;
-  const float rx = pos[3 * c] - xn, ry = pos[3 * c + 1] - yn, rz = pos[3 * c + 2] - zn;   // pos[col] - pos[row]
+  const float rx = sign * (pos[3 * c] - xn), ry = sign * (pos[3 * c + 1] - yn), rz = sign * (pos[3 * c + 2] - zn);   // pos[col] - pos[row]
   const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz));
   const float qq = 1.0f - d2 / r2max;
   g.window = (d2 < r2max) ? qq * qq * qq : 0.f;
@@ -140,6 +144,10 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 // pairs at 8 e_t: an edge has at most 8 corners, so the bases need no scan across tiles.
 struct PairJob {
   int D, n_cells;
+  const int* rowptr;    // [n + 1] first edge of every row ...
+  const int* centres;   // ... and the node each edge lists
+  const int* deg;       // NULL: a row ends where the next begins (CSR); else padded rows (ELL), deg[i] entries valid
+  float sign;           // +1 forward lists, -1 adjoint lists (see edge_geo)
   const int* cell_map;
   int2 *desc, *rows;
   int* pair_src;        // [8 * edge_capacity] source node of every (edge, corner) pair ...
@@ -161,11 +169,13 @@ __device__ long long* g_pairs_trace = nullptr;
 constexpr int PAIR_THREADS = 1024;
 constexpr int SEG = 16, NSEG = TN / SEG;                   // node segments of the two-level scan
 __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
-    const float* __restrict__ pos, const int* __restrict__ rowptr, const int* __restrict__ centres, int n, float r2max,
-    const PairJobs jobs) {
+    const float* __restrict__ pos, int n, float r2max, const PairJobs jobs) {
   extern __shared__ unsigned smem[];
   const PairJob& job = jobs.j[blockIdx.y];
   const int D = job.D, n_cells = job.n_cells;
+  const int* __restrict__ rowptr = job.rowptr;
+  const int* __restrict__ centres = job.centres;
+  const float sign = job.sign;
   int2* __restrict__ desc = job.desc;
   int2* __restrict__ rows = job.rows;
   int* __restrict__ psrc = job.pair_src;
@@ -177,6 +187,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   __shared__ int cell_rows[MAXC], cell_pairs[MAXC], cell_rowbase[MAXC], cell_pairbase[MAXC], cell_stepbase[MAXC];
   __shared__ int seg_pairs[NSEG][MAXC], seg_rows[NSEG][MAXC];
   __shared__ int rp[TN + 1];
+  __shared__ int rdeg[TN];                                  // edges of every row (CSR: rp[i + 1] - rp[i]; ELL: deg[i])
   __shared__ int cmap[216];                                 // D <= 6
   __shared__ int next_node, s_tile_steps, s_over;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -193,10 +204,14 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   // row can only overflow one with more than 65 535 edges (a hub of a > 65 536-body clump under the search's "first 32
   // by index" rule): such a tile is marked instead of counted wrongly -- tile_nsteps = -1, which the fused kernel skips
   // and the finishing kernel turns into NaN outputs for the tile's nodes. Loud, not silent.
-  if (tid < n_here && rp[tid + 1] - rp[tid] > 65535) s_over = 1;
-  if (tid < n_here) job.inv_deg[n0 + tid] = 1.0f / (float)max(rp[tid + 1] - rp[tid], 1);      // = nbd_degree_scale_f32 mode 0
+  if (tid < n_here) {
+    const int dg = job.deg ? job.deg[n0 + tid] : rp[tid + 1] - rp[tid];
+    rdeg[tid] = dg;
+    if (dg > 65535) s_over = 1;
+    job.inv_deg[n0 + tid] = 1.0f / (float)max(dg, 1);      // = nbd_degree_scale_f32 mode 0
+  }
   __syncthreads();
-  const int e_t = rp[0], e_end = s_over ? rp[0] : rp[n_here];
+  const int e_t = rp[0], e_end = s_over ? rp[0] : rp[n_here - 1] + rdeg[n_here - 1];
   const size_t row_base = (size_t)8 * e_t + tile, pair_base = (size_t)8 * e_t;
   int4* __restrict__ t_steps = job.steps + step_base(tile, e_t, n_cells);
 
@@ -206,7 +221,8 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
     int lo = 0, hi = n_here;                               // largest nl with rp[nl] <= e
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rp[mid] <= e) lo = mid; else hi = mid; }
     const int nl = lo, node = n0 + nl;
-    const Geo g = edge_geo(pos, centres[e], pos[3 * node], pos[3 * node + 1], pos[3 * node + 2], r2max, half);
+    if (e - rp[nl] >= rdeg[nl]) continue;                  // padding of an ELL row
+    const Geo g = edge_geo(pos, centres[e], pos[3 * node], pos[3 * node + 1], pos[3 * node + 2], r2max, half, sign);
     if (g.window == 0.f) continue;                         // outside the radius: the reference multiplies by 0
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner) {
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
     if (nl >= n_here || s_over) break;
     const int node = n0 + nl;
     const float xn = pos[3 * node], yn = pos[3 * node + 1], zn = pos[3 * node + 2];
-    const int e0 = rp[nl], e1 = rp[nl + 1];
+    const int e0 = rp[nl], e1 = e0 + rdeg[nl];
     // the source of the NEXT trip is fetched before this trip's counters and stores (a dense tile's nodes have
     // ~200 edges: seven trips per node, each otherwise paying centres -> pos -> store in sequence)
     int c = (e0 + hl < e1) ? centres[e0 + hl] : 0;
@@ -324,7 +340,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
       const float sx = px, sy = py, sz = pz;
       if (e + 32 < e1) { c = centres[e + 32]; px = pos[3 * c]; py = pos[3 * c + 1]; pz = pos[3 * c + 2]; }
       const float src[3] = {sx, sy, sz};
-      const Geo g = edge_geo(src, 0, xn, yn, zn, r2max, half);
+      const Geo g = edge_geo(src, 0, xn, yn, zn, r2max, half, sign);
       if (g.window == 0.f) continue;
       // the eight counters are decremented by eight UNCONDITIONAL returning atomics issued together (a corner that
       // falls outside subtracts 0 from cell 0's word), then the eight stores: with `if (k < 0) continue` in front of
@@ -1122,6 +1138,162 @@ __global__ __launch_bounds__(256) void contconv_stream_finish_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- filter gradient
+// dF[k][i][o] = sum over the touched blocks (node n, cell k) of A[n][k][i] * g[n][o], A[n][k] = the block's weighted
+// sum of gathered feature rows exactly as the forward kernel forms it, g = scale * act'(out) * dout (contconv.py:92-98
+// differentiated with respect to `filters`). The binned matrix is not formed here either.
+// grid (cells, slabs of tiles), 256 threads. A workgroup walks the rows of ITS cell through its slab's tiles, 16 at a
+// time -- rows of different tiles share a step (the contraction runs over rows: no padding but the last step's) --
+// and per step the four waves build the 16 A rows and copy the 16 g rows into LDS (double-buffered: one barrier per
+// step), then multiply A^T (I x 16) by g (16 x O) with v_mfma_f32_16x16x4_f32; wave w keeps the 4 x 4 blocks of
+// 16 x 16 of quadrant w of the I x O result in registers for the whole walk. One partial sum per slab, added in slab
+// order by the finishing kernel: deterministic, no float atomics.
+constexpr int WG_LD = 144;       // LDS row stride (floats): the four k-rows a fragment read touches land on distinct banks
+constexpr int WG_MAXT = 64;      // tiles per slab (one wave scans their row counts)
+
+struct WGArgs {
+  const float* feat; int ldf, I; const float* g; int ldg, O;
+  const int* rowptr; int n, n_tiles, n_cells, tiles_per_slab;
+  const int2* desc; const int2* rows; const int* pair_src; const float* pair_w; const int* tile_nsteps;
+  float* partial;              // [slabs][cells][I][O]
+};
+
+__global__ __launch_bounds__(256) void contconv_wgrad_kernel(const WGArgs A) {
+  __shared__ __attribute__((aligned(16))) float a_s[2][16][WG_LD];
+  __shared__ __attribute__((aligned(16))) float g_s[2][16][WG_LD];
+  __shared__ int t_pref[WG_MAXT + 1], t_row0[WG_MAXT];
+  __shared__ long long t_e8[WG_MAXT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = UNI(tid >> 6);
+  const int k = blockIdx.x, slab = blockIdx.y;
+  const int t0 = slab * A.tiles_per_slab, nt = min(A.tiles_per_slab, A.n_tiles - t0);
+  const int I = A.I, O = A.O;
+  if (wave == 0) {
+    const int t = t0 + lane;
+    int cnt = 0, row0 = 0;
+    long long e8 = 0;
+    if (lane < nt && A.tile_nsteps[t] >= 0) {              // -1: a tile the pair kernel refused (see there)
+      const int2 d = A.desc[(size_t)t * A.n_cells + k];
+      row0 = d.x; cnt = d.y;
+      e8 = (long long)8 * A.rowptr[t * TN];
+    }
+    const int incl = wave_incl_scan(cnt, lane);
+    t_pref[lane + 1] = incl;
+    if (lane == 0) t_pref[0] = 0;
+    t_row0[lane] = row0; t_e8[lane] = e8;
+  }
+  __syncthreads();
+  const int R = t_pref[nt], nsteps = (R + 15) >> 4;
+  const bool live = 2 * lane < I;
+  const int fo = min(2 * lane, I - 2);
+
+  auto gather = [&](int s, int buf) {
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = wave * 4 + rr, q = 16 * s + r;
+      f2 acc = {0.f, 0.f};
+      float g0 = 0.f, g1 = 0.f;
+      if (q < R) {                                         // wave-uniform
+        int j = 0;
+        while (j + 1 < nt && t_pref[j + 1] <= q) ++j;      // the tile of row q (LDS broadcasts)
+        j = UNI(j);
+        const int tile = t0 + j;
+        const long long e8 = t_e8[j];
+        const int2* rw = A.rows + e8 + tile + t_row0[j] + (q - t_pref[j]);
+        const int2 rec = uni2(rw[0]);
+        const int p1 = UNI(rw[1].y);
+        const int node = tile * TN + rec.x;
+        const int* ps = A.pair_src + e8;
+        const float* pw = A.pair_w + e8;
+        int p = rec.y;
+        for (; p + 4 <= p1; p += 4) {
+          int sidx[4]; float wv[4]; f2 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { sidx[u] = UNI(ps[p + u]); wv[u] = __int_as_float(UNI(__float_as_int(pw[p + u]))); }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f2*>(A.feat + (size_t)sidx[u] * A.ldf + fo);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc = __builtin_elementwise_fma(f2{wv[u], wv[u]}, v[u], acc);
+        }
+        for (; p < p1; ++p) {
+          const int si = UNI(ps[p]);
+          const float w = __int_as_float(UNI(__float_as_int(pw[p])));
+          acc = __builtin_elementwise_fma(f2{w, w}, *reinterpret_cast<const f2*>(A.feat + (size_t)si * A.ldf + fo), acc);
+        }
+        const float* gr = A.g + (size_t)node * A.ldg;
+        g0 = lane < O ? gr[lane] : 0.f;
+        g1 = lane + 64 < O ? gr[lane + 64] : 0.f;
+      }
+      *reinterpret_cast<f2*>(&a_s[buf][r][2 * lane]) = live ? acc : f2{0.f, 0.f};
+      g_s[buf][r][lane] = g0; g_s[buf][r][lane + 64] = g1;
+    }
+  };
+
+  const int ib0 = (wave >> 1) * 4, ob0 = (wave & 1) * 4;
+  const int IB = (I + 15) >> 4, OB = (O + 15) >> 4;
+  f4v acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = f4v{0.f, 0.f, 0.f, 0.f};
+  if (nsteps > 0) gather(0, 0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) gather(s + 1, buf ^ 1);
+    if (ib0 < IB && ob0 < OB) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int kr = kk * 4 + (lane >> 4), c = lane & 15;
+        float av[4], bv[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) av[x] = a_s[buf][kr][min(ib0 + x, 7) * 16 + c];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) bv[y] = g_s[buf][kr][min(ob0 + y, 7) * 16 + c];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int y = 0; y < 4; ++y)
+            if (ib0 + x < IB && ob0 + y < OB)            // wave-uniform
+              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  float* dst = A.partial + ((size_t)slab * A.n_cells + k) * (size_t)I * O;
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      if (ib0 + x >= IB || ob0 + y >= OB) continue;
+      const int o = (ob0 + y) * 16 + (lane & 15);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int i = (ib0 + x) * 16 + 4 * (lane >> 4) + v;
+        if (i < I && o < O) dst[(size_t)i * O + o] = acc[x][y][v];
+      }
+    }
+}
+
+// dfilters[e] = sum over slabs, in slab order
+__global__ __launch_bounds__(256) void contconv_wgrad_finish_kernel(const float* __restrict__ partial, int slabs, size_t per_slab,
+                                                                    float* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= per_slab) return;
+  float v = slabs > 0 ? partial[e] : 0.f;                  // no slabs (no nodes): the gradient is zero
+  for (int s = 1; s < slabs; ++s) v += partial[(size_t)s * per_slab + e];
+  out[e] = v;
+}
+
+inline void wgrad_plan(int n, int n_cells, int* slabs, int* tiles_per_slab) {
+  const int tiles = ceil_div(n, TN);
+  int S = tiles < ceil_div(1024, n_cells) ? tiles : ceil_div(1024, n_cells);
+  int tps = ceil_div(tiles, S);
+  if (tps > WG_MAXT) tps = WG_MAXT;
+  *tiles_per_slab = tps;
+  *slabs = ceil_div(tiles, tps);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1172,27 +1344,27 @@ int nbd_contconv_pairs_layout(int n, int64_t edge_capacity, int n_cells, size_t*
   return 0;
 }
 
-int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int* centres, int n, int64_t edge_capacity,
-                                 float radius_sq, int n_res, const int* filter_resolutions, const int* const* cell_maps,
-                                 const int* n_cells, void* const* pair_lists, const size_t* pair_lists_bytes,
-                                 nbd_stream_t stream) {
-  if (n < 0 || edge_capacity < 0 || n_res < 1 || n_res > NBD_CC_MAX_RES) return NBD_E_BADARG;
-  if (!filter_resolutions || !cell_maps || !n_cells || !pair_lists || !pair_lists_bytes) return NBD_E_BADARG;
+int nbd_contconv_pairs_jobs_f32(const float* pos, int n, float radius_sq, int n_jobs, const nbd_cc_pairs_job* jd,
+                                nbd_stream_t stream) {
+  if (n < 0 || n_jobs < 1 || n_jobs > NBD_CC_MAX_RES || !jd) return NBD_E_BADARG;
   if (n == 0) return 0;
-  if (!pos || !rowptr || !centres) return NBD_E_BADARG;
-  if (edge_capacity > (int64_t)0x0fffffff) return NBD_E_BADARG;       // 8 x edges indexes the pair arrays as int
+  if (!pos) return NBD_E_BADARG;
   PairJobs jobs;
   int kc_max = 0;
-  for (int r = 0; r < n_res; ++r) {
-    const int d = filter_resolutions[r], nc = n_cells[r];
+  for (int r = 0; r < n_jobs; ++r) {
+    const nbd_cc_pairs_job& q = jd[r];
+    const int d = q.filter_resolution, nc = q.n_cells;
+    if (!q.rowptr || !q.centres || q.edge_capacity < 0) return NBD_E_BADARG;
+    if (q.edge_capacity > (int64_t)0x0fffffff) return NBD_E_BADARG;     // 8 x edges indexes the pair arrays as int
     if (d < 2 || d > 6 || nc <= 0 || nc > MAXC || nc > d * d * d) return NBD_E_BADARG;
-    if (!cell_maps[r] && nc != d * d * d) return NBD_E_BADARG;
-    if (!pair_lists[r] || (reinterpret_cast<uintptr_t>(pair_lists[r]) & 15) != 0) return NBD_E_BADARG;
-    if (pair_lists_bytes[r] < nbd_contconv_pairs_bytes(n, edge_capacity, nc)) return NBD_E_WORKSPACE;
+    if (!q.cell_map && nc != d * d * d) return NBD_E_BADARG;
+    if (!q.pair_lists || (reinterpret_cast<uintptr_t>(q.pair_lists) & 15) != 0) return NBD_E_BADARG;
+    if (q.pair_lists_bytes < nbd_contconv_pairs_bytes(n, q.edge_capacity, nc)) return NBD_E_WORKSPACE;
     PairJob& j = jobs.j[r];
-    j.D = d; j.n_cells = nc; j.cell_map = cell_maps[r];
-    const PairsLayout L = pairs_layout(n, edge_capacity, nc);
-    char* base = static_cast<char*>(pair_lists[r]);
+    j.D = d; j.n_cells = nc; j.cell_map = q.cell_map;
+    j.rowptr = q.rowptr; j.centres = q.centres; j.deg = q.deg; j.sign = q.adjoint ? -1.0f : 1.0f;
+    const PairsLayout L = pairs_layout(n, q.edge_capacity, nc);
+    char* base = static_cast<char*>(q.pair_lists);
     j.desc = reinterpret_cast<int2*>(base + L.desc); j.rows = reinterpret_cast<int2*>(base + L.rows);
     j.pair_src = reinterpret_cast<int*>(base + L.src); j.pair_w = reinterpret_cast<float*>(base + L.w);
     j.steps = reinterpret_cast<int4*>(base + L.steps); j.tile_nsteps = reinterpret_cast<int*>(base + L.nsteps);
@@ -1201,16 +1373,32 @@ int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int*
     const int kc = (nc + 3) & ~3;
     if (kc > kc_max) kc_max = kc;
   }
-  for (int r = n_res; r < NBD_CC_MAX_RES; ++r) jobs.j[r] = jobs.j[0];
+  for (int r = n_jobs; r < NBD_CC_MAX_RES; ++r) jobs.j[r] = jobs.j[0];
   const size_t lds = (size_t)TN * kc_max / 2 * 4 + (size_t)TN * kc_max * 4 + (size_t)TN * kc_max;
   {   // > 64 KiB of dynamic LDS needs the opt-in (a per-function attribute, idempotent)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(contconv_pairs_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
     if (e != hipSuccess) return (int)e;
   }
-  contconv_pairs_kernel<<<dim3(ceil_div(n, TN), n_res), PAIR_THREADS, lds, (hipStream_t)stream>>>(
-      pos, rowptr, centres, n, radius_sq, jobs);
+  contconv_pairs_kernel<<<dim3(ceil_div(n, TN), n_jobs), PAIR_THREADS, lds, (hipStream_t)stream>>>(pos, n, radius_sq, jobs);
   return status();
+}
+
+int nbd_contconv_pairs_batch_f32(const float* pos, const int* rowptr, const int* centres, int n, int64_t edge_capacity,
+                                 float radius_sq, int n_res, const int* filter_resolutions, const int* const* cell_maps,
+                                 const int* n_cells, void* const* pair_lists, const size_t* pair_lists_bytes,
+                                 nbd_stream_t stream) {
+  if (n < 0 || edge_capacity < 0 || n_res < 1 || n_res > NBD_CC_MAX_RES) return NBD_E_BADARG;
+  if (!filter_resolutions || !cell_maps || !n_cells || !pair_lists || !pair_lists_bytes) return NBD_E_BADARG;
+  if (n == 0) return 0;
+  if (!pos || !rowptr || !centres) return NBD_E_BADARG;
+  nbd_cc_pairs_job jd[NBD_CC_MAX_RES];
+  for (int r = 0; r < n_res; ++r) {
+    jd[r].rowptr = rowptr; jd[r].centres = centres; jd[r].deg = nullptr; jd[r].edge_capacity = edge_capacity;
+    jd[r].filter_resolution = filter_resolutions[r]; jd[r].cell_map = cell_maps[r]; jd[r].n_cells = n_cells[r];
+    jd[r].adjoint = 0; jd[r].pair_lists = pair_lists[r]; jd[r].pair_lists_bytes = pair_lists_bytes[r];
+  }
+  return nbd_contconv_pairs_jobs_f32(pos, n, radius_sq, n_res, jd, stream);
 }
 
 int nbd_contconv_pairs_f32(const float* pos, const int* rowptr, const int* centres, int n, int64_t edge_capacity,
@@ -1281,6 +1469,47 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
   if (rc) return rc;
   contconv_stream_finish_kernel<<<dim3(tiles, 4), 256, 0, st>>>(partial, tile_nsteps, cuts, tiles, CC_GRID, rowscale, act, out,
                                                                  ldo, n, out_channels, OP);
+  return status();
+}
+
+size_t nbd_contconv_filter_grad_workspace_bytes(int n, int n_cells, int in_channels, int out_channels) {
+  if (n <= 0 || n_cells <= 0 || in_channels <= 0 || out_channels <= 0) return 0;
+  int S, tps;
+  wgrad_plan(n, n_cells, &S, &tps);
+  return S > 1 ? (size_t)S * n_cells * in_channels * out_channels * sizeof(float) : 0;
+}
+
+int nbd_contconv_filter_grad_f32(const float* feat, int ldf, int in_channels, const float* g, int ldg, int out_channels,
+                                 const int* rowptr, int n, int64_t edge_capacity, const void* pair_lists, int n_cells,
+                                 float* dfilters, void* workspace, size_t workspace_bytes, nbd_stream_t stream) {
+  if (n < 0 || in_channels <= 0 || in_channels % 2 != 0 || in_channels > 128 || out_channels <= 0 || out_channels > 128 ||
+      n_cells <= 0 || n_cells > MAXC || ldf < in_channels || (ldf & 1) || ldg < out_channels)
+    return NBD_E_BADARG;
+  if (!dfilters) return NBD_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t per_slab = (size_t)n_cells * in_channels * out_channels;
+  if (n == 0) {        // no rows: the gradient is zero
+    contconv_wgrad_finish_kernel<<<ceil_div((int)per_slab, 256), 256, 0, st>>>(nullptr, 0, per_slab, dfilters);
+    return status();
+  }
+  if (!feat || !g || !rowptr || !pair_lists || (reinterpret_cast<uintptr_t>(feat) & 7)) return NBD_E_BADARG;
+  int S, tps;
+  wgrad_plan(n, n_cells, &S, &tps);
+  if (S > 1 && (!workspace || workspace_bytes < nbd_contconv_filter_grad_workspace_bytes(n, n_cells, in_channels, out_channels)))
+    return NBD_E_WORKSPACE;
+  const PairsLayout L = pairs_layout(n, edge_capacity, n_cells);
+  const char* base = static_cast<const char*>(pair_lists);
+  WGArgs A;
+  A.feat = feat; A.ldf = ldf; A.I = in_channels; A.g = g; A.ldg = ldg; A.O = out_channels;
+  A.rowptr = rowptr; A.n = n; A.n_tiles = ceil_div(n, TN); A.n_cells = n_cells; A.tiles_per_slab = tps;
+  A.desc = reinterpret_cast<const int2*>(base + L.desc); A.rows = reinterpret_cast<const int2*>(base + L.rows);
+  A.pair_src = reinterpret_cast<const int*>(base + L.src); A.pair_w = reinterpret_cast<const float*>(base + L.w);
+  A.tile_nsteps = reinterpret_cast<const int*>(base + L.nsteps);
+  A.partial = S > 1 ? static_cast<float*>(workspace) : dfilters;
+  contconv_wgrad_kernel<<<dim3(n_cells, S), 256, 0, st>>>(A);
+  int rc = status();
+  if (rc || S == 1) return rc;
+  contconv_wgrad_finish_kernel<<<ceil_div((int)per_slab, 256), 256, 0, st>>>(A.partial, S, per_slab, dfilters);
   return status();
 }
 

@@ -57,6 +57,15 @@ class GnnForwardArgs(ctypes.Structure):
                 ("edge_index", c_void_p), ("n_layers", c_int), ("layers", GnnLayerArgs * GNN_MAX_LAYERS)]
 
 
+class CcPairsJob(ctypes.Structure):
+    """Mirror of `nbd_cc_pairs_job` (include/nbd.h), field for field."""
+    _fields_ = [("rowptr", c_void_p), ("centres", c_void_p), ("deg", c_void_p), ("edge_capacity", c_int64),
+                ("filter_resolution", c_int), ("cell_map", c_void_p), ("n_cells", c_int), ("adjoint", c_int),
+                ("pair_lists", c_void_p), ("pair_lists_bytes", c_size_t)]
+
+
+CC_MAX_RES = 4
+
 # name -> (restype, argtypes); mirrors include/nbd.h one to one (tests check the two agree)
 _F = POINTER(c_float)
 SIGNATURES = {
@@ -152,6 +161,10 @@ SIGNATURES = {
     "nbd_contconv_pairs_batch_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_float, c_int, POINTER(c_int),
                                              POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), POINTER(c_size_t),
                                              c_void_p]),
+    "nbd_contconv_pairs_jobs_f32": (c_int, [c_void_p, c_int, c_float, c_int, POINTER(CcPairsJob), c_void_p]),
+    "nbd_contconv_filter_grad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "nbd_contconv_filter_grad_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int64,
+                                             c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nbd_contconv_fused_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "nbd_contconv_filter_floats": (c_size_t, [c_int, c_int, c_int]),
     "nbd_contconv_fused_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_int,

@@ -230,3 +230,116 @@ class ContConvFn(Function):
             da = nnops.linear(gs, w)
             dfeat = nnops.contconv_bin_bwd(pos, da, i_ch, d, r2, cell_map=cmap, cells_out=k, **ctx.bwd_lists)
         return dfeat, dfilters, None, None, None, None, None, None, None, None
+
+
+_VIRTUAL_ROWPTR = {}
+
+
+def ell_rowptr(n, cap, device):
+    """int32 [n + 1] = i * cap: the row starts of a padded (ELL) list array, built once per (n, cap, device)."""
+    key = (int(n), int(cap), str(device))
+    rp = _VIRTUAL_ROWPTR.get(key)
+    if rp is None:
+        if len(_VIRTUAL_ROWPTR) > 64:
+            _VIRTUAL_ROWPTR.clear()
+        rp = (torch.arange(n + 1, device=device, dtype=torch.int64) * cap).to(torch.int32)
+        _VIRTUAL_ROWPTR[key] = rp
+    return rp
+
+
+class ConvGraph:
+    """The edges of one ContinuousConv forward pass in the two groupings the fused kernels walk -- by aggregation
+    target (forward, filter gradient) and by feature source (feature gradient) -- and the pair lists built from them,
+    per filter resolution, on first use or several per launch (prebuild)."""
+
+    def __init__(self, pos, r2, fwd, adj):
+        self.pos, self.r2, self.n = pos, float(r2), pos.shape[0]
+        self.fwd, self.adj = fwd, adj        # (rowptr, listed nodes, deg or None, edge capacity)
+        self._pairs = {}
+
+    @classmethod
+    def from_lists(cls, pos, r2, lists):
+        """From graphops.radius_lists: its transposed CSR is the forward grouping, its own padded per-centre lists
+        (rows of `cap` entries, `deg` valid) the adjoint one -- no conversion."""
+        adj = None
+        if lists.deg is not None and lists.nbr is not None:
+            n, cap = lists.n, lists.nbr.shape[1]
+            adj = (ell_rowptr(n, cap, pos.device), lists.nbr.reshape(-1), lists.deg, n * cap)
+        return cls(pos, r2, (lists.rowptr, lists.centres, None, lists.centres.numel()), adj)
+
+    @classmethod
+    def from_edge_index(cls, pos, r2, rowptr, centres, edge_index):
+        rp, tg = graphops.csr_by_key(edge_index[1], edge_index[0], pos.shape[0])
+        if tg.numel() == 0:
+            tg = torch.zeros(1, dtype=torch.int32, device=pos.device)
+        return cls(pos, r2, (rowptr, centres, None, centres.numel()), (rp, tg, None, tg.numel()))
+
+    def _job(self, d, cmap, n_cells, adjoint):
+        rowptr, centres, deg, cap_e = self.adj if adjoint else self.fwd
+        return dict(rowptr=rowptr, centres=centres, deg=deg, edge_capacity=cap_e, d=d, cell_map=cmap, n_cells=n_cells,
+                    adjoint=adjoint, radius_sq=self.r2)
+
+    def prebuild(self, wants):
+        """wants: [(d, cell_map, n_cells, adjoint)] -- built four jobs per launch, skipping what exists."""
+        todo = []
+        for d, cmap, nc, adjoint in wants:
+            key = (int(d), int(nc), bool(adjoint))
+            if key not in self._pairs and key not in [t[0] for t in todo] and self.n > 0:
+                todo.append((key, self._job(d, cmap, nc, adjoint)))
+        for lo in range(0, len(todo), 4):
+            got = nnops.contconv_pairs_jobs(self.pos, [j for _, j in todo[lo:lo + 4]])
+            for (key, _), g in zip(todo[lo:lo + 4], got):
+                self._pairs[key] = g
+
+    def pairs(self, d, cmap, n_cells, adjoint=False):
+        key = (int(d), int(n_cells), bool(adjoint))
+        if key not in self._pairs:
+            self.prebuild([(d, cmap, n_cells, adjoint)])
+        return self._pairs[key]
+
+    def rows(self, adjoint=False):
+        return (self.adj if adjoint else self.fwd)[0]
+
+
+class ContConvFusedFn(Function):
+    """ContinuousConv layer (contconv.py:80-98) on the block-sparse fused kernels, forward AND backward: the binned
+    matrix A is formed in neither.
+      forward   out = act(scale_n * sum_cells A[n][cell] . F[cell])              nbd_contconv_fused_f32, forward lists
+      dfilters  [cell] = sum_n A[n][cell]^T g[n],  g = scale * act'(out) * dout   nbd_contconv_filter_grad_f32
+      dfeat     = the forward kernel over the ADJOINT lists (rows = feature sources) with g as the features and every
+                  cell's filter transposed: dfeat[c] = sum_cells B[c][cell] . F[cell]^T, B = the adjoint blocks' sums of g rows."""
+
+    @staticmethod
+    def forward(ctx, feat, filters, graph, d, scale, act, cells):
+        idx, cmap, k = cells
+        o_ch = filters.shape[4]
+        feat = feat if (feat.stride(1) == 1 and feat.stride(0) % 2 == 0 and feat.data_ptr() % 8 == 0) else feat.contiguous()
+        pb, cap_e = graph.pairs(d, cmap, k)
+        wf = nnops.contconv_shuffle_filters(filters, idx)
+        out = nnops.contconv_fused(feat, graph.rows(), pb, cap_e, wf, k, o_ch, rowscale=scale, act=act)
+        ctx.save_for_backward(feat, filters, out, scale)
+        ctx.graph, ctx.d, ctx.act, ctx.cells = graph, d, act, cells
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        feat, filters, out, scale = ctx.saved_tensors
+        graph, d = ctx.graph, ctx.d
+        idx, cmap, k = ctx.cells
+        i_ch, o_ch = filters.shape[3], filters.shape[4]
+        dout = dout if dout.stride(1) == 1 else dout.contiguous()
+        gs = nnops.act_bwd(dout, out if ctx.act == "tanh" else None, ctx.act, rowscale=scale)
+        dfilters = dfeat = None
+        if ctx.needs_input_grad[1]:
+            pb, cap_e = graph.pairs(d, cmap, k)
+            dw = nnops.contconv_filter_grad(feat, gs, graph.rows(), pb, cap_e, k)
+            # unreachable grid points never enter a product: their gradient is exactly zero
+            dfilters = torch.zeros((d * d * d, i_ch, o_ch), dtype=torch.float32, device=dw.device)
+            dfilters.index_copy_(0, idx, dw)
+            dfilters = dfilters.reshape(filters.shape)
+        if ctx.needs_input_grad[0]:
+            pa, cap_a = graph.pairs(d, cmap, k, adjoint=True)
+            wt = nnops.contconv_shuffle_filters(filters.transpose(3, 4), idx)
+            dfeat = nnops.contconv_fused(gs, graph.rows(adjoint=True), pa, cap_a, wt, k, i_ch)
+        return dfeat, dfilters, None, None, None, None, None

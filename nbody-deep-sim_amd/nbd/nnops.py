@@ -232,6 +232,56 @@ def contconv_pairs_batch(pos, rowptr, centres, edge_capacity: int, radius_sq: fl
     return [(b, edge_capacity) for b in bufs]
 
 
+def contconv_pairs_jobs(pos, jobs):
+    """nbd_contconv_pairs_jobs_f32: up to four pair-list jobs over the same nodes in ONE launch. jobs: dicts with
+    rowptr, centres, deg (None = CSR), edge_capacity, d, cell_map, n_cells, adjoint. Returns [(buffer, edge_capacity)]."""
+    n = pos.shape[0]
+    if pos.shape != (n, 3) or pos.dtype != torch.float32 or not pos.is_contiguous():
+        raise _lib.NbdError("pos must be contiguous fp32 (n,3)")
+    if not 1 <= len(jobs) <= _lib.CC_MAX_RES:
+        raise _lib.NbdError(f"contconv_pairs_jobs: 1 .. {_lib.CC_MAX_RES} jobs per launch")
+    L = _lib.lib()
+    arr = (_lib.CcPairsJob * len(jobs))()
+    out = []
+    r2 = None
+    for a, j in zip(arr, jobs):
+        rowptr, centres, deg, cmap = j["rowptr"], j["centres"], j.get("deg"), j.get("cell_map")
+        if rowptr.dtype != torch.int32 or rowptr.numel() != n + 1 or centres.dtype != torch.int32 or \
+                (deg is not None and (deg.dtype != torch.int32 or deg.numel() != n)):
+            raise _lib.NbdError("rowptr int32 [n+1] / centres int32 / deg int32 [n] required")
+        d, nc = int(j["d"]), int(j["n_cells"])
+        if cmap is not None and (cmap.dtype != torch.int32 or cmap.numel() != d * d * d or not cmap.is_cuda):
+            raise _lib.NbdError("cell_map must be an int32 CUDA tensor of d^3 entries")
+        cap_e = max(int(j["edge_capacity"]), centres.numel())
+        buf = torch.empty(max(L.nbd_contconv_pairs_bytes(n, cap_e, nc), 16), dtype=torch.uint8, device=pos.device)
+        a.rowptr, a.centres, a.deg, a.edge_capacity = rowptr.data_ptr(), centres.data_ptr(), _lib.ptr(deg), cap_e
+        a.filter_resolution, a.cell_map, a.n_cells, a.adjoint = d, _lib.ptr(cmap), nc, int(bool(j.get("adjoint")))
+        a.pair_lists, a.pair_lists_bytes = buf.data_ptr(), buf.numel()
+        r2 = float(j["radius_sq"]) if r2 is None else r2
+        out.append((buf, cap_e))
+    with _lib.on_device(pos.device):
+        _lib.check(L.nbd_contconv_pairs_jobs_f32(pos.data_ptr(), n, r2, len(jobs), arr, _lib.current_stream(pos.device)),
+                   "nbd_contconv_pairs_jobs_f32")
+    return out
+
+
+def contconv_filter_grad(feat, g, rowptr, pair_buf, edge_capacity: int, n_cells: int):
+    """(n_cells, I, O) = sum over the touched (node, cell) blocks of A[node][cell]^T g[node] (nbd_contconv_filter_grad_f32):
+    ContinuousConv's filter gradient over the forward pair lists, cells in compact (kept) order."""
+    n, i_ch, o_ch = rowptr.numel() - 1, feat.shape[1], g.shape[1]
+    ldf, ldg = _mat(feat, "feat"), _mat(g, "g")
+    L = _lib.lib()
+    out = torch.empty((n_cells, i_ch, o_ch), dtype=torch.float32, device=feat.device)
+    need = L.nbd_contconv_filter_grad_workspace_bytes(n, int(n_cells), i_ch, o_ch)
+    ws = _ws(need, feat.device)
+    with _lib.on_device(feat.device):
+        _lib.check(L.nbd_contconv_filter_grad_f32(feat.data_ptr(), ldf, i_ch, g.data_ptr(), ldg, o_ch, rowptr.data_ptr(), n,
+                                                  int(edge_capacity), pair_buf.data_ptr(), int(n_cells), out.data_ptr(),
+                                                  _lib.ptr(ws), need, _lib.current_stream(feat.device)),
+                   "nbd_contconv_filter_grad_f32")
+    return out
+
+
 def contconv_pairs_inv_degree(pair_buf, n: int, edge_capacity: int, n_cells: int) -> torch.Tensor:
     """float32 [n] view into the pair-list buffer: 1 / max(in-degree, 1), the mean aggregation's row scale, which the
     pair kernel writes as a by-product (no degree_scale launch)."""

@@ -304,7 +304,8 @@ def test_batchnorm_train_matches_torch(n, c, act, gpu_device):
         ag.batchnorm_act(x[:1].cuda(), bn_g, act)
 
 
-@pytest.mark.parametrize("agg,D,I,O", [("mean", 4, 8, 16), ("sum", 3, 70, 40), ("mean", 6, 32, 128), ("mean", 2, 130, 5)])
+@pytest.mark.parametrize("agg,D,I,O", [("mean", 4, 8, 16), ("sum", 3, 70, 40), ("mean", 6, 32, 128), ("mean", 2, 130, 5),
+                                       ("sum", 5, 12, 20), ("mean", 4, 4, 64), ("mean", 6, 128, 128), ("sum", 4, 64, 4)])
 def test_contconv_layer_gradients_match_oracle(agg, D, I, O, gpu_device):
     import contconv
     from nbd import graphops
@@ -334,6 +335,38 @@ def test_contconv_layer_gradients_match_oracle(agg, D, I, O, gpu_device):
     layer(pos.cuda(), fg2, lists=lists, act="tanh").backward(dout.cuda())
     assert global_rel(fg2.grad.cpu(), fr.grad) < TOL and global_rel(layer.filters.grad.cpu(), ora.filters.grad) < TOL
     assert torch.equal(g1, layer.filters.grad) or global_rel(g1.cpu(), layer.filters.grad.cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("D,I,O,n", [(6, 64, 64, 3000), (4, 128, 32, 1500), (3, 8, 128, 700)])
+def test_contconv_pair_list_backward_equals_binned_backward(D, I, O, n, gpu_device):
+    """The training step on the pair lists (ag.ContConvFusedFn: fused forward, nbd_contconv_filter_grad_f32, feature
+    gradient = the forward kernel over the adjoint lists) against the binned-matrix formulation (ag.ContConvFn) on
+    graphs of several tiles and slabs; twice, bit-identically (fixed summation order); and the adjoint pair lists hold
+    the forward lists' weights exactly (same multiset of (target, source, cell, weight))."""
+    import contconv
+    from nbd import autograd as ag
+    from nbd import graphops
+    torch.manual_seed(n)
+    pos, _, _ = _plummer(n, 8)
+    pos = (pos * (n / 300.0) ** (1.0 / 3.0) * 0.7).cuda().contiguous()
+    feat = torch.randn(n, I, device="cuda")
+    dout = torch.randn(n, O, device="cuda")
+    layer = contconv.ContinuousConv(I, O, D, radius=1.0, agg="mean").cuda()
+    assert layer.trains_fused()
+    lists = graphops.radius_lists(pos, 1.0, None, loop=True, max_num_neighbors=32)
+    got = []
+    for fused in (True, True, False):
+        layer.use_fused = fused
+        layer.filters.grad = None
+        f = feat.clone().requires_grad_()
+        out = layer(pos, f, lists=lists, act="tanh")
+        out.backward(dout)
+        got.append((out.detach().clone(), f.grad.clone(), layer.filters.grad.clone()))
+    layer.use_fused = True
+    for a, b in zip(got[0], got[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(got[0], got[2]):
+        assert global_rel(a.cpu(), b.cpu()) < TOL
 
 
 @pytest.mark.parametrize("agg", ["max", "min"])
