@@ -425,6 +425,40 @@ int nbd_layernorm_bwd_f32(const float* x, int ldx, int c, const float* gamma, fl
                           float* dx, int lddx, float* dgamma, float* dbeta, int n, void* workspace,
                           size_t workspace_bytes, nbd_stream_t stream);
 
+/* ---- GraphModel's training step with the whole model behind one call per direction (csrc/train_model.hip):
+ * forward = gnn.py:130-148 (node encoder MLP or none, message_passing_steps EdgeConv layers with aggr sum / mean in the
+ * per-node factored form, LayerNorm over [encoder output | last layer], Linear or MLP decoder), keeping what the
+ * backward pass needs in `workspace`; backward = what `loss.backward()` computes for every parameter (gnn.py:170,183,
+ * 189), from d loss / d out. Same kernels and summation orders as the per-layer entry points above (bit-reproducible).
+ * Weights in torch.nn.Linear layout (out x in, contiguous); w1[l] is the EdgeConv MLP's first Linear (h x 2 F_l),
+ * w2[l] its second (h x h). enc_dim[0 .. n_enc] / head_dim[0 .. n_head]: layer widths (tanh between the Linears, none
+ * after the last), enc_dim[0] = f, head_dim[0] = encoder output + h. (rowptr | fixed_k, src): edges grouped by target as
+ * for nbd_edgeconv_aggregate_f32; (rowptr_t, tgt_t): the same edges grouped by source (nbd_csr_by_key_i64), read by the
+ * backward pass only. The same args struct (same workspace) goes to both calls. n = 0: NBD_E_UNSUPPORTED. */
+#define NBD_TRAIN_MAX_MLP 8
+typedef struct nbd_gnn_train_args {
+  int n; const int* rowptr; const int64_t* src; int fixed_k; const int* rowptr_t; const int* tgt_t; int aggr;
+  const float* x; int ldx; int f;
+  int n_enc; const float* enc_w[NBD_TRAIN_MAX_MLP]; const float* enc_b[NBD_TRAIN_MAX_MLP]; int enc_dim[NBD_TRAIN_MAX_MLP + 1];
+  int n_layers; int h;
+  const float* w1[NBD_GNN_MAX_LAYERS]; const float* b1[NBD_GNN_MAX_LAYERS];
+  const float* w2[NBD_GNN_MAX_LAYERS]; const float* b2[NBD_GNN_MAX_LAYERS];
+  const float* ln_g; const float* ln_b; float ln_eps;
+  int n_head; const float* head_w[NBD_TRAIN_MAX_MLP]; const float* head_b[NBD_TRAIN_MAX_MLP]; int head_dim[NBD_TRAIN_MAX_MLP + 1];
+  float* out; int ldout;
+  void* workspace; size_t workspace_bytes;
+} nbd_gnn_train_args;
+typedef struct nbd_gnn_train_grads {
+  float* enc_w[NBD_TRAIN_MAX_MLP]; float* enc_b[NBD_TRAIN_MAX_MLP];
+  float* w1[NBD_GNN_MAX_LAYERS]; float* b1[NBD_GNN_MAX_LAYERS]; float* w2[NBD_GNN_MAX_LAYERS]; float* b2[NBD_GNN_MAX_LAYERS];
+  float* ln_g; float* ln_b;
+  float* head_w[NBD_TRAIN_MAX_MLP]; float* head_b[NBD_TRAIN_MAX_MLP];
+} nbd_gnn_train_grads;
+size_t nbd_gnn_train_workspace_bytes(const nbd_gnn_train_args* args);
+int nbd_gnn_train_forward_f32(const nbd_gnn_train_args* args, nbd_stream_t stream);
+int nbd_gnn_train_backward_f32(const nbd_gnn_train_args* args, const float* dout, int lddout,
+                               const nbd_gnn_train_grads* grads, nbd_stream_t stream);
+
 /* ---- ContinuousConv.forward (contconv.py:80-98), block-sparse and fused: only the (node, filter cell) blocks
  * some edge touches are multiplied, and the binned features never reach HBM (csrc/contconv_fused.hip).
  * For in_channels % 4 == 0, in_channels <= 128 (nbd_contconv_fused_supported), inference and training alike (the

@@ -832,7 +832,7 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
     const int p1 = min(g1, p0 + CC_CAP), npass = p1 - p0;
     DBG_T(t0_)
     cc_load_table(A, L, p0, p1, tid);
-    DBG_ACC(true, dbg[2], t0_)
+    (void)0;   /* (table loads: ~2 us per workgroup, see the producers' [2]) */
     // pipeline registers: the first reads of the step about to run (when `have`), that step's tile
     f4 a0n = {0.f, 0.f, 0.f, 0.f};
     int node_n = -1;
@@ -965,7 +965,7 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
         const int meta_n = UNI(meta_nv), rem_n = steps_of(meta_n, inext);
         if (has_cols && !CC_ABL_ONE_FRAGMENT) load_b(bf1, meta_n & 0xff);   // past the end: the last cell again, never used
         meta_nv = meta_at(inext + rem_n);
-        CC_FRAGMENT_LANDED(bf0)
+        DBG_T(f0_) CC_FRAGMENT_LANDED(bf0) DBG_ACC(true, dbg[2], f0_)      /* probe build: [2] = time waiting for fragments */
         CC_STEP(bf0, i)
         for (int u = 1; u < rem; ++u) CC_STEP(bf0, i + u)
         i = inext; rem = rem_n;
@@ -976,7 +976,7 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
         const int meta_n = UNI(meta_nv), rem_n = steps_of(meta_n, inext);
         if (has_cols && !CC_ABL_ONE_FRAGMENT) load_b(bf0, meta_n & 0xff);
         meta_nv = meta_at(inext + rem_n);
-        CC_FRAGMENT_LANDED(bf1)
+        DBG_T(f1_) CC_FRAGMENT_LANDED(bf1) DBG_ACC(true, dbg[2], f1_)
         CC_STEP(bf1, i)
         for (int u = 1; u < rem; ++u) CC_STEP(bf1, i + u)
         i = inext; rem = rem_n;
@@ -1187,12 +1187,18 @@ __global__ __launch_bounds__(256) void contconv_wgrad_kernel(const WGArgs A) {
   const bool live = 2 * lane < I;
   const int fo = min(2 * lane, I - 2);
 
+  // A wave builds four rows of a step. Its memory accesses form three dependent levels (row records -> pair records
+  // -> feature rows); every level is issued for all four rows at once, so a step costs three round trips, not twelve
+  // (the first version walked row after row: 174 us for the 2 000-node training batch). Rows of more than four pairs
+  // finish in a per-row loop.
   auto gather = [&](int s, int buf) {
-#pragma unroll 1
+    int p0[4], p1[4], node[4];
+    const int* ps[4];
+    const float* pw[4];
+#pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const int r = wave * 4 + rr, q = 16 * s + r;
-      f2 acc = {0.f, 0.f};
-      float g0 = 0.f, g1 = 0.f;
+      const int q = 16 * s + wave * 4 + rr;
+      p0[rr] = 0; p1[rr] = 0; node[rr] = 0; ps[rr] = A.pair_src; pw[rr] = A.pair_w;
       if (q < R) {                                         // wave-uniform
         int j = 0;
         while (j + 1 < nt && t_pref[j + 1] <= q) ++j;      // the tile of row q (LDS broadcasts)
@@ -1200,32 +1206,53 @@ __global__ __launch_bounds__(256) void contconv_wgrad_kernel(const WGArgs A) {
         const int tile = t0 + j;
         const long long e8 = t_e8[j];
         const int2* rw = A.rows + e8 + tile + t_row0[j] + (q - t_pref[j]);
-        const int2 rec = uni2(rw[0]);
-        const int p1 = UNI(rw[1].y);
-        const int node = tile * TN + rec.x;
-        const int* ps = A.pair_src + e8;
-        const float* pw = A.pair_w + e8;
-        int p = rec.y;
-        for (; p + 4 <= p1; p += 4) {
-          int sidx[4]; float wv[4]; f2 v[4];
+        const int2 rec = rw[0];
+        p1[rr] = rw[1].y; p0[rr] = rec.y;
+        node[rr] = tile * TN + rec.x;
+        ps[rr] = A.pair_src + e8; pw[rr] = A.pair_w + e8;
+      }
+    }
+    int sidx[4][4];
+    float wv[4][4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { sidx[u] = UNI(ps[p + u]); wv[u] = __int_as_float(UNI(__float_as_int(pw[p + u]))); }
+    for (int rr = 0; rr < 4; ++rr) {
+      p0[rr] = UNI(p0[rr]); p1[rr] = UNI(p1[rr]); node[rr] = UNI(node[rr]);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f2*>(A.feat + (size_t)sidx[u] * A.ldf + fo);
+      for (int u = 0; u < 4; ++u) {
+        const bool in = p0[rr] + u < p1[rr];
+        const int at = in ? p0[rr] + u : 0;                // a padding slot reads the tile's first pair with weight 0
+        sidx[rr][u] = ps[rr][at];
+        wv[rr][u] = in ? pw[rr][at] : 0.f;
+      }
+    }
+    f2 v[4][4];
+    float g0[4], g1[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) acc = __builtin_elementwise_fma(f2{wv[u], wv[u]}, v[u], acc);
-        }
-        for (; p < p1; ++p) {
-          const int si = UNI(ps[p]);
-          const float w = __int_as_float(UNI(__float_as_int(pw[p])));
-          acc = __builtin_elementwise_fma(f2{w, w}, *reinterpret_cast<const f2*>(A.feat + (size_t)si * A.ldf + fo), acc);
-        }
-        const float* gr = A.g + (size_t)node * A.ldg;
-        g0 = lane < O ? gr[lane] : 0.f;
-        g1 = lane + 64 < O ? gr[lane + 64] : 0.f;
+    for (int rr = 0; rr < 4; ++rr) {
+      const bool row_ok = 16 * s + wave * 4 + rr < R;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        v[rr][u] = *reinterpret_cast<const f2*>(A.feat + (size_t)UNI(sidx[rr][u]) * A.ldf + fo);
+      const float* gr = A.g + (size_t)node[rr] * A.ldg;
+      g0[rr] = (row_ok && lane < O) ? gr[lane] : 0.f;
+      g1[rr] = (row_ok && lane + 64 < O) ? gr[lane + 64] : 0.f;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = wave * 4 + rr;
+      f2 acc = {0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float w = __int_as_float(UNI(__float_as_int(wv[rr][u])));
+        acc = __builtin_elementwise_fma(f2{w, w}, v[rr][u], acc);
+      }
+      for (int p = p0[rr] + 4; p < p1[rr]; ++p) {          // the same order as the first four: pair after pair
+        const int si = UNI(ps[rr][p]);
+        const float w = __int_as_float(UNI(__float_as_int(pw[rr][p])));
+        acc = __builtin_elementwise_fma(f2{w, w}, *reinterpret_cast<const f2*>(A.feat + (size_t)si * A.ldf + fo), acc);
       }
       *reinterpret_cast<f2*>(&a_s[buf][r][2 * lane]) = live ? acc : f2{0.f, 0.f};
-      g_s[buf][r][lane] = g0; g_s[buf][r][lane + 64] = g1;
+      g_s[buf][r][lane] = g0[rr]; g_s[buf][r][lane + 64] = g1[rr];
     }
   };
 
@@ -1287,7 +1314,10 @@ __global__ __launch_bounds__(256) void contconv_wgrad_finish_kernel(const float*
 
 inline void wgrad_plan(int n, int n_cells, int* slabs, int* tiles_per_slab) {
   const int tiles = ceil_div(n, TN);
+  // enough workgroups to fill the chip, but at least four tiles per slab: every slab writes (and the finishing kernel
+  // reads) a whole cells x I x O partial, which is what a 2 000-node training batch spent its time on with 7 slabs
   int S = tiles < ceil_div(1024, n_cells) ? tiles : ceil_div(1024, n_cells);
+  if (S > ceil_div(tiles, 4)) S = ceil_div(tiles, 4);
   int tps = ceil_div(tiles, S);
   if (tps > WG_MAXT) tps = WG_MAXT;
   *tiles_per_slab = tps;

@@ -47,21 +47,38 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------ column sums (two stages)
-constexpr int kColRows = 512;     // rows per stage-1 block
+constexpr int kColRows = 128;     // rows per stage-1 block (512 at first: 128 dependent loads per thread, 26 us for 2 000 rows)
 // stage 1: grid = (row blocks, 64-column groups); the block's 256 threads are 4 row phases x 64 columns
-// (coalesced 256-B reads); the 4 phase sums meet in LDS in fixed order.
+// (coalesced 256-B reads), each thread four independent partial sums (loads in flight together) combined in fixed
+// order; the 4 phase sums meet in LDS in fixed order.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ldx,
                                                              const float* __restrict__ w, int n, int c,
                                                              float* __restrict__ part) {
   __shared__ float red[256];
   const int r0 = blockIdx.x * kColRows, r1 = min(r0 + kColRows, n);
   const int col = blockIdx.y * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
-  float s = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (col < c) {
-    if (w) for (int r = r0 + ph; r < r1; r += 4) s = __builtin_fmaf(w[r], x[(size_t)r * ldx + col], s);
-    else   for (int r = r0 + ph; r < r1; r += 4) s += x[(size_t)r * ldx + col];
+    int r = r0 + ph;
+    if (w) {
+      for (; r + 12 < r1; r += 16) {
+        s0 = __builtin_fmaf(w[r], x[(size_t)r * ldx + col], s0);
+        s1 = __builtin_fmaf(w[r + 4], x[(size_t)(r + 4) * ldx + col], s1);
+        s2 = __builtin_fmaf(w[r + 8], x[(size_t)(r + 8) * ldx + col], s2);
+        s3 = __builtin_fmaf(w[r + 12], x[(size_t)(r + 12) * ldx + col], s3);
+      }
+      for (; r < r1; r += 4) s0 = __builtin_fmaf(w[r], x[(size_t)r * ldx + col], s0);
+    } else {
+      for (; r + 12 < r1; r += 16) {
+        s0 += x[(size_t)r * ldx + col];
+        s1 += x[(size_t)(r + 4) * ldx + col];
+        s2 += x[(size_t)(r + 8) * ldx + col];
+        s3 += x[(size_t)(r + 12) * ldx + col];
+      }
+      for (; r < r1; r += 4) s0 += x[(size_t)r * ldx + col];
+    }
   }
-  red[threadIdx.x] = s;
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (ph == 0 && col < c)
     part[(size_t)blockIdx.x * c + col] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
@@ -101,16 +118,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G,
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int lc = tid & 63, lr = tid >> 6;            // loader: 64 columns x 4 rows per pass
+  // The next stage's 32 rows travel to registers while this stage multiplies (one global-load latency per stage was
+  // the whole cost of a 2 000-row gradient: 26 us for 64 MFMAs).
+  float gr[WG_R / 4], xr[WG_R / 4];
+  const bool gcol = m0 + lc < m, xcol = k0 + lc < k;
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int u = 0; u < WG_R / 4; ++u) {
+      const int row = r0 + lr + 4 * u;
+      const bool ok = row < r_end;
+      gr[u] = (ok && gcol) ? G[(size_t)row * ldg + m0 + lc] : 0.f;
+      xr[u] = (ok && xcol) ? X[(size_t)row * ldx + k0 + lc] : 0.f;
+    }
+  };
+  if (r_begin < r_end) fetch(r_begin);
   for (int r0 = r_begin; r0 < r_end; r0 += WG_R) {
     __syncthreads();
 #pragma unroll
-    for (int rr = lr; rr < WG_R; rr += 4) {
-      const int row = r0 + rr;
-      const bool ok = row < r_end;
-      gs[rr * WG_LD + lc] = (ok && m0 + lc < m) ? G[(size_t)row * ldg + m0 + lc] : 0.f;
-      xs[rr * WG_LD + lc] = (ok && k0 + lc < k) ? X[(size_t)row * ldx + k0 + lc] : 0.f;
+    for (int u = 0; u < WG_R / 4; ++u) {
+      gs[(lr + 4 * u) * WG_LD + lc] = gr[u];
+      xs[(lr + 4 * u) * WG_LD + lc] = xr[u];
     }
     __syncthreads();
+    if (r0 + WG_R < r_end) fetch(r0 + WG_R);
     const float* a_ptr = gs + (lane >> 5) * WG_LD + wm * 32 + (lane & 31);
     const float* b_ptr = xs + (lane >> 5) * WG_LD + wk * 32 + (lane & 31);
 #pragma unroll
@@ -201,7 +231,7 @@ __global__ __launch_bounds__(256) void edgeconv_bwd_kernel(
 // Block = 4 waves x kLnRows rows each. Per row (one wave): mean / rstd recomputed as the forward does,
 // a = mean_c(dy g), b = mean_c(dy g xhat), dx = rstd (dy g - a - xhat b). The block then sums
 // dy xhat and dy over its rows per channel into part[block][0:c | c:2c] for nbd_colsum's second stage.
-constexpr int kLnRows = 16;
+constexpr int kLnRows = 4;        // (16 at first: 64 serial rows per block, 56 us for 2 000 rows)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);

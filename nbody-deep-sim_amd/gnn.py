@@ -509,6 +509,37 @@ class GraphModel(torch.nn.Module):
                 pass
         return cached
 
+    use_one_call_train = True    # forward + backward of the whole model through ONE C-ABI call each (csrc/train_model.hip)
+
+    def _one_call_train(self, x_in, lists):
+        """The training forward as one autograd node (ag.GnnModelFn), or None when the configuration is outside what
+        nbd_gnn_train_*_f32 covers: aggr = "max", an active encoder dropout, an empty batch, more layers than the
+        C-ABI's fixed arrays hold."""
+        from nbd import _lib
+        enc = self.node_encoder if isinstance(self.node_encoder, MLP) else None
+        if (not self.use_one_call_train or self.aggr == "max" or x_in.shape[0] == 0 or lists.src.numel() == 0
+                or (enc is not None and (enc.has_norm or (self.training and enc.dropout > 0) or len(enc.lins) > _lib.TRAIN_MAX_MLP))
+                or len(self.gnns) > _lib.GNN_MAX_LAYERS):
+            return None
+        head = [self.output] if isinstance(self.output, Linear) else [m for m in self.output if isinstance(m, Linear)]
+        if len(head) > _lib.TRAIN_MAX_MLP:
+            return None
+        params = []
+        if enc is not None:
+            for lin in enc.lins:
+                params += [lin.weight, lin.bias]
+        for g in self.gnns:
+            params += [g.nn[0].weight, g.nn[0].bias, g.nn[2].weight, g.nn[2].bias]
+        params += [self.layer_norm.weight, self.layer_norm.bias]
+        for lin in head:
+            params += [lin.weight, lin.bias]
+        if any(p is None for p in params):
+            return None
+        spec = {"aggr": "mean" if self.aggr == "mean" else "sum", "n_layers": len(self.gnns), "h": self.gnn_dim,
+                "enc_dims": enc.channels if enc is not None else None, "ln_eps": self.layer_norm.eps,
+                "head_dims": [head[0].in_features] + [lin.out_features for lin in head]}
+        return ag.GnnModelFn.apply(x_in, lists, spec, *params)
+
     def _forward_autograd(self, data):
         """gnn.py:130-148 with every layer a torch.autograd.Function over the HIP kernels."""
         x7 = data.x
@@ -517,6 +548,10 @@ class GraphModel(torch.nn.Module):
         n, h = x7.shape[0], self.gnn_dim
         x_in = torch.cat((x7[:, :3], x7[:, 6:]), dim=-1) if self.input_dim == 4 else x7
         x_in = x_in.to(torch.float32).contiguous()
+        lists = self._graph_lists(data, n)
+        one = self._one_call_train(x_in, lists)
+        if one is not None:
+            return one
         if isinstance(self.node_encoder, MLP):
             enc, last = x_in, len(self.node_encoder.lins) - 1
             for i, lin in enumerate(self.node_encoder.lins):
@@ -525,7 +560,6 @@ class GraphModel(torch.nn.Module):
                     enc = torch.nn.functional.dropout(enc, p=self.node_encoder.dropout, training=True)
         else:
             enc = x_in
-        lists = self._graph_lists(data, n)
         if lists.rowptr is None:
             val = float(lists.fixed_k) if self.aggr != "mean" else (1.0 if lists.fixed_k > 0 else 0.0)
             brs = torch.full((n,), val, dtype=torch.float32, device=x7.device)

@@ -19,7 +19,9 @@ import torch  # noqa: F401  (load order matters, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
-LIB_PATH = os.path.join(CSRC_DIR, "libnbd_hip.so")
+# NBD_LIB_OVERRIDE: a probe / ablation build of the SAME library (tools/build_contconv_trace.sh -> tools/_trace/*.so),
+# for the measurement tools only; there is still no other path than a HIP build of csrc/.
+LIB_PATH = os.environ.get("NBD_LIB_OVERRIDE") or os.path.join(CSRC_DIR, "libnbd_hip.so")
 
 
 class NbdError(RuntimeError):
@@ -55,6 +57,29 @@ class GnnForwardArgs(ctypes.Structure):
     """Mirror of `nbd_gnn_forward_args` (include/nbd.h), field for field."""
     _fields_ = [("pos", c_void_p), ("n", c_int), ("k", c_int), ("loop", c_int), ("use_hint", c_int),
                 ("edge_index", c_void_p), ("n_layers", c_int), ("layers", GnnLayerArgs * GNN_MAX_LAYERS)]
+
+
+TRAIN_MAX_MLP = 8
+_PF = c_void_p * TRAIN_MAX_MLP
+_PL = c_void_p * GNN_MAX_LAYERS
+
+
+class GnnTrainArgs(ctypes.Structure):
+    """Mirror of `nbd_gnn_train_args` (include/nbd.h), field for field."""
+    _fields_ = [("n", c_int), ("rowptr", c_void_p), ("src", c_void_p), ("fixed_k", c_int), ("rowptr_t", c_void_p),
+                ("tgt_t", c_void_p), ("aggr", c_int),
+                ("x", c_void_p), ("ldx", c_int), ("f", c_int),
+                ("n_enc", c_int), ("enc_w", _PF), ("enc_b", _PF), ("enc_dim", c_int * (TRAIN_MAX_MLP + 1)),
+                ("n_layers", c_int), ("h", c_int), ("w1", _PL), ("b1", _PL), ("w2", _PL), ("b2", _PL),
+                ("ln_g", c_void_p), ("ln_b", c_void_p), ("ln_eps", c_float),
+                ("n_head", c_int), ("head_w", _PF), ("head_b", _PF), ("head_dim", c_int * (TRAIN_MAX_MLP + 1)),
+                ("out", c_void_p), ("ldout", c_int), ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
+class GnnTrainGrads(ctypes.Structure):
+    """Mirror of `nbd_gnn_train_grads` (include/nbd.h), field for field."""
+    _fields_ = [("enc_w", _PF), ("enc_b", _PF), ("w1", _PL), ("b1", _PL), ("w2", _PL), ("b2", _PL),
+                ("ln_g", c_void_p), ("ln_b", c_void_p), ("head_w", _PF), ("head_b", _PF)]
 
 
 class CcPairsJob(ctypes.Structure):
@@ -171,6 +196,9 @@ SIGNATURES = {
                                        c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "nbd_degree_scale_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nbd_gnn_forward_f32": (c_int, [c_void_p, c_void_p]),
+    "nbd_gnn_train_workspace_bytes": (c_size_t, [POINTER(GnnTrainArgs)]),
+    "nbd_gnn_train_forward_f32": (c_int, [POINTER(GnnTrainArgs), c_void_p]),
+    "nbd_gnn_train_backward_f32": (c_int, [POINTER(GnnTrainArgs), c_void_p, c_int, POINTER(GnnTrainGrads), c_void_p]),
     "nbd_gnn_layer_f32": (c_int, [POINTER(GnnLayerArgs), c_void_p]),
     # --- backward kernels (csrc/train.hip) and the transposed adjacency they gather over
     "nbd_csr_by_key_i64": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -343,3 +343,80 @@ class ContConvFusedFn(Function):
             wt = nnops.contconv_shuffle_filters(filters.transpose(3, 4), idx)
             dfeat = nnops.contconv_fused(gs, graph.rows(adjoint=True), pa, cap_a, wt, k, i_ch)
         return dfeat, dfilters, None, None, None, None, None
+
+
+class GnnModelFn(Function):
+    """GraphModel.forward (gnn.py:130-148) as ONE autograd node: nbd_gnn_train_forward_f32 enqueues the whole forward and
+    keeps its activations in a workspace, nbd_gnn_train_backward_f32 the whole adjoint, writing every parameter gradient
+    (csrc/train_model.hip). The per-layer Functions above remain for what this does not cover (aggr = "max", dropout)."""
+
+    @staticmethod
+    def forward(ctx, x_in, lists, spec, *params):
+        import ctypes
+        from . import _lib
+        n, dev = x_in.shape[0], x_in.device
+        p = [t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float() for t in params]
+        a = _lib.GnnTrainArgs()
+        a.n, a.rowptr, a.src, a.fixed_k = n, _lib.ptr(lists.rowptr), _lib.ptr(lists.src), int(lists.fixed_k)
+        a.aggr = 1 if spec["aggr"] == "mean" else 0
+        a.x, a.ldx, a.f = x_in.data_ptr(), x_in.stride(0), x_in.shape[1]
+        k = 0
+        a.n_enc = len(spec["enc_dims"]) - 1 if spec["enc_dims"] else 0
+        for i in range(a.n_enc):
+            a.enc_w[i], a.enc_b[i] = p[k].data_ptr(), p[k + 1].data_ptr()
+            k += 2
+        for i, d in enumerate(spec["enc_dims"] or []):
+            a.enc_dim[i] = d
+        a.n_layers, a.h = spec["n_layers"], spec["h"]
+        for l in range(a.n_layers):
+            a.w1[l], a.b1[l], a.w2[l], a.b2[l] = (p[k + j].data_ptr() for j in range(4))
+            k += 4
+        a.ln_g, a.ln_b, a.ln_eps = p[k].data_ptr(), p[k + 1].data_ptr(), float(spec["ln_eps"])
+        k += 2
+        a.n_head = len(spec["head_dims"]) - 1
+        for i in range(a.n_head):
+            a.head_w[i], a.head_b[i] = p[k].data_ptr(), p[k + 1].data_ptr()
+            k += 2
+        for i, d in enumerate(spec["head_dims"]):
+            a.head_dim[i] = d
+        out = torch.empty((n, spec["head_dims"][-1]), dtype=torch.float32, device=dev)
+        a.out, a.ldout = out.data_ptr(), out.stride(0)
+        L = _lib.lib()
+        need = L.nbd_gnn_train_workspace_bytes(ctypes.byref(a))
+        if need == 0:
+            raise _lib.NbdError("nbd_gnn_train_workspace_bytes: configuration rejected")
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), need
+        with _lib.on_device(dev):
+            _lib.check(L.nbd_gnn_train_forward_f32(ctypes.byref(a), _lib.current_stream(dev)), "nbd_gnn_train_forward_f32")
+        ctx.args, ctx.keep, ctx.lists = a, (x_in, ws, p, out.data_ptr()), lists      # (the output itself is not read back)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        import ctypes
+        from . import _lib
+        a, (x_in, ws, p, _), lists = ctx.args, ctx.keep, ctx.lists
+        dev = x_in.device
+        dout = dout if (dout.stride(1) == 1 and dout.dtype == torch.float32) else dout.contiguous().float()
+        rowptr_t, tgt_t = lists.by_source()
+        a.rowptr_t, a.tgt_t = rowptr_t.data_ptr(), tgt_t.data_ptr()
+        grads = [torch.empty_like(t) for t in p]
+        g = _lib.GnnTrainGrads()
+        k = 0
+        for i in range(a.n_enc):
+            g.enc_w[i], g.enc_b[i] = grads[k].data_ptr(), grads[k + 1].data_ptr()
+            k += 2
+        for l in range(a.n_layers):
+            g.w1[l], g.b1[l], g.w2[l], g.b2[l] = (grads[k + j].data_ptr() for j in range(4))
+            k += 4
+        g.ln_g, g.ln_b = grads[k].data_ptr(), grads[k + 1].data_ptr()
+        k += 2
+        for i in range(a.n_head):
+            g.head_w[i], g.head_b[i] = grads[k].data_ptr(), grads[k + 1].data_ptr()
+            k += 2
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().nbd_gnn_train_backward_f32(ctypes.byref(a), dout.data_ptr(), dout.stride(0), ctypes.byref(g),
+                                                             _lib.current_stream(dev)), "nbd_gnn_train_backward_f32")
+        return (None, None, None, *grads)

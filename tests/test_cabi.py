@@ -4,6 +4,7 @@ import ctypes
 import glob
 import os
 import re
+import sys
 
 import pytest
 
@@ -97,3 +98,17 @@ def test_no_cpu_path():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):
             simulation.LeapFrogSimulator(positions=z, velocities=z, masses=np.ones(4))
+
+
+def test_fused_contconv_prefetch_survives_the_compiler():
+    """The fused ContinuousConv kernel keeps the next cell's filter fragment in flight behind a hand-counted
+    `s_waitcnt vmcnt(8)` issued from inline asm, which hipcc's own wait insertion does not track: nothing may touch
+    the fragment registers between a load and its wait, and the kernel must stay within 128 VGPRs / its two known
+    spills (tools/check_contconv_isa.py disassembles the gfx950 code and checks exactly that; no GPU needed)."""
+    import shutil
+    if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_contconv_isa
+    ok, report = check_contconv_isa.main()
+    assert ok, report
