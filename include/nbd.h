@@ -253,6 +253,10 @@ int nbd_csr_by_key_i64(const int64_t* key, const int64_t* val, int64_t n_edges, 
 /* ptr[0] = 0, ptr[i+1] = ptr[i] + counts[i]  (int32, n counts -> n+1 entries). */
 int nbd_exclusive_scan_i32(const int* counts, int n, int* ptr, nbd_stream_t stream);
 
+/* rowptr[0 .. n] of an edge list whose targets are already in ascending order (knn_graph's output, and the collation of
+ * such graphs): rowptr[i] = first edge with tgt >= i. One launch. */
+int nbd_rowptr_sorted_i64(const int64_t* tgt, int64_t n_edges, int n, int* rowptr, nbd_stream_t stream);
+
 /* ELL lists -> compact int64 edge_index[2][num_edges] (what radius_graph returns). */
 int nbd_ell_to_edge_index(const int* nbr, const int* deg, const int* ptr, int n, int cap, int64_t num_edges,
                           int64_t* edge_index, nbd_stream_t stream);
@@ -384,6 +388,11 @@ int nbd_colsum_f32(const float* x, int ldx, const float* rowweight, int n, int c
 size_t nbd_linear_wgrad_workspace_bytes(int n, int m, int k);
 int nbd_linear_wgrad_f32(const float* g, int ldg, const float* x, int ldx, int n, int m, int k, float* dw, int lddw,
                          void* workspace, size_t workspace_bytes, nbd_stream_t stream);
+/* The same with the bias gradient in the same launches: db[m] = sum_n rowweight[n] * g[n][m] (rowweight NULL = 1) as one
+ * more column of the product (what nbd_colsum_f32 would return; its own summation order, fixed). */
+size_t nbd_linear_wgrad_bias_workspace_bytes(int n, int m, int k);
+int nbd_linear_wgrad_bias_f32(const float* g, int ldg, const float* x, int ldx, const float* rowweight, int n, int m, int k,
+                              float* dw, int lddw, float* db, void* workspace, size_t workspace_bytes, nbd_stream_t stream);
 
 /* Backward of nbd_edgeconv_aggregate_f32 for aggr 0 (sum) / 1 (mean): dpq[n][2h] = [dP | dQ] from ds[n][h].
  * (rowptr | fixed_k, src): the forward's by-target lists; (rowptr_t, tgt_t): the same edges grouped by
@@ -515,6 +524,19 @@ size_t nbd_contconv_filter_grad_workspace_bytes(int n, int n_cells, int in_chann
 int nbd_contconv_filter_grad_f32(const float* feat, int ldf, int in_channels, const float* g, int ldg, int out_channels,
                                  const int* rowptr, int n, int64_t edge_capacity, const void* pair_lists, int n_cells,
                                  float* dfilters, void* workspace, size_t workspace_bytes, nbd_stream_t stream);
+/* The same gradient laid out over the FULL filter grid (cells_total = D^3 cells of in x out; cell_map int32
+ * [cells_total] -> compact cell or -1, NULL when every cell is kept): unreachable cells get exact zeros -- the
+ * reference's (D, D, D, in, out) `.grad` in one call. workspace >= n_cells * in * out * 4 +
+ * nbd_contconv_filter_grad_workspace_bytes(...) bytes. */
+int nbd_contconv_filter_grad_full_f32(const float* feat, int ldf, int in_channels, const float* g, int ldg, int out_channels,
+                                      const int* rowptr, int n, int64_t edge_capacity, const void* pair_lists, int n_cells,
+                                      const int* cell_map, int cells_total, float* dfilters_full, void* workspace,
+                                      size_t workspace_bytes, nbd_stream_t stream);
+/* filters (cells_total, in, out) row-major -> filters_shuffled, the fragment order nbd_contconv_fused_f32 reads, over the
+ * kept cells kept_cells[0 .. n_cells) (int64 indices into the full grid, ascending). transposed = 1 re-lays every cell's
+ * filter TRANSPOSED (the operand of the feature gradient: in / out swapped). nbd_contconv_filter_floats floats out. */
+int nbd_contconv_shuffle_filters_f32(const float* filters, const int64_t* kept_cells, int n_cells, int in_channels,
+                                     int out_channels, int transposed, float* filters_shuffled, nbd_stream_t stream);
 /* Byte offsets of the sections of a pair-list buffer (for reports and tests; the layout is otherwise opaque):
  * [0] per-(tile, cell) descriptors, [1] rows, [2] pair sources, [3] pair weights, [4] step records (int4 per 16-row
  * step), [5] steps per tile (int32 [tiles], tiles = ceil(n / NBD_CC_TILE)), [6] cost per tile (int32 [tiles]),

@@ -371,6 +371,57 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------- plan
+// Once per pair list (one workgroup per job, right behind the pair kernel): tile_base[t] = first step of tile t in the
+// global step sequence, cuts[w] = first step of persistent workgroup w's range -- the sequence cut where the running cost
+// crosses w / G of its total: cut(w) = first step whose cost-before is >= B_w = C w / G. Every w is one thread: two
+// binary searches (tile by cost prefix, step by the running cost inside the tile).
+struct PlanJob { const int* tile_nsteps; const int* tile_cost; const int4* steps; const int* rowptr; int n_cells; int* cuts; int* tile_base; int* cost_base; };
+struct PlanJobs { PlanJob j[NBD_CC_MAX_RES]; };
+__global__ __launch_bounds__(1024) void contconv_plan_kernel(const PlanJobs jobs, int n_tiles, int G) {
+  const PlanJob& J = jobs.j[blockIdx.x];
+  __shared__ int red[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int scarry = 0, ccarry = 0;
+  for (int c0 = 0; c0 < n_tiles; c0 += 1024) {
+    const int t = c0 + tid;
+    const int vs = t < n_tiles ? max(J.tile_nsteps[t], 0) : 0;      // -1: a tile the pair kernel refused
+    const int vc = (t < n_tiles && J.tile_nsteps[t] > 0) ? J.tile_cost[t] : 0;
+    const int is = wave_incl_scan(vs, lane), ic = wave_incl_scan(vc, lane);
+    __syncthreads();
+    if (lane == 63) { red[0][wave] = is; red[1][wave] = ic; }
+    __syncthreads();
+    int os = 0, oc = 0, ts = 0, tc = 0;
+    for (int i = 0; i < 16; ++i) { const int x = red[0][i], y = red[1][i]; os += i < wave ? x : 0; oc += i < wave ? y : 0; ts += x; tc += y; }
+    if (t < n_tiles) { J.tile_base[t] = scarry + os + is - vs; J.cost_base[t] = ccarry + oc + ic - vc; }
+    scarry += ts; ccarry += tc;
+  }
+  if (tid == 0) { J.tile_base[n_tiles] = scarry; J.cost_base[n_tiles] = ccarry; }
+  __threadfence_block();
+  __syncthreads();
+  const int T = scarry;
+  const long long Ctot = ccarry;
+  for (int w = tid; w <= G; w += 1024) {
+    int cut;
+    if (w == 0 || Ctot == 0) cut = w == G ? T : 0;
+    else if (w >= G) cut = T;
+    else {
+      const int B = (int)(Ctot * w / G);
+      int lo = 0, hi = n_tiles - 1;                          // smallest t with cost_base[t + 1] > B
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (J.cost_base[mid + 1] > B) hi = mid; else lo = mid + 1; }
+      const int t = lo, rel = B - J.cost_base[t], sb = J.tile_base[t], ns = J.tile_base[t + 1] - sb;
+      if (rel == 0) cut = sb;
+      else {
+        const int4* ts_ = J.steps + step_base(t, J.rowptr[t * TN], J.n_cells);
+        int a = 0, b = ns;                                   // steps i with running cost ts_[i].w < rel (.w increases)
+        while (a < b) { const int mid = (a + b) >> 1; if (ts_[mid].w < rel) a = mid + 1; else b = mid; }
+        cut = sb + min(1 + a, ns);
+      }
+    }
+    J.cuts[w] = cut;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- fused conv
 // grid = (persistent workgroups, 1, column groups of 128); block = 1024 threads: waves 0-7 consume (MFMA, 16 output
 // columns each), waves 8-15 produce (gather + sum of the packed A rows; producer p owns ring buffer p).
@@ -484,7 +535,8 @@ __host__ __device__ inline int range_begin(long long T, int w, int G) { return (
 struct CCArgs {
   const float* feat; int ldf, I; const int* rowptr; int n, n_tiles;
   const int2* rows; const int* pair_src; const float* pair_w; const int4* steps; const int* tile_nsteps; const int* tile_cost;
-  int* cuts;           // [gridDim.x + 1] first step of every workgroup's range, written here, read by the finishing kernel
+  const int* cuts;     // [CC_GRID + 1] first step of every workgroup's range ...
+  const int* tile_base;   // ... and [tiles + 1] first step of every tile: the plan, computed once per pair list (contconv_plan_kernel)
   const f4* filt; int n_cells, kq_count, colblocks, OP; float* partial;
 };
 
@@ -522,23 +574,12 @@ __device__ __forceinline__ void cc_load_table(const CCArgs& A, const CCLds& L, i
   __syncthreads();
   if (tid == 0) *L.s_nseg = 0;
   __syncthreads();
-  int carry = 0;
-  for (int c0 = 0; c0 < A.n_tiles && carry < p1; c0 += CC_THREADS) {
-    const int t = c0 + tid;
-    const int v = t < A.n_tiles ? max(A.tile_nsteps[t], 0) : 0;      // -1: a tile the pair kernel refused (see there)
-    const int incl = wave_incl_scan(v, lane);
-    if (lane == 63) L.s_red[wave] = incl;
-    __syncthreads();
-    int woff = 0, tot = 0;
-    for (int i = 0; i < CC_THREADS / 64; ++i) { const int x = L.s_red[i]; woff += i < wave ? x : 0; tot += x; }
-    tot = UNI(tot);
-    const int base = carry + woff + incl - v;
+  for (int t = tid; t < A.n_tiles; t += CC_THREADS) {
+    const int base = A.tile_base[t], v = A.tile_base[t + 1] - base;
     if (v > 0 && base < p1 && base + v > p0) {
       const int s = atomicAdd(L.s_nseg, 1);                        // order-free: every segment is copied whole
       L.seg[s] = t; L.seg[CC_CAP + s] = base; L.seg[2 * CC_CAP + s] = v;
     }
-    carry += tot;
-    __syncthreads();
   }
   __syncthreads();
   const int nseg = UNI(*L.s_nseg);
@@ -996,7 +1037,6 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
   // float[] it began at an 8-byte offset and every ds_read_b128 / ds_write_b64 took the unaligned path)
   extern __shared__ f4 lds_aligned[];
   __shared__ int statics[32 + NBUF * CC_CONSUMERS + 4];            // s_red[16], s_nseg, full[8], done[8][8], turn[4]
-  __shared__ int s_total, s_ctot, s_hit[4], s_red2[16];
   const CCLds L = cc_lds(reinterpret_cast<float*>(lds_aligned), statics);
   const int tid = threadIdx.x, lane = tid & 63, wave = UNI(tid >> 6);
 #ifdef NBD_CC_TRACE
@@ -1005,70 +1045,15 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
 #endif
   long long dbg_wait[4] = {0, 0, 0, 0};        // [0] time on the flags, [1] in the steps, [2] in the table loads, [3] whole role
 
-  // ---- this workgroup's range of the global step sequence. The sequence is cut where the running COST (per step:
-  // max(CC_COST_MIN, pairs)) crosses w / G of its total: equal matrix work where the tiles are sparse, equal gather work
-  // where they are dense (cut by step COUNT, the first persistent version left the densest workgroups running 1.4x the
-  // mean at D = 4: their producers, not their MFMAs, set the pace). cut(w) = first step whose cost-before is >= B_w.
-  {
-    int lc = 0, ls = 0;
-    for (int t = tid; t < A.n_tiles; t += CC_THREADS) { lc += A.tile_cost[t]; ls += max(A.tile_nsteps[t], 0); }
-    lc = wave_sum(lc); ls = wave_sum(ls);
-    if (lane == 0) { L.s_red[wave] = lc; s_red2[wave] = ls; }
-    __syncthreads();
-    if (tid == 0) {
-      int C = 0, T = 0;
-      for (int i = 0; i < CC_THREADS / 64; ++i) { C += L.s_red[i]; T += s_red2[i]; }
-      s_total = T; s_ctot = C;
-    }
-    if (tid < NBUF) L.full[tid] = 0;
-    if (tid < NBUF * CC_CONSUMERS + 4) L.done[tid] = 0;             // and turn[4] behind it
-    __syncthreads();
-  }
-  const int T = UNI(s_total);
-  const long long Ctot = UNI(s_ctot);
-  auto cut = [&](int w) -> int {                                   // all threads; a few barriers
-    if (w <= 0) return 0;
-    if (w >= (int)gridDim.x) return T;
-    const int B = (int)(Ctot * w / gridDim.x);
-    if (tid == 0) s_hit[0] = -1;
-    int cbase = 0, sbase = 0;
-    for (int c0 = 0; c0 < A.n_tiles; c0 += CC_THREADS) {
-      const int t = c0 + tid;
-      const int vc = t < A.n_tiles ? A.tile_cost[t] : 0, vs = t < A.n_tiles ? max(A.tile_nsteps[t], 0) : 0;
-      const int ic = wave_incl_scan(vc, lane), is = wave_incl_scan(vs, lane);
-      __syncthreads();
-      if (lane == 63) { L.s_red[wave] = ic; s_red2[wave] = is; }
-      __syncthreads();
-      int oc = 0, os = 0, tc = 0, ts = 0;
-      for (int i = 0; i < CC_THREADS / 64; ++i) {
-        const int x = L.s_red[i], y = s_red2[i];
-        oc += i < wave ? x : 0; os += i < wave ? y : 0; tc += x; ts += y;
-      }
-      const int cb = cbase + oc + ic - vc;
-      if (vc > 0 && cb <= B && B < cb + vc) { s_hit[0] = t; s_hit[1] = B - cb; s_hit[2] = sbase + os + is - vs; s_hit[3] = vs; }
-      cbase += UNI(tc); sbase += UNI(ts);
-    }
-    __syncthreads();
-    const int t = UNI(s_hit[0]);
-    if (t < 0) return T;                                           // B beyond the last step's start (cannot happen for w < G)
-    const int rel = UNI(s_hit[1]), sb = UNI(s_hit[2]), ns = UNI(s_hit[3]);
-    if (rel == 0) return sb;
-    const int4* ts_ = A.steps + step_base(t, UNI(A.rowptr[t * TN]), A.n_cells);
-    int cnt = 0;
-    for (int i = tid; i < ns; i += CC_THREADS) cnt += ts_[i].w < rel ? 1 : 0;      // steps i + 1 that start before rel
-    cnt = wave_sum(cnt);
-    __syncthreads();
-    if (lane == 0) L.s_red[wave] = cnt;
-    __syncthreads();
-    int tot = 0;
-    for (int i = 0; i < CC_THREADS / 64; ++i) tot += L.s_red[i];
-    return sb + min(1 + UNI(tot), ns);
-  };
-  const int g0 = cut(blockIdx.x), g1 = cut(blockIdx.x + 1);
-  if (tid == 0 && blockIdx.z == 0) {
-    A.cuts[blockIdx.x] = g0;
-    if (blockIdx.x + 1 == gridDim.x) A.cuts[gridDim.x] = g1;
-  }
+  // ---- this workgroup's range of the global step sequence: cut where the running COST (per step: max(CC_COST_MIN,
+  // pairs)) crosses w / G of its total -- equal matrix work where the tiles are sparse, equal gather work where they
+  // are dense (cut by step COUNT, the first persistent version left the densest workgroups running 1.4x the mean at
+  // D = 4: their producers, not their MFMAs, set the pace). The cuts are part of the pair lists (contconv_plan_kernel,
+  // once per graph and resolution): computing them here cost every launch ~20 us of barriers and dependent loads in
+  // front of its first step (two layers per rollout step share one graph).
+  if (tid < NBUF) L.full[tid] = 0;
+  if (tid < NBUF * CC_CONSUMERS + 4) L.done[tid] = 0;               // and turn[4] behind it
+  const int g0 = UNI(A.cuts[blockIdx.x]), g1 = UNI(A.cuts[blockIdx.x + 1]);
   if (g0 >= g1) return;                                            // uniform: the whole workgroup leaves
   for (int i = tid; i < TN * LDO / 4; i += CC_THREADS) reinterpret_cast<f4*>(L.out_acc)[i] = f4{0.f, 0.f, 0.f, 0.f};
   // (the first cc_load_table's barriers order the zeroing before any consumer's first scatter)
@@ -1090,22 +1075,20 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
 #endif
 }
 
-// out = act(scale * sum of the tile's partial slots), in workgroup order. grid (tiles, 4): 32 rows of a tile each.
+// out = act(scale * sum of the tile's partial slots), in workgroup order. grid (tiles, 4): 32 rows of a tile each
+// (graphs of < 64 tiles: (tiles, 16), 8 rows each -- a 2 000-node training batch spreads every tile over ~16 workgroups'
+// slots, and 64 blocks walking them serially took 40 us).
 // cuts[w] = first step of workgroup w's range (written by the fused kernel): the workgroups whose ranges meet the
 // tile's steps [base, base + cnt) are the ones that wrote a slot for it.
 __global__ __launch_bounds__(256) void contconv_stream_finish_kernel(
-    const float* __restrict__ partial, const int* __restrict__ tile_nsteps, const int* __restrict__ cuts, int n_tiles,
+    const float* __restrict__ partial, const int* __restrict__ tile_nsteps, const int* __restrict__ cuts,
+    const int* __restrict__ tile_base, int n_tiles,
     int G, const float* __restrict__ rowscale, int act, float* __restrict__ out, int ldo, int n, int O, int OP) {
-  __shared__ int s_lo[4];
   __shared__ int s_cut[CC_GRID + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
-  int lo = 0;
-  for (int t = tid; t < tile; t += 256) lo += max(tile_nsteps[t], 0);
-  lo = wave_sum(lo);
-  if (lane == 0) s_lo[wave] = lo;
+  const int tid = threadIdx.x, tile = blockIdx.x;
   for (int w = tid; w <= G; w += 256) s_cut[w] = cuts[w];
   __syncthreads();
-  const int base = s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3];
+  const int base = tile_base[tile];
   const int cnt = tile_nsteps[tile];
   int w_first = 0, w_last = -1;
   if (cnt > 0) {
@@ -1115,8 +1098,9 @@ __global__ __launch_bounds__(256) void contconv_stream_finish_kernel(
     w_last = a;
     while (w_last + 1 < G && s_cut[w_last + 1] < base + cnt) ++w_last;
   }
-  const int r0 = tile * TN + blockIdx.y * 32;
-  for (int e = tid; e < 32 * OP / 4; e += 256) {
+  const int rb = TN / gridDim.y;                                   // rows of the tile this block finishes
+  const int r0 = tile * TN + blockIdx.y * rb;
+  for (int e = tid; e < rb * OP / 4; e += 256) {
     const int rl = e / (OP / 4), c = (e - rl * (OP / 4)) * 4;
     const int row = r0 + rl;
     if (row >= n || c >= O) continue;
@@ -1143,12 +1127,12 @@ __global__ __launch_bounds__(256) void contconv_stream_finish_kernel(
 // dF[k][i][o] = sum over the touched blocks (node n, cell k) of A[n][k][i] * g[n][o], A[n][k] = the block's weighted
 // sum of gathered feature rows exactly as the forward kernel forms it, g = scale * act'(out) * dout (contconv.py:92-98
 // differentiated with respect to `filters`). The binned matrix is not formed here either.
-// grid (cells, slabs of tiles), 256 threads. A workgroup walks the rows of ITS cell through its slab's tiles, 16 at a
+// grid (cells, slabs of tiles), 1024 threads. A workgroup walks the rows of ITS cell through its slab's tiles, 16 at a
 // time -- rows of different tiles share a step (the contraction runs over rows: no padding but the last step's) --
-// and per step the four waves build the 16 A rows and copy the 16 g rows into LDS (double-buffered: one barrier per
-// step), then multiply A^T (I x 16) by g (16 x O) with v_mfma_f32_16x16x4_f32; wave w keeps the 4 x 4 blocks of
-// 16 x 16 of quadrant w of the I x O result in registers for the whole walk. One partial sum per slab, added in slab
-// order by the finishing kernel: deterministic, no float atomics.
+// and per step its sixteen waves build the 16 A rows (one each) and copy the 16 g rows into LDS (double-buffered: one
+// barrier per step), then multiply A^T (I x 16) by g (16 x O) with v_mfma_f32_16x16x4_f32; wave w keeps four 16 x 16
+// blocks of the I x O result in registers for the whole walk. One partial sum per slab, added in slab order by the
+// finishing kernel: deterministic, no float atomics.
 constexpr int WG_LD = 144;       // LDS row stride (floats): the four k-rows a fragment read touches land on distinct banks
 constexpr int WG_MAXT = 64;      // tiles per slab (one wave scans their row counts)
 
@@ -1159,7 +1143,13 @@ struct WGArgs {
   float* partial;              // [slabs][cells][I][O]
 };
 
-__global__ __launch_bounds__(256) void contconv_wgrad_kernel(const WGArgs A) {
+// 16 waves per workgroup: wave w builds row w of the step (in training batches the rows are SKEWED -- radius_graph keeps
+// the first 32 hits by index, so the low-index bodies of every graph are listed by everyone around them and their
+// blocks hold 50-100 pairs next to blocks of 3 -- and hub rows are consecutive: with four rows per wave a step of hubs
+// cost one wave 400 dependent-latency-bound pairs, 20 us per step, 220-350 us per launch in four successive forms of
+// this kernel), then multiplies one 16-row block of A^T by four 16-column blocks of g.
+constexpr int WG_WAVES = 16;
+__global__ __launch_bounds__(64 * WG_WAVES) void contconv_wgrad_kernel(const WGArgs A) {
   __shared__ __attribute__((aligned(16))) float a_s[2][16][WG_LD];
   __shared__ __attribute__((aligned(16))) float g_s[2][16][WG_LD];
   __shared__ int t_pref[WG_MAXT + 1], t_row0[WG_MAXT];
@@ -1187,119 +1177,108 @@ __global__ __launch_bounds__(256) void contconv_wgrad_kernel(const WGArgs A) {
   const bool live = 2 * lane < I;
   const int fo = min(2 * lane, I - 2);
 
-  // A wave builds four rows of a step. Its memory accesses form three dependent levels (row records -> pair records
-  // -> feature rows); every level is issued for all four rows at once, so a step costs three round trips, not twelve
-  // (the first version walked row after row: 174 us for the 2 000-node training batch). Rows of more than four pairs
-  // finish in a per-row loop.
+  // One row per wave: three dependent levels (row record -> pair records -> feature rows). The pair records of the row
+  // are fetched LANE-PARALLEL (lane i = the row's i-th pair: one coalesced load per array and 64 pairs), the feature rows
+  // with the source index broadcast out of its lane (v_readlane): the first 8 at once, then 24, then 32 per trip -- every
+  // trip inside one 64-record chunk, pairs summed in list order.
   auto gather = [&](int s, int buf) {
-    int p0[4], p1[4], node[4];
-    const int* ps[4];
-    const float* pw[4];
+    const int r = wave, q = 16 * s + r;
+    int p0 = 0, np = 0, node = 0;
+    const int* ps = A.pair_src;
+    const float* pw = A.pair_w;
+    if (q < R) {                                           // wave-uniform
+      int j = 0;
+      while (j + 1 < nt && t_pref[j + 1] <= q) ++j;        // the tile of row q (LDS broadcasts)
+      j = UNI(j);
+      const int tile = t0 + j;
+      const long long e8 = t_e8[j];
+      const int2* rw = A.rows + e8 + tile + t_row0[j] + (q - t_pref[j]);
+      const int2 rec = rw[0];
+      np = UNI(rw[1].y - rec.y); p0 = UNI(rec.y);
+      node = UNI(tile * TN + rec.x);
+      ps = A.pair_src + e8; pw = A.pair_w + e8;
+    }
+    const int at0 = p0 + min(lane, max(np - 1, 0));        // past the row's end: its last pair again, weight 0
+    int sr = np > 0 ? ps[at0] : 0;
+    float wr = lane < np ? pw[at0] : 0.f;
+    const float* gr = A.g + (size_t)node * A.ldg;
+    const float g0 = (np > 0 && lane < O) ? gr[lane] : 0.f;        // (a row of the lists always holds a pair)
+    const float g1 = (np > 0 && lane + 64 < O) ? gr[lane + 64] : 0.f;
+    f2 acc = {0.f, 0.f};
+    {
+      f2 v[8];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int q = 16 * s + wave * 4 + rr;
-      p0[rr] = 0; p1[rr] = 0; node[rr] = 0; ps[rr] = A.pair_src; pw[rr] = A.pair_w;
-      if (q < R) {                                         // wave-uniform
-        int j = 0;
-        while (j + 1 < nt && t_pref[j + 1] <= q) ++j;      // the tile of row q (LDS broadcasts)
-        j = UNI(j);
-        const int tile = t0 + j;
-        const long long e8 = t_e8[j];
-        const int2* rw = A.rows + e8 + tile + t_row0[j] + (q - t_pref[j]);
-        const int2 rec = rw[0];
-        p1[rr] = rw[1].y; p0[rr] = rec.y;
-        node[rr] = tile * TN + rec.x;
-        ps[rr] = A.pair_src + e8; pw[rr] = A.pair_w + e8;
+      for (int u = 0; u < 8; ++u)
+        v[u] = *reinterpret_cast<const f2*>(A.feat + (size_t)__builtin_amdgcn_readlane(sr, u) * A.ldf + fo);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wr), u));
+        acc = __builtin_elementwise_fma(f2{w, w}, v[u], acc);
       }
     }
-    int sidx[4][4];
-    float wv[4][4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      p0[rr] = UNI(p0[rr]); p1[rr] = UNI(p1[rr]); node[rr] = UNI(node[rr]);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool in = p0[rr] + u < p1[rr];
-        const int at = in ? p0[rr] + u : 0;                // a padding slot reads the tile's first pair with weight 0
-        sidx[rr][u] = ps[rr][at];
-        wv[rr][u] = in ? pw[rr][at] : 0.f;
+    for (int base = 8; base < np;) {                       // wave-uniform
+      const int next = base < 32 ? 32 : base + 32, len = next - base;
+      if ((base & 63) == 0) {                              // the next 64 records
+        const int at = p0 + min(base + lane, np - 1);
+        sr = ps[at];
+        wr = base + lane < np ? pw[at] : 0.f;
       }
-    }
-    f2 v[4][4];
-    float g0[4], g1[4];
+      f2 t[32];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const bool row_ok = 16 * s + wave * 4 + rr < R;
+      for (int u = 0; u < 32; ++u)
+        t[u] = *reinterpret_cast<const f2*>(A.feat + (size_t)__builtin_amdgcn_readlane(sr, min((base & 63) + u, 63)) * A.ldf + fo);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        v[rr][u] = *reinterpret_cast<const f2*>(A.feat + (size_t)UNI(sidx[rr][u]) * A.ldf + fo);
-      const float* gr = A.g + (size_t)node[rr] * A.ldg;
-      g0[rr] = (row_ok && lane < O) ? gr[lane] : 0.f;
-      g1[rr] = (row_ok && lane + 64 < O) ? gr[lane + 64] : 0.f;
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int r = wave * 4 + rr;
-      f2 acc = {0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float w = __int_as_float(UNI(__float_as_int(wv[rr][u])));
-        acc = __builtin_elementwise_fma(f2{w, w}, v[rr][u], acc);
+      for (int u = 0; u < 32; ++u) {
+        float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wr), min((base & 63) + u, 63)));
+        w = u < len ? w : 0.f;                             // (a 24-pair trip: the lanes of the next trip carry live weights)
+        acc = __builtin_elementwise_fma(f2{w, w}, t[u], acc);
       }
-      for (int p = p0[rr] + 4; p < p1[rr]; ++p) {          // the same order as the first four: pair after pair
-        const int si = UNI(ps[rr][p]);
-        const float w = __int_as_float(UNI(__float_as_int(pw[rr][p])));
-        acc = __builtin_elementwise_fma(f2{w, w}, *reinterpret_cast<const f2*>(A.feat + (size_t)si * A.ldf + fo), acc);
-      }
-      *reinterpret_cast<f2*>(&a_s[buf][r][2 * lane]) = live ? acc : f2{0.f, 0.f};
-      g_s[buf][r][lane] = g0[rr]; g_s[buf][r][lane + 64] = g1[rr];
+      base = next;
     }
+    *reinterpret_cast<f2*>(&a_s[buf][r][2 * lane]) = (live && np > 0) ? acc : f2{0.f, 0.f};      // padding rows: exact zeros
+    g_s[buf][r][lane] = g0; g_s[buf][r][lane + 64] = g1;
   };
 
-  const int ib0 = (wave >> 1) * 4, ob0 = (wave & 1) * 4;
+  // wave w multiplies 16-row block (w & 7) of A^T by the 16-column blocks 4 (w >> 3) .. + 3 of g
+  const int ib = wave & 7, ob0 = (wave >> 3) * 4;
   const int IB = (I + 15) >> 4, OB = (O + 15) >> 4;
-  f4v acc[4][4];
+  f4v acc[4];
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) acc[x][y] = f4v{0.f, 0.f, 0.f, 0.f};
+  for (int y = 0; y < 4; ++y) acc[y] = f4v{0.f, 0.f, 0.f, 0.f};
   if (nsteps > 0) gather(0, 0);
   __syncthreads();
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & 1;
     if (s + 1 < nsteps) gather(s + 1, buf ^ 1);
-    if (ib0 < IB && ob0 < OB) {
+    if (ib < IB && ob0 < OB) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int kr = kk * 4 + (lane >> 4), c = lane & 15;
-        float av[4], bv[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) av[x] = a_s[buf][kr][min(ib0 + x, 7) * 16 + c];
+        const float av = a_s[buf][kr][ib * 16 + c];
+        float bv[4];
 #pragma unroll
         for (int y = 0; y < 4; ++y) bv[y] = g_s[buf][kr][min(ob0 + y, 7) * 16 + c];
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-          for (int y = 0; y < 4; ++y)
-            if (ib0 + x < IB && ob0 + y < OB)            // wave-uniform
-              acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+        for (int y = 0; y < 4; ++y)
+          if (ob0 + y < OB)                                // wave-uniform
+            acc[y] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[y], acc[y], 0, 0, 0);
       }
     }
     __syncthreads();
   }
   float* dst = A.partial + ((size_t)slab * A.n_cells + k) * (size_t)I * O;
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
+  if (ib < IB) {
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
-      if (ib0 + x >= IB || ob0 + y >= OB) continue;
+      if (ob0 + y >= OB) continue;
       const int o = (ob0 + y) * 16 + (lane & 15);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const int i = (ib0 + x) * 16 + 4 * (lane >> 4) + v;
-        if (i < I && o < O) dst[(size_t)i * O + o] = acc[x][y][v];
+        const int i = ib * 16 + 4 * (lane >> 4) + v;
+        if (i < I && o < O) dst[(size_t)i * O + o] = acc[y][v];
       }
     }
+  }
 }
 
 // dfilters[e] = sum over slabs, in slab order
@@ -1310,6 +1289,53 @@ __global__ __launch_bounds__(256) void contconv_wgrad_finish_kernel(const float*
   float v = slabs > 0 ? partial[e] : 0.f;                  // no slabs (no nodes): the gradient is zero
   for (int s = 1; s < slabs; ++s) v += partial[(size_t)s * per_slab + e];
   out[e] = v;
+}
+
+// dfilters over the FULL grid: cell c of the D^3 grid takes the sum of the slabs of its compact cell cell_map[c], or an
+// exact zero when no sample can reach it (cell_map[c] < 0) -- the (D, D, D, I, O) gradient tensor in one launch
+// (torch.zeros + index_copy_ before)
+__global__ __launch_bounds__(256) void contconv_wgrad_finish_full_kernel(const float* __restrict__ partial, int slabs, int n_cells,
+                                                                         int io, const int* __restrict__ cell_map, int d3,
+                                                                         float* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)d3 * io) return;
+  const int c = (int)(e / io), r = (int)(e - (size_t)c * io);
+  const int k = cell_map ? cell_map[c] : c;
+  float v = 0.f;
+  if (k >= 0) {
+    const size_t per_slab = (size_t)n_cells * io, at = (size_t)k * io + r;
+    for (int s = 0; s < slabs; ++s) v += partial[(size_t)s * per_slab + at];
+  }
+  out[e] = v;
+}
+
+// filters (cells_total, I, O) -> the fused kernel's MFMA fragment order over the kept cells (include/nbd.h):
+// float index ((((cell * CB + cb) * G + g) * 64 + lane) * 4 + j) = F[kept[cell]][16 g + 4 (lane >> 4) + j][16 cb + (lane & 15)],
+// zero beyond I / O; transposed = 1 re-lays F^T (in / out swapped: the feature gradient's operand). One thread per
+// (cell, cb, g, lane): four strided reads, one 16-byte store. (Five torch launches per call before, four calls per
+// training step.)
+__global__ __launch_bounds__(256) void contconv_shuffle_kernel(const float* __restrict__ f, const int64_t* __restrict__ kept,
+                                                               int n_cells, int I, int O, int transposed, f4* __restrict__ out) {
+  const int Ii = transposed ? O : I, Oo = transposed ? I : O;           // the operand's own in / out
+  const int G = (Ii + 15) >> 4, CB = (Oo + 15) >> 4;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)n_cells * CB * G * 64) return;
+  const int lane = (int)(idx & 63);
+  size_t rest = idx >> 6;
+  const int g = (int)(rest % G); rest /= G;
+  const int cb = (int)(rest % CB);
+  const int cell = (int)(rest / CB);
+  const float* src = f + (size_t)kept[cell] * I * O;
+  const int col = 16 * cb + (lane & 15);
+  f4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int kk = 16 * g + 4 * (lane >> 4) + j;
+    float x = 0.f;
+    if (kk < Ii && col < Oo) x = transposed ? src[(size_t)col * O + kk] : src[(size_t)kk * O + col];
+    v[j] = x;
+  }
+  out[idx] = v;
 }
 
 inline void wgrad_plan(int n, int n_cells, int* slabs, int* tiles_per_slab) {
@@ -1342,7 +1368,7 @@ int nbd_contconv_fused_supported(int in_channels, int out_channels, int n_cells)
 }
 
 namespace {
-struct PairsLayout { size_t desc, rows, src, w, steps, nsteps, cost, scale, total; };
+struct PairsLayout { size_t desc, rows, src, w, steps, nsteps, cost, scale, cuts, tbase, cbase, total; };
 PairsLayout pairs_layout(int n, int64_t edge_capacity, int n_cells) {
   const size_t tiles = (size_t)ceil_div(n, TN);
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -1356,6 +1382,9 @@ PairsLayout pairs_layout(int n, int64_t edge_capacity, int n_cells) {
   L.nsteps = at; at += up(tiles * sizeof(int));
   L.cost = at; at += up(tiles * sizeof(int));
   L.scale = at; at += up((size_t)n * sizeof(float));
+  L.cuts = at; at += up((CC_GRID + 1) * sizeof(int));          // the plan (contconv_plan_kernel)
+  L.tbase = at; at += up((tiles + 1) * sizeof(int));
+  L.cbase = at; at += up((tiles + 1) * sizeof(int));
   L.total = at + 256;
   return L;
 }
@@ -1380,6 +1409,7 @@ int nbd_contconv_pairs_jobs_f32(const float* pos, int n, float radius_sq, int n_
   if (n == 0) return 0;
   if (!pos) return NBD_E_BADARG;
   PairJobs jobs;
+  PlanJobs plans;
   int kc_max = 0;
   for (int r = 0; r < n_jobs; ++r) {
     const nbd_cc_pairs_job& q = jd[r];
@@ -1400,10 +1430,14 @@ int nbd_contconv_pairs_jobs_f32(const float* pos, int n, float radius_sq, int n_
     j.steps = reinterpret_cast<int4*>(base + L.steps); j.tile_nsteps = reinterpret_cast<int*>(base + L.nsteps);
     j.tile_cost = reinterpret_cast<int*>(base + L.cost);
     j.inv_deg = reinterpret_cast<float*>(base + L.scale);
+    PlanJob& pj = plans.j[r];
+    pj.tile_nsteps = j.tile_nsteps; pj.tile_cost = j.tile_cost; pj.steps = j.steps; pj.rowptr = q.rowptr; pj.n_cells = nc;
+    pj.cuts = reinterpret_cast<int*>(base + L.cuts); pj.tile_base = reinterpret_cast<int*>(base + L.tbase);
+    pj.cost_base = reinterpret_cast<int*>(base + L.cbase);
     const int kc = (nc + 3) & ~3;
     if (kc > kc_max) kc_max = kc;
   }
-  for (int r = n_jobs; r < NBD_CC_MAX_RES; ++r) jobs.j[r] = jobs.j[0];
+  for (int r = n_jobs; r < NBD_CC_MAX_RES; ++r) { jobs.j[r] = jobs.j[0]; plans.j[r] = plans.j[0]; }
   const size_t lds = (size_t)TN * kc_max / 2 * 4 + (size_t)TN * kc_max * 4 + (size_t)TN * kc_max;
   {   // > 64 KiB of dynamic LDS needs the opt-in (a per-function attribute, idempotent)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(contconv_pairs_kernel),
@@ -1411,6 +1445,9 @@ int nbd_contconv_pairs_jobs_f32(const float* pos, int n, float radius_sq, int n_
     if (e != hipSuccess) return (int)e;
   }
   contconv_pairs_kernel<<<dim3(ceil_div(n, TN), n_jobs), PAIR_THREADS, lds, (hipStream_t)stream>>>(pos, n, radius_sq, jobs);
+  int rc = status();
+  if (rc) return rc;
+  contconv_plan_kernel<<<n_jobs, 1024, 0, (hipStream_t)stream>>>(plans, ceil_div(n, TN), CC_GRID);
   return status();
 }
 
@@ -1477,13 +1514,14 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
   const int* tile_nsteps = reinterpret_cast<const int*>(base + L.nsteps);
   const int* tile_cost = reinterpret_cast<const int*>(base + L.cost);
   const int tiles = ceil_div(n, TN), colgroups = ceil_div(out_channels, 128), OP = colgroups * 128;
-  int* cuts = static_cast<int*>(workspace);
+  const int* cuts = reinterpret_cast<const int*>(base + L.cuts);        // (the workspace keeps its 4 KiB header: unused now)
+  const int* tile_base = reinterpret_cast<const int*>(base + L.tbase);
   float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + CC_CUTS_BYTES);
   const dim3 grid(CC_GRID, 1, colgroups);
   const int kq_count = ceil_div(in_channels, 16);
   CCArgs A;
   A.feat = feat; A.ldf = ldf; A.I = in_channels; A.rowptr = rowptr; A.n = n; A.n_tiles = tiles;
-  A.rows = rows; A.pair_src = pair_src; A.pair_w = pair_w; A.steps = steps; A.tile_nsteps = tile_nsteps; A.tile_cost = tile_cost; A.cuts = cuts;
+  A.rows = rows; A.pair_src = pair_src; A.pair_w = pair_w; A.steps = steps; A.tile_nsteps = tile_nsteps; A.tile_cost = tile_cost; A.cuts = cuts; A.tile_base = tile_base;
   A.filt = reinterpret_cast<const f4*>(filters_shuffled); A.n_cells = n_cells; A.kq_count = kq_count;
   A.colblocks = ceil_div(out_channels, 16); A.OP = OP; A.partial = partial;
 #define CC_LAUNCH(K)                                                                                                \
@@ -1497,7 +1535,7 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
 #undef CC_LAUNCH
   int rc = status();
   if (rc) return rc;
-  contconv_stream_finish_kernel<<<dim3(tiles, 4), 256, 0, st>>>(partial, tile_nsteps, cuts, tiles, CC_GRID, rowscale, act, out,
+  contconv_stream_finish_kernel<<<dim3(tiles, tiles >= 64 ? 4 : 16), 256, 0, st>>>(partial, tile_nsteps, cuts, tile_base, tiles, CC_GRID, rowscale, act, out,
                                                                  ldo, n, out_channels, OP);
   return status();
 }
@@ -1536,10 +1574,41 @@ int nbd_contconv_filter_grad_f32(const float* feat, int ldf, int in_channels, co
   A.pair_src = reinterpret_cast<const int*>(base + L.src); A.pair_w = reinterpret_cast<const float*>(base + L.w);
   A.tile_nsteps = reinterpret_cast<const int*>(base + L.nsteps);
   A.partial = S > 1 ? static_cast<float*>(workspace) : dfilters;
-  contconv_wgrad_kernel<<<dim3(n_cells, S), 256, 0, st>>>(A);
+  contconv_wgrad_kernel<<<dim3(n_cells, S), 64 * WG_WAVES, 0, st>>>(A);
   int rc = status();
   if (rc || S == 1) return rc;
   contconv_wgrad_finish_kernel<<<ceil_div((int)per_slab, 256), 256, 0, st>>>(A.partial, S, per_slab, dfilters);
+  return status();
+}
+
+int nbd_contconv_shuffle_filters_f32(const float* filters, const int64_t* kept_cells, int n_cells, int in_channels,
+                                     int out_channels, int transposed, float* filters_shuffled, nbd_stream_t stream) {
+  if (n_cells <= 0 || in_channels <= 0 || out_channels <= 0 || !filters || !kept_cells || !filters_shuffled) return NBD_E_BADARG;
+  if (reinterpret_cast<uintptr_t>(filters_shuffled) & 15) return NBD_E_BADARG;
+  const int Ii = transposed ? out_channels : in_channels, Oo = transposed ? in_channels : out_channels;
+  const size_t quads = (size_t)n_cells * ceil_div(Oo, 16) * ceil_div(Ii, 16) * 64;
+  contconv_shuffle_kernel<<<(unsigned)((quads + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      filters, kept_cells, n_cells, in_channels, out_channels, transposed ? 1 : 0, reinterpret_cast<f4*>(filters_shuffled));
+  return status();
+}
+
+int nbd_contconv_filter_grad_full_f32(const float* feat, int ldf, int in_channels, const float* g, int ldg, int out_channels,
+                                      const int* rowptr, int n, int64_t edge_capacity, const void* pair_lists, int n_cells,
+                                      const int* cell_map, int cells_total, float* dfilters_full, void* workspace,
+                                      size_t workspace_bytes, nbd_stream_t stream) {
+  if (cells_total < n_cells || (!cell_map && cells_total != n_cells) || !dfilters_full) return NBD_E_BADARG;
+  const size_t compact = (size_t)n_cells * in_channels * out_channels * sizeof(float);
+  const size_t inner = nbd_contconv_filter_grad_workspace_bytes(n, n_cells, in_channels, out_channels);
+  // workspace: [compact gradient][the slab partials of nbd_contconv_filter_grad_f32]
+  if (!workspace || workspace_bytes < compact + inner || (reinterpret_cast<uintptr_t>(workspace) & 15)) return NBD_E_WORKSPACE;
+  float* dcompact = static_cast<float*>(workspace);
+  int rc = nbd_contconv_filter_grad_f32(feat, ldf, in_channels, g, ldg, out_channels, rowptr, n, edge_capacity, pair_lists,
+                                        n_cells, dcompact, static_cast<char*>(workspace) + compact, inner, stream);
+  if (rc) return rc;
+  const int io = in_channels * out_channels;
+  const size_t total = (size_t)cells_total * io;
+  contconv_wgrad_finish_full_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      dcompact, 1, n_cells, io, cell_map, cells_total, dfilters_full);
   return status();
 }
 

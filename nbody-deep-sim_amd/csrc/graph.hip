@@ -710,6 +710,18 @@ __global__ __launch_bounds__(256) void ell_to_edges_kernel(const int* __restrict
   edge_index[e_total + e] = i;
 }
 
+// rowptr[i] = first edge whose (ascending) target is >= i: the CSR of an edge list already grouped by ascending target
+// (what knn_graph and the collation of such graphs produce) in one launch -- the torch route (bincount, cumsum, cast,
+// assignment) was five launches and 0.1 ms of host time in front of every training step
+__global__ __launch_bounds__(256) void rowptr_sorted_kernel(const int64_t* __restrict__ tgt, int64_t e, int n,
+                                                            int* __restrict__ rowptr) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > n) return;
+  int64_t lo = 0, hi = e;                                  // first index with tgt[index] >= i
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (tgt[mid] < i) lo = mid + 1; else hi = mid; }
+  rowptr[i] = (int)lo;
+}
+
 // Zero fill as a kernel of our own: hipMemsetAsync nodes captured into a hipGraph did not re-execute on
 // replay on this stack (ROCm 7.2 + torch 2.10 stream capture) -- the counters below then kept their
 // previous values, the second replay doubled every in-degree and the scatter ran off its buffer.
@@ -1015,6 +1027,12 @@ int nbd_csr_by_key_i64(const int64_t* key, const int64_t* val, int64_t n_edges, 
 int nbd_exclusive_scan_i32(const int* counts, int n, int* ptr, nbd_stream_t stream) {
   if (n < 0 || !ptr || (n > 0 && !counts)) return NBD_E_BADARG;
   exclusive_scan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(counts, n, ptr);
+  return status();
+}
+
+int nbd_rowptr_sorted_i64(const int64_t* tgt, int64_t n_edges, int n, int* rowptr, nbd_stream_t stream) {
+  if (n < 0 || n_edges < 0 || n_edges > 0x7fffffffLL || !rowptr || (n_edges > 0 && !tgt)) return NBD_E_BADARG;
+  rowptr_sorted_kernel<<<ceil_div(n + 1, 256), 256, 0, (hipStream_t)stream>>>(tgt, n_edges, n, rowptr);
   return status();
 }
 

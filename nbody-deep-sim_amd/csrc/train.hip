@@ -83,22 +83,26 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   if (ph == 0 && col < c)
     part[(size_t)blockIdx.x * c + col] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
-// stage 2: thread = column (coalesced reads of each partial row); the loop over blocks is unrolled by
-// four independent accumulators so that the loads overlap -- still one fixed summation order
+// stage 2: grid = 64-column groups; the block's 256 threads are 4 phases x 64 columns, phase p adds the partial rows
+// p, p + 4, ... (two accumulators each: loads in flight together), the four phase sums meet in LDS -- one fixed
+// summation order. (Thread = column walking all partial rows: 10 us for the 74 partial rows of a 9 458-row batch.)
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int ldpart, int blocks,
                                                            int c, float* __restrict__ out) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= c) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 4 <= blocks; b += 4) {
-    s0 += part[(size_t)b * ldpart + col];
-    s1 += part[(size_t)(b + 1) * ldpart + col];
-    s2 += part[(size_t)(b + 2) * ldpart + col];
-    s3 += part[(size_t)(b + 3) * ldpart + col];
+  __shared__ float red[256];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < c) {
+    int b = ph;
+    for (; b + 4 < blocks; b += 8) {
+      s0 += part[(size_t)b * ldpart + col];
+      s1 += part[(size_t)(b + 4) * ldpart + col];
+    }
+    if (b < blocks) s0 += part[(size_t)b * ldpart + col];
   }
-  for (; b < blocks; ++b) s0 += part[(size_t)b * ldpart + col];
-  out[col] = (s0 + s1) + (s2 + s3);
+  red[threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (ph == 0 && col < c)
+    out[col] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
 // ------------------------------------------------------------------ weight gradient: dW = G^T X
@@ -107,9 +111,14 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 // a stride of 96 floats (== 32 mod 64 banks), so that the MFMA operand reads -- lanes 0-31: 32
 // consecutive columns of row r, lanes 32-63: the same columns of row r+1 -- touch 64 distinct banks.
 constexpr int WG_T = 64, WG_R = 32, WG_LD = 96;
+// With `db` the bias gradient rides along as one more column of X: column k holds the row weight (1 without), so
+// output column k is db[m] = sum_n w_n g[n][m] -- the two launches of a separate column sum are gone (a training step
+// has eleven Linears; its backward pass is bounded by launches, tools/train_phases.py).
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X,
                                                     int ldx, int n, int m, int k, int rows_per_slab,
-                                                    float* __restrict__ out, int ldo, size_t slab_stride) {
+                                                    float* __restrict__ out, int ldo, size_t slab_stride,
+                                                    const float* __restrict__ roww = nullptr, float* __restrict__ db = nullptr,
+                                                    int with_bias = 0) {
   __shared__ float gs[WG_R * WG_LD], xs[WG_R * WG_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wk = wave >> 1;
   const int m0 = blockIdx.x * WG_T, k0 = blockIdx.y * WG_T;
@@ -121,14 +130,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G,
   // The next stage's 32 rows travel to registers while this stage multiplies (one global-load latency per stage was
   // the whole cost of a 2 000-row gradient: 26 us for 64 MFMAs).
   float gr[WG_R / 4], xr[WG_R / 4];
-  const bool gcol = m0 + lc < m, xcol = k0 + lc < k;
+  const bool gcol = m0 + lc < m, xcol = k0 + lc < k, bcol = with_bias && k0 + lc == k;
   auto fetch = [&](int r0) {
 #pragma unroll
     for (int u = 0; u < WG_R / 4; ++u) {
       const int row = r0 + lr + 4 * u;
       const bool ok = row < r_end;
       gr[u] = (ok && gcol) ? G[(size_t)row * ldg + m0 + lc] : 0.f;
-      xr[u] = (ok && xcol) ? X[(size_t)row * ldx + k0 + lc] : 0.f;
+      xr[u] = (ok && xcol) ? X[(size_t)row * ldx + k0 + lc] : (ok && bcol) ? (roww ? roww[row] : 1.0f) : 0.f;
     }
   };
   if (r_begin < r_end) fetch(r_begin);
@@ -154,15 +163,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G,
   for (int r = 0; r < 16; ++r) {
     const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (row < m && col < k) o[(size_t)row * ldo + col] = acc[r];
+    if (row < m && with_bias && col == k) {               // slabs: the extra column of the slab; one slab: db itself
+      if (db) db[row] = acc[r]; else o[(size_t)row * ldo + k] = acc[r];
+    }
   }
 }
+// kk = k (+ 1 with the bias column): slabs are m x kk; column k goes to db
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ slabs, int n_slabs, int m, int k,
-                                                           float* __restrict__ dw, int lddw) {
+                                                           float* __restrict__ dw, int lddw, int kk = 0,
+                                                           float* __restrict__ db = nullptr) {
+  if (kk == 0) kk = k;
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= m * k) return;
-  float s = 0.f;
-  for (int b = 0; b < n_slabs; ++b) s += slabs[(size_t)b * m * k + idx];
-  dw[(size_t)(idx / k) * lddw + idx % k] = s;
+  if (idx >= m * kk) return;
+  float s0 = 0.f, s1 = 0.f;
+  int b = 0;
+  for (; b + 2 <= n_slabs; b += 2) {                      // two chains: the loads of a pair of slabs travel together
+    s0 += slabs[(size_t)b * m * kk + idx];
+    s1 += slabs[(size_t)(b + 1) * m * kk + idx];
+  }
+  if (b < n_slabs) s0 += slabs[(size_t)b * m * kk + idx];
+  const float s = s0 + s1;
+  const int row = idx / kk, col = idx - row * kk;
+  if (col < k) dw[(size_t)row * lddw + col] = s; else db[row] = s;
 }
 struct WgradPlan { int slabs, rows_per_slab; size_t ws; };
 WgradPlan plan_wgrad(int n, int m, int k) {
@@ -486,13 +508,45 @@ int nbd_colsum_f32(const float* x, int ldx, const float* rowweight, int n, int c
   if (n > 0 && (!workspace || workspace_bytes < nbd_colsum_workspace_bytes(n, c))) return NBD_E_BADARG;
   float* part = static_cast<float*>(workspace);
   if (n > 0) colsum_partial_kernel<<<dim3(blocks, ceil_div(c, 64)), 256, 0, st>>>(x, ldx, rowweight, n, c, part);
-  colsum_final_kernel<<<ceil_div(c, 256), 256, 0, st>>>(part, c, blocks, c, out);
+  colsum_final_kernel<<<ceil_div(c, 64), 256, 0, st>>>(part, c, blocks, c, out);
   return status();
 }
 
 size_t nbd_linear_wgrad_workspace_bytes(int n, int m, int k) {
   if (n <= 0 || m <= 0 || k <= 0) return 0;
   return plan_wgrad(n, m, k).ws;
+}
+
+size_t nbd_linear_wgrad_bias_workspace_bytes(int n, int m, int k) {
+  if (n <= 0 || m <= 0 || k <= 0) return 0;
+  const WgradPlan p = plan_wgrad(n, m, k + 1);
+  return p.slabs > 1 ? (size_t)p.slabs * m * (k + 1) * sizeof(float) : 0;
+}
+
+int nbd_linear_wgrad_bias_f32(const float* g, int ldg, const float* x, int ldx, const float* rowweight, int n, int m, int k,
+                              float* dw, int lddw, float* db, void* workspace, size_t workspace_bytes, nbd_stream_t stream) {
+  if (n < 0 || m < 0 || k < 0) return NBD_E_BADARG;
+  if (m == 0) return 0;
+  if (!db || (k > 0 && (!dw || lddw < k)) || (n > 0 && (!g || ldg < m || (k > 0 && (!x || ldx < k))))) return NBD_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ceil_div(m, WG_T), ceil_div(k + 1, WG_T), 1);
+  if (n == 0) {
+    wgrad_kernel<<<grid, 256, 0, st>>>(g, ldg, x, ldx, 0, m, k, WG_R, dw, lddw, 0, nullptr, db, 1);
+    return status();
+  }
+  const WgradPlan p = plan_wgrad(n, m, k + 1);
+  if (p.slabs == 1) {
+    wgrad_kernel<<<grid, 256, 0, st>>>(g, ldg, x, ldx, n, m, k, p.rows_per_slab, dw, lddw, 0, rowweight, db, 1);
+    return status();
+  }
+  if (!workspace || workspace_bytes < (size_t)p.slabs * m * (k + 1) * sizeof(float)) return NBD_E_BADARG;
+  grid.z = p.slabs;
+  float* slabs = static_cast<float*>(workspace);
+  wgrad_kernel<<<grid, 256, 0, st>>>(g, ldg, x, ldx, n, m, k, p.rows_per_slab, slabs, k + 1, (size_t)m * (k + 1), rowweight, nullptr, 1);
+  int rc = status();
+  if (rc) return rc;
+  wgrad_finish_kernel<<<ceil_div(m * (k + 1), 256), 256, 0, st>>>(slabs, p.slabs, m, k, dw, lddw, k + 1, db);
+  return status();
 }
 
 int nbd_linear_wgrad_f32(const float* g, int ldg, const float* x, int ldx, int n, int m, int k, float* dw, int lddw,
@@ -624,8 +678,8 @@ int nbd_layernorm_bwd_f32(const float* x, int ldx, int c, const float* gamma, fl
                                                  static_cast<float*>(workspace));
   }
   float* part = static_cast<float*>(workspace);            // [blocks][dgamma partials (c) | dbeta partials (c)]
-  colsum_final_kernel<<<ceil_div(c, 256), 256, 0, st>>>(part, 2 * c, blocks, c, dgamma);
-  colsum_final_kernel<<<ceil_div(c, 256), 256, 0, st>>>(part ? part + c : part, 2 * c, blocks, c, dbeta);
+  colsum_final_kernel<<<ceil_div(c, 64), 256, 0, st>>>(part, 2 * c, blocks, c, dgamma);
+  colsum_final_kernel<<<ceil_div(c, 64), 256, 0, st>>>(part ? part + c : part, 2 * c, blocks, c, dbeta);
   return status();
 }
 

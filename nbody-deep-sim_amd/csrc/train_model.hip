@@ -95,8 +95,13 @@ int lin_bwd(const float* dy, int lddy, const float* y, int ldy, int act, const f
     if (rc) return rc;
     g = gbuf; ldg = L.out;
   }
-  if (dW) { rc = nbd_linear_wgrad_f32(g, ldg, x, ldx, n, L.out, L.in, dW, L.in, sc.p, sc.bytes, st); if (rc) return rc; }
-  if (db) { rc = nbd_colsum_f32(g, ldg, brs, n, L.out, db, sc.p, sc.bytes, st); if (rc) return rc; }
+  if (dW && db) {           // the bias gradient as one more column of the weight gradient's product
+    rc = nbd_linear_wgrad_bias_f32(g, ldg, x, ldx, brs, n, L.out, L.in, dW, L.in, db, sc.p, sc.bytes, st);
+    if (rc) return rc;
+  } else {
+    if (dW) { rc = nbd_linear_wgrad_f32(g, ldg, x, ldx, n, L.out, L.in, dW, L.in, sc.p, sc.bytes, st); if (rc) return rc; }
+    if (db) { rc = nbd_colsum_f32(g, ldg, brs, n, L.out, db, sc.p, sc.bytes, st); if (rc) return rc; }
+  }
   if (dx) {
     transpose_kernel<<<ceil_div(L.in * L.out, 256), 256, 0, (hipStream_t)st>>>(L.w, L.out, L.in, wt);
     rc = nbd_linear_f32(g, ldg, wt, L.out, nullptr, nullptr, nullptr, 0, dx, lddx, n, L.in, L.out, sc.p, sc.bytes, st);
@@ -154,7 +159,7 @@ GnnWs gnn_layout(const nbd_gnn_train_args& a, void* base, size_t* total) {
   w.dxa = ar.take(n * M); w.dxb = ar.take(n * M);
   // scratch of the library calls: split-K partials of a Linear, slabs of a weight gradient (<= 32 of m x k), column-sum /
   // LayerNorm partials
-  size_t sb = (size_t)32 * M * M * sizeof(float);
+  size_t sb = (size_t)32 * M * (M + 1) * sizeof(float);
   const size_t cs = nbd_colsum_workspace_bytes(a.n, 2 * M), ls = nbd_layernorm_bwd_workspace_bytes(a.n, w.C);
   const size_t lw = nbd_linear_workspace_bytes(a.n, M, M);
   sb = cs > sb ? cs : sb; sb = ls > sb ? ls : sb; sb = lw > sb ? lw : sb;

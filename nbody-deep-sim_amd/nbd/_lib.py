@@ -165,6 +165,7 @@ SIGNATURES = {
     "nbd_radius_transpose_fill_f32": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_void_p]),
     "nbd_exclusive_scan_i32": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "nbd_rowptr_sorted_i64": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "nbd_ell_to_edge_index": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p]),
     # --- surrogate models: dense blocks (csrc/nn.hip)
     "nbd_linear_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
@@ -190,6 +191,9 @@ SIGNATURES = {
     "nbd_contconv_filter_grad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "nbd_contconv_filter_grad_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int64,
                                              c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nbd_contconv_filter_grad_full_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int64,
+                                                  c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nbd_contconv_shuffle_filters_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nbd_contconv_fused_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "nbd_contconv_filter_floats": (c_size_t, [c_int, c_int, c_int]),
     "nbd_contconv_fused_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_int,
@@ -218,6 +222,9 @@ SIGNATURES = {
     "nbd_linear_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "nbd_linear_wgrad_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                      c_void_p, c_size_t, c_void_p]),
+    "nbd_linear_wgrad_bias_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "nbd_linear_wgrad_bias_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
+                                          c_void_p, c_void_p, c_size_t, c_void_p]),
     "nbd_edgeconv_aggregate_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                                c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "nbd_segment_max_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,

@@ -67,8 +67,12 @@ class LinearFn(Function):
         dy = dy if dy.stride(1) == 1 else dy.contiguous()
         g = nnops.act_bwd(dy, y, "tanh") if ctx.act == "tanh" else dy
         dx = nnops.linear(g, w.t().contiguous()) if ctx.needs_input_grad[0] else None
-        dw = nnops.linear_wgrad(g, x) if ctx.needs_input_grad[1] else None
-        db = nnops.colsum(g, rowweight=brs) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if want_w and want_b:       # the bias gradient as one more column of the weight gradient's product
+            dw, db = nnops.linear_wgrad_bias(g, x, rowweight=brs)
+        else:
+            dw = nnops.linear_wgrad(g, x) if want_w else None
+            db = nnops.colsum(g, rowweight=brs) if want_b else None
         return dx, dw, db, None, None
 
 
@@ -315,7 +319,7 @@ class ContConvFusedFn(Function):
         o_ch = filters.shape[4]
         feat = feat if (feat.stride(1) == 1 and feat.stride(0) % 2 == 0 and feat.data_ptr() % 8 == 0) else feat.contiguous()
         pb, cap_e = graph.pairs(d, cmap, k)
-        wf = nnops.contconv_shuffle_filters(filters, idx)
+        wf = nnops.contconv_shuffle_filters_kernel(filters, idx)
         out = nnops.contconv_fused(feat, graph.rows(), pb, cap_e, wf, k, o_ch, rowscale=scale, act=act)
         ctx.save_for_backward(feat, filters, out, scale)
         ctx.graph, ctx.d, ctx.act, ctx.cells = graph, d, act, cells
@@ -333,14 +337,11 @@ class ContConvFusedFn(Function):
         dfilters = dfeat = None
         if ctx.needs_input_grad[1]:
             pb, cap_e = graph.pairs(d, cmap, k)
-            dw = nnops.contconv_filter_grad(feat, gs, graph.rows(), pb, cap_e, k)
-            # unreachable grid points never enter a product: their gradient is exactly zero
-            dfilters = torch.zeros((d * d * d, i_ch, o_ch), dtype=torch.float32, device=dw.device)
-            dfilters.index_copy_(0, idx, dw)
-            dfilters = dfilters.reshape(filters.shape)
+            # over the full grid in one call: unreachable grid points never enter a product, their gradient is exactly zero
+            dfilters = nnops.contconv_filter_grad_full(feat, gs, graph.rows(), pb, cap_e, k, cmap, d)
         if ctx.needs_input_grad[0]:
             pa, cap_a = graph.pairs(d, cmap, k, adjoint=True)
-            wt = nnops.contconv_shuffle_filters(filters.transpose(3, 4), idx)
+            wt = nnops.contconv_shuffle_filters_kernel(filters, idx, transposed=True)
             dfeat = nnops.contconv_fused(gs, graph.rows(adjoint=True), pa, cap_a, wt, k, i_ch)
         return dfeat, dfilters, None, None, None, None, None
 

@@ -246,6 +246,14 @@ def csr_by_target(edge_index: torch.Tensor, n: int, return_tgt: bool = False):
     return_tgt also the target of every edge in that order."""
     tgt = edge_index[1]
     src = edge_index[0]
+    if (marked(edge_index, "_nbd_grouped") and edge_index.is_cuda and edge_index.dtype == torch.int64
+            and edge_index.stride(1) == 1):
+        # known to be grouped by ascending target (knn_graph's output, collated batches of it): one launch
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=edge_index.device)
+        with _lib.on_device(edge_index.device):
+            _lib.check(_lib.lib().nbd_rowptr_sorted_i64(tgt.data_ptr(), tgt.numel(), n, rowptr.data_ptr(),
+                                                        _stream(edge_index.device)), "nbd_rowptr_sorted_i64")
+        return (rowptr, src.contiguous(), tgt.contiguous()) if return_tgt else (rowptr, src.contiguous())
     if not marked(edge_index, "_nbd_grouped") and tgt.numel() > 1 and bool((tgt[1:] < tgt[:-1]).any()):
         order = torch.sort(tgt, stable=True).indices
         tgt, src = tgt[order], src[order]

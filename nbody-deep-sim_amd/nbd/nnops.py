@@ -181,6 +181,39 @@ def contconv_shuffle_filters(filters: torch.Tensor, cells: torch.Tensor) -> torc
     return f.reshape(-1)
 
 
+def contconv_shuffle_filters_kernel(filters: torch.Tensor, cells: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+    """contconv_shuffle_filters as ONE launch (nbd_contconv_shuffle_filters_f32): what the training step calls four times
+    (two layers, forward and the transposed operand of the feature gradient); `cells` int64 on the device."""
+    d, i_ch, o_ch = filters.shape[0], filters.shape[3], filters.shape[4]
+    f = filters.detach()
+    f = f if (f.is_contiguous() and f.dtype == torch.float32) else f.contiguous().float()
+    k = int(cells.numel())
+    L = _lib.lib()
+    ii, oo = (o_ch, i_ch) if transposed else (i_ch, o_ch)
+    out = torch.empty(L.nbd_contconv_filter_floats(ii, oo, k), dtype=torch.float32, device=f.device)
+    with _lib.on_device(f.device):
+        _lib.check(L.nbd_contconv_shuffle_filters_f32(f.data_ptr(), cells.data_ptr(), k, i_ch, o_ch, int(transposed),
+                                                      out.data_ptr(), _lib.current_stream(f.device)),
+                   "nbd_contconv_shuffle_filters_f32")
+    return out
+
+
+def contconv_filter_grad_full(feat, g, rowptr, pair_buf, edge_capacity: int, n_cells: int, cell_map, d: int):
+    """(d, d, d, I, O): the filter gradient over the full grid, zeros at the cells no sample can reach."""
+    n, i_ch, o_ch = rowptr.numel() - 1, feat.shape[1], g.shape[1]
+    ldf, ldg = _mat(feat, "feat"), _mat(g, "g")
+    L = _lib.lib()
+    out = torch.empty((d, d, d, i_ch, o_ch), dtype=torch.float32, device=feat.device)
+    need = n_cells * i_ch * o_ch * 4 + L.nbd_contconv_filter_grad_workspace_bytes(n, int(n_cells), i_ch, o_ch)
+    ws = _ws(need, feat.device)
+    with _lib.on_device(feat.device):
+        _lib.check(L.nbd_contconv_filter_grad_full_f32(feat.data_ptr(), ldf, i_ch, g.data_ptr(), ldg, o_ch, rowptr.data_ptr(), n,
+                                                       int(edge_capacity), pair_buf.data_ptr(), int(n_cells),
+                                                       _lib.ptr(cell_map), d * d * d, out.data_ptr(), _lib.ptr(ws), need,
+                                                       _lib.current_stream(feat.device)), "nbd_contconv_filter_grad_full_f32")
+    return out
+
+
 def contconv_pairs(pos, rowptr, centres, edge_capacity: int, d: int, radius_sq: float, cell_map, n_cells: int):
     """Pair lists of one (graph, filter resolution): opaque device buffer for contconv_fused (see include/nbd.h)."""
     n = pos.shape[0]
@@ -430,6 +463,24 @@ def linear_wgrad(g, x):
                                                    _mat(x, "x") if n else k, n, m, k, dw.data_ptr(), k, _lib.ptr(ws),
                                                    need, _lib.current_stream(g.device)), "nbd_linear_wgrad_f32")
     return dw
+
+
+def linear_wgrad_bias(g, x, rowweight=None):
+    """(dW (m, k), db (m,)) = (g^T x, sum_n w_n g_n) in the same launches (nbd_linear_wgrad_bias_f32)."""
+    n, m = g.shape
+    k = x.shape[1]
+    if x.shape[0] != n:
+        raise _lib.NbdError(f"linear_wgrad_bias: g is {tuple(g.shape)}, x is {tuple(x.shape)}")
+    dw = torch.empty((m, k), dtype=torch.float32, device=g.device)
+    db = torch.empty(m, dtype=torch.float32, device=g.device)
+    need = _lib.lib().nbd_linear_wgrad_bias_workspace_bytes(n, m, k)
+    ws = _ws(need, g.device)
+    with _lib.on_device(g.device):
+        _lib.check(_lib.lib().nbd_linear_wgrad_bias_f32(g.data_ptr(), _mat(g, "g") if n else m, x.data_ptr(),
+                                                        _mat(x, "x") if n else k, _vec(rowweight, n, "rowweight"), n, m, k,
+                                                        dw.data_ptr(), k, db.data_ptr(), _lib.ptr(ws), need,
+                                                        _lib.current_stream(g.device)), "nbd_linear_wgrad_bias_f32")
+    return dw, db
 
 
 def edgeconv_aggregate_bwd(pq, h, ds, rowptr, src, fixed_k, rowptr_t, tgt_t, aggr):
