@@ -295,6 +295,21 @@ int nbd_segment_reduce_f32(const float* m, int ldm, int h, const int* rowptr, in
 int nbd_layernorm_f32(const float* x, int ldx, int c, const float* gamma, const float* beta, float eps, float* y,
                       int ldy, int n, nbd_stream_t stream);
 
+/* LayerNorm + decoder in ONE launch: out = MLP(LayerNorm(x)) (gnn.py:105-114,146-148; contconv.py:206-216,233-234) for
+ * c <= 256 channels, n_layers in 1..3 Linears with tanh between them, hidden widths <= 64, last width <= 8
+ * (dims[0 .. n_layers], dims[0] = c). w[i] for the hidden layers (i < n_layers - 1) is the TRANSPOSED weight, [in][out]
+ * contiguous; w[n_layers - 1] is out x in as torch.nn.Linear holds it; b[i] may be NULL. With hidden layers
+ * (n_layers >= 2: fp32 MFMA, 16 rows per wave) the LayerNorm's affine part must come FOLDED into the first Linear --
+ * w[0] = (W1 diag(gamma))^T, b[0] = b1 + W1 beta -- and gamma = beta = NULL; with n_layers = 1 gamma / beta are applied
+ * here. kick_vel (n x last width,
+ * contiguous) non-NULL: kick_vel += kick_c * out in the epilogue (Trainer.step's second half-kick, trainer.py:225-226).
+ * nbd_ln_mlp_head_lds_bytes returns 0 for shapes it does not cover (the caller then runs nbd_layernorm_f32 +
+ * nbd_linear_f32). Host arrays w / b / dims. */
+size_t nbd_ln_mlp_head_lds_bytes(int c, int n_layers, const int* dims);
+int nbd_ln_mlp_head_f32(const float* x, int ldx, int c, const float* gamma, const float* beta, float eps, int n_layers,
+                        const float* const* w, const float* const* b, const int* dims, float* out, int ldout,
+                        float* kick_vel, float kick_c, int n, nbd_stream_t stream);
+
 /* ContinuousConv.forward (contconv.py:80-98) feature-side binning:
  * a_out[n][cell][i] = sum over edges e with edge_index[0][e] == n of
  *      window_e * trilinear_weight_e(cell) * feat[centre_e][i],   cell = (z*D + y)*D + x,

@@ -273,12 +273,15 @@ class ContinuousConvModel(nn.Module):
         self.use_radius_cache = True
         self._side_stream = None
         self.overlap_encoder = True
+        self.use_fused_head = True     # LayerNorm + decoder in one launch (nbd_ln_mlp_head_f32) where the shapes allow
         self.to(device)
 
     def _build_weights(self):
         enc = self.node_encoder.folded() if isinstance(self.node_encoder, MLP) else None
+        head = head_chain(self.output)
         return {"enc": enc, "wt": [layer.weight_fused() if layer.fused_ok() else layer.weight_t() for layer in self.contconv],
-                "head": head_chain(self.output)}
+                "head": head, "head_plan": nnops.ln_mlp_head_plan(self.layer_norm.normalized_shape[0], head, self.layer_norm.weight.detach(),
+                                                            self.layer_norm.bias.detach())}
 
     def forward(self, data):                                                         # contconv.py:218-234
         needs_train_path = self.training and (isinstance(self.node_encoder, MLP) and self.node_encoder.has_norm
@@ -347,12 +350,20 @@ class ContinuousConvModel(nn.Module):
             pairs = pair_cache.get((layer.filter_resolution, float(layer.radius))) if layer.fused_ok() else None
             h = layer(pos, h, lists=lists, act="tanh", out=conv_view if last else None, wt=w["wt"][li], pairs=pairs,
                       scale=inv_deg)
-        ln = nnops.layernorm(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
-                             self.layer_norm.eps)
         out = getattr(data, "_out", None)          # _predict_posm(): the caller's acceleration buffer, written directly
         if out is not None and (tuple(out.shape) != (n, self.out_channels) or out.dtype != torch.float32
                                 or not out.is_contiguous() or out.device != x7.device):
             out = None
+        if w["head_plan"] is not None and self.use_fused_head and n > 0:
+            # LayerNorm + decoder (+ the caller's half-kick) in one launch: they sit at the end of the step's dependency chain
+            kick = getattr(data, "_kick", None)
+            pred = nnops.ln_mlp_head(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
+                                     self.layer_norm.eps, w["head_plan"], out=out,
+                                     kick_vel=kick[0] if kick is not None else None, kick_c=kick[1] if kick is not None else 0.0)
+            self._kick_done = kick is not None
+            return pred
+        ln = nnops.layernorm(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
+                             self.layer_norm.eps)
         return run_chain(ln, w["head"], out_last=out)
 
     @property
@@ -365,7 +376,8 @@ class ContinuousConvModel(nn.Module):
         """predict() for a caller that already holds the packed rows {x, y, z, mass} the kick-drift kernel writes
         (Trainer's captured rollout step): with in_channels == 4 that IS the model input, so neither [vel | mass] nor
         [pos | mass] is concatenated and the prediction lands in the caller's buffer (three launches fewer per step).
-        The second half-kick stays with the caller (`_kick_done` False)."""
+        kick = (vel, c): vel += c * prediction in the decoder kernel's epilogue when the fused head runs; `_kick_done`
+        tells the caller whether it did (otherwise the caller kicks)."""
         from nbd.data import Data
         self.eval()
         self._kick_done = False
@@ -376,6 +388,7 @@ class ContinuousConvModel(nn.Module):
             data = Data(x=pos, batch=None)
             data._x_pos = (posm[:n], pos)
             data._out = out
+            data._kick = kick
             data._radius_cache = self._radius_cache if self.use_radius_cache else None
             return self.forward(data)
 

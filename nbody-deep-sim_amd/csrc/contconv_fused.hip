@@ -61,13 +61,19 @@ constexpr int MAXC = 160;            // filter cells kept (reachable) supported:
                                      // kernel's LDS tables (7 bytes per (node, cell) + scan scratch) fill the 160 KiB at that
 constexpr int SUBR = 16;             // packed rows per step of the fused kernel (one 16 x 16 MFMA tile of rows)
 // Cost of a step for the fused kernel's split of the step sequence over its workgroups, in pairs: a step takes the
-// consumers ~1.45 us whatever it holds and the producers ~14.5 ns per pair (in-kernel stamps at the published shape,
-// round 3: the gathers are served from the Infinity Cache at ~3.5 TB/s), so below ~100 pairs the matrix side sets
-// the pace and above it the gather.
+// consumers ~1.1-1.45 us whatever it holds and the producers ~14.5 ns per pair (in-kernel stamps at the published shape,
+// round 3: the gathers are served from the Infinity Cache at ~3.5 TB/s), so below ~80-100 pairs the matrix side sets
+// the pace and above it the gather. (The additive model cost = a + pairs, a = 32 .. 96, measured 2-12 % slower.)
 #ifndef NBD_CC_COST_MIN
-#define NBD_CC_COST_MIN 96
-#endif
+#define NBD_CC_COST_MIN 80         // swept again once the cuts moved into the plan kernel (profiles/r03_contconv_ablations.json):
+#endif                             // 56 / 64 / 72 / 80 / 88 / 96 -> D = 6 + D = 4 layers 0.657 / 0.636 / 0.633 / 0.626 / 0.634 / 0.633 ms
 constexpr int CC_COST_MIN = NBD_CC_COST_MIN;
+#ifndef NBD_CC_COST_ADD
+#define NBD_CC_COST_ADD 0          // experiment switch: > 0 = the additive model cost = NBD_CC_COST_ADD + pairs
+#endif
+__host__ __device__ inline int step_cost(int pairs) {
+  return NBD_CC_COST_ADD > 0 ? NBD_CC_COST_ADD + pairs : (pairs > CC_COST_MIN ? pairs : CC_COST_MIN);
+}
 
 // first step record of a tile: a (tile, cell) with r rows has ceil(r / 16) <= r / 16 + 1 steps and a tile's rows
 // are <= 8 x its edges, so e_t / 2 + tile * (cells + 2) needs no scan across tiles (one terminal record per tile)
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
     int carry = 0;
     for (int j0 = 0; j0 < ns; j0 += PAIR_THREADS) {
       const int j = j0 + tid;
-      const int c = j < ns ? max(CC_COST_MIN, t_steps[j + 1].z - t_steps[j].z) : 0;
+      const int c = j < ns ? step_cost(t_steps[j + 1].z - t_steps[j].z) : 0;
       const int incl = wave_incl_scan(c, lane);
       if (lane == 63) seg_pairs[0][wave] = incl;              // B's scratch, free by now
       __syncthreads();
@@ -570,7 +576,6 @@ constexpr size_t CC_LDS_BYTES = (size_t)(TN * LDO + NBUF * SUBR * LDA) * sizeof(
 // points, so the barriers match). The ring is idle here (first pass: untouched; later passes: every wave has left
 // the previous pass), so the segment list may borrow its first buffer.
 __device__ __forceinline__ void cc_load_table(const CCArgs& A, const CCLds& L, int p0, int p1, int tid) {
-  const int lane = tid & 63, wave = UNI(tid >> 6);
   __syncthreads();
   if (tid == 0) *L.s_nseg = 0;
   __syncthreads();
@@ -1038,8 +1043,9 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
   extern __shared__ f4 lds_aligned[];
   __shared__ int statics[32 + NBUF * CC_CONSUMERS + 4];            // s_red[16], s_nseg, full[8], done[8][8], turn[4]
   const CCLds L = cc_lds(reinterpret_cast<float*>(lds_aligned), statics);
-  const int tid = threadIdx.x, lane = tid & 63, wave = UNI(tid >> 6);
+  const int tid = threadIdx.x, wave = UNI(tid >> 6);
 #ifdef NBD_CC_TRACE
+  const int lane = tid & 63;
   const long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
   __shared__ long long s_dbg[16][4];
 #endif
@@ -1127,21 +1133,78 @@ __global__ __launch_bounds__(256) void contconv_stream_finish_kernel(
 // dF[k][i][o] = sum over the touched blocks (node n, cell k) of A[n][k][i] * g[n][o], A[n][k] = the block's weighted
 // sum of gathered feature rows exactly as the forward kernel forms it, g = scale * act'(out) * dout (contconv.py:92-98
 // differentiated with respect to `filters`). The binned matrix is not formed here either.
-// grid (cells, slabs of tiles), 1024 threads. A workgroup walks the rows of ITS cell through its slab's tiles, 16 at a
-// time -- rows of different tiles share a step (the contraction runs over rows: no padding but the last step's) --
-// and per step its sixteen waves build the 16 A rows (one each) and copy the 16 g rows into LDS (double-buffered: one
-// barrier per step), then multiply A^T (I x 16) by g (16 x O) with v_mfma_f32_16x16x4_f32; wave w keeps four 16 x 16
-// blocks of the I x O result in registers for the whole walk. One partial sum per slab, added in slab order by the
-// finishing kernel: deterministic, no float atomics.
+// 512 workgroups of 1024 threads, each over ONE contiguous range of the (cell, tile) units in cell-major order, the
+// ranges of equal cost (contconv_wplan_kernel). Inside a cell a workgroup walks the rows of its tiles 16 at a time -- rows
+// of different tiles share a step (the contraction runs over rows: no padding but a segment's last step) -- and per step
+// its sixteen waves build the 16 A rows (one each) and copy the 16 g rows into LDS (double-buffered: one barrier per
+// step), then multiply A^T (I x 16) by g (16 x O) with v_mfma_f32_16x16x4_f32; wave w keeps four 16 x 16 blocks of the
+// I x O result in registers for the whole cell. When the range leaves a cell its block goes to partial slot
+// (range + cell); the finishing kernel adds a cell's slots in range order: deterministic, no float atomics.
 constexpr int WG_LD = 144;       // LDS row stride (floats): the four k-rows a fragment read touches land on distinct banks
 constexpr int WG_MAXT = 64;      // tiles per slab (one wave scans their row counts)
 
 struct WGArgs {
   const float* feat; int ldf, I; const float* g; int ldg, O;
-  const int* rowptr; int n, n_tiles, n_cells, tiles_per_slab;
+  const int* rowptr; int n, n_tiles, n_cells;
   const int2* desc; const int2* rows; const int* pair_src; const float* pair_w; const int* tile_nsteps;
-  float* partial;              // [slabs][cells][I][O]
+  int* ucut;                   // [WG_RANGES + 1] first unit of every workgroup's range (contconv_wplan_kernel)
+  float* partial;              // [(range + cell) < WG_RANGES + cells][I][O]
 };
+constexpr int WG_RANGES = 512;   // workgroups of the filter-gradient kernel (two per CU in turn)
+
+// The units of the filter gradient's work -- (cell, tile) pairs in CELL-major order, u = cell * tiles + tile -- cut into
+// WG_RANGES contiguous ranges of equal cost (per unit: its pairs + 8 per row: a row costs its share of the MFMA step and
+// of the three round trips, a pair one gathered row). A grid of (cells x slabs of tiles), the first form, ran as long as
+// its heaviest cell: with self loops every node sends a row to each of the 8 cells around the grid centre (|r| = 0 maps
+// there), so those cells hold N rows each while the outer ones hold a handful -- 200+ us per launch on a 2 000-node
+// batch whatever the kernel inside did. One workgroup, once per call.
+__global__ __launch_bounds__(1024) void contconv_wplan_kernel(const WGArgs A) {
+  __shared__ long long red[16];
+  __shared__ long long s_tot;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int U = A.n_cells * A.n_tiles;
+  auto cost = [&](int u) -> int {
+    if (u >= U) return 0;
+    const int cell = u / A.n_tiles, tile = u - cell * A.n_tiles;
+    if (A.tile_nsteps[tile] < 0) return 0;                 // a tile the pair kernel refused
+    const int2 d = A.desc[(size_t)tile * A.n_cells + cell];
+    if (d.y <= 0) return 0;
+    const int2* rw = A.rows + (size_t)8 * A.rowptr[tile * TN] + tile + d.x;
+    return (rw[d.y].y - rw[0].y) + 8 * d.y;
+  };
+  long long mine = 0;
+  for (int u = tid; u < U; u += 1024) mine += cost(u);
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+  if (lane == 0) red[wave] = mine;
+  __syncthreads();
+  if (tid == 0) { long long t = 0; for (int i = 0; i < 16; ++i) t += red[i]; s_tot = t; }
+  __syncthreads();
+  const long long Ctot = s_tot;
+  // every cut starts at unit 0 (what a cut at cost 0 is; with no rows at all the last range visits every cell and writes
+  // zeros); the units below move the cuts that fall behind them
+  for (int r = tid; r < WG_RANGES; r += 1024) A.ucut[r] = 0;
+  if (tid == 0) A.ucut[WG_RANGES] = U;
+  if (Ctot == 0) return;
+  long long carry = 0;
+  for (int c0 = 0; c0 < U; c0 += 1024) {
+    const int u = c0 + tid;
+    const long long c = cost(u);
+    long long incl = c;
+    for (int off = 1; off < 64; off <<= 1) { const long long t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    __syncthreads();
+    if (lane == 63) red[wave] = incl;
+    __syncthreads();
+    long long woff = 0, tot = 0;
+    for (int i = 0; i < 16; ++i) { const long long x = red[i]; woff += i < wave ? x : 0; tot += x; }
+    const long long e0 = carry + woff + incl - c, e1 = e0 + c;        // cost before / behind unit u
+    if (c > 0) {                                             // the cuts B_r = Ctot r / G that fall in (e0, e1] start at u + 1
+      long long r = e0 * WG_RANGES / Ctot;
+      while (r < WG_RANGES && Ctot * r / WG_RANGES <= e0) ++r;
+      for (; r < WG_RANGES && Ctot * r / WG_RANGES <= e1; ++r) A.ucut[r] = u + 1;
+    }
+    carry += tot;
+  }
+}
 
 // 16 waves per workgroup: wave w builds row w of the step (in training batches the rows are SKEWED -- radius_graph keeps
 // the first 32 hits by index, so the low-index bodies of every graph are listed by everyone around them and their
@@ -1155,9 +1218,24 @@ __global__ __launch_bounds__(64 * WG_WAVES) void contconv_wgrad_kernel(const WGA
   __shared__ int t_pref[WG_MAXT + 1], t_row0[WG_MAXT];
   __shared__ long long t_e8[WG_MAXT];
   const int tid = threadIdx.x, lane = tid & 63, wave = UNI(tid >> 6);
-  const int k = blockIdx.x, slab = blockIdx.y;
-  const int t0 = slab * A.tiles_per_slab, nt = min(A.tiles_per_slab, A.n_tiles - t0);
+  const int range = blockIdx.x;
+  const int u0 = UNI(A.ucut[range]), u1 = UNI(A.ucut[range + 1]);
+  if (u0 >= u1) return;                                    // an empty range writes no slot (the finishing kernel skips it)
   const int I = A.I, O = A.O;
+  const bool live = 2 * lane < I;
+  const int fo = min(2 * lane, I - 2);
+  // wave w multiplies 16-row block (w & 7) of A^T by the 16-column blocks 4 (w >> 3) .. + 3 of g
+  const int ib = wave & 7, ob0 = (wave >> 3) * 4;
+  const int IB = (I + 15) >> 4, OB = (O + 15) >> 4;
+  f4v acc[4];
+#pragma unroll
+  for (int y = 0; y < 4; ++y) acc[y] = f4v{0.f, 0.f, 0.f, 0.f};
+  const int cell_a = u0 / A.n_tiles, cell_b = (u1 - 1) / A.n_tiles;
+  for (int k = cell_a; k <= cell_b; ++k) {
+  const int seg0 = max(u0, k * A.n_tiles) - k * A.n_tiles, seg1 = min(u1, (k + 1) * A.n_tiles) - k * A.n_tiles;
+  for (int t0 = seg0; t0 < seg1; t0 += WG_MAXT) {           // the tiles of this cell in this range, <= 64 at a time
+  const int nt = min(WG_MAXT, seg1 - t0);
+  __syncthreads();                                         // the previous segment's readers of t_pref / a_s / g_s are done
   if (wave == 0) {
     const int t = t0 + lane;
     int cnt = 0, row0 = 0;
@@ -1174,82 +1252,107 @@ __global__ __launch_bounds__(64 * WG_WAVES) void contconv_wgrad_kernel(const WGA
   }
   __syncthreads();
   const int R = t_pref[nt], nsteps = (R + 15) >> 4;
-  const bool live = 2 * lane < I;
-  const int fo = min(2 * lane, I - 2);
 
-  // One row per wave: three dependent levels (row record -> pair records -> feature rows). The pair records of the row
-  // are fetched LANE-PARALLEL (lane i = the row's i-th pair: one coalesced load per array and 64 pairs), the feature rows
-  // with the source index broadcast out of its lane (v_readlane): the first 8 at once, then 24, then 32 per trip -- every
-  // trip inside one 64-record chunk, pairs summed in list order.
-  auto gather = [&](int s, int buf) {
-    const int r = wave, q = 16 * s + r;
-    int p0 = 0, np = 0, node = 0;
-    const int* ps = A.pair_src;
-    const float* pw = A.pair_w;
-    if (q < R) {                                           // wave-uniform
+  // One row per wave: three dependent levels of memory accesses (row record -> pair records -> feature rows),
+  // SOFTWARE-PIPELINED across steps: while step s multiplies, the wave has the feature rows of step s + 1, the pair
+  // records of step s + 2 and the row record of step s + 3 in flight together, so a step exposes one round trip, not
+  // three (with the three levels back to back per step the launch was latency-bound at 5-10 us per step whatever the
+  // in-flight depth inside a level: 174-350 us in five successive forms). The pair records of a row are fetched
+  // LANE-PARALLEL (lane i = the row's i-th pair: one coalesced load per array and 64 pairs), the feature rows with the
+  // source index broadcast out of its lane (v_readlane): the first 8 at once, then 24, then 32 per trip -- every trip
+  // inside one 64-record chunk, pairs summed in list order.
+  struct S1 { int2 rec; int nexty, tile; long long e8; bool ok; };
+  struct S2 { int p0, np, sr; float wr, g0, g1; const int* ps; const float* pw; };
+  auto stage1 = [&](int s) {
+    S1 x;
+    x.rec = make_int2(0, 0); x.nexty = 0; x.tile = 0; x.e8 = 0; x.ok = false;
+    const int q = 16 * s + wave;
+    if (s < nsteps && q < R) {                             // wave-uniform
       int j = 0;
       while (j + 1 < nt && t_pref[j + 1] <= q) ++j;        // the tile of row q (LDS broadcasts)
       j = UNI(j);
-      const int tile = t0 + j;
-      const long long e8 = t_e8[j];
-      const int2* rw = A.rows + e8 + tile + t_row0[j] + (q - t_pref[j]);
-      const int2 rec = rw[0];
-      np = UNI(rw[1].y - rec.y); p0 = UNI(rec.y);
-      node = UNI(tile * TN + rec.x);
-      ps = A.pair_src + e8; pw = A.pair_w + e8;
+      x.tile = t0 + j; x.e8 = t_e8[j];
+      const int2* rw = A.rows + x.e8 + x.tile + t_row0[j] + (q - t_pref[j]);
+      x.rec = rw[0]; x.nexty = rw[1].y;
+      x.ok = true;
     }
-    const int at0 = p0 + min(lane, max(np - 1, 0));        // past the row's end: its last pair again, weight 0
-    int sr = np > 0 ? ps[at0] : 0;
-    float wr = lane < np ? pw[at0] : 0.f;
-    const float* gr = A.g + (size_t)node * A.ldg;
-    const float g0 = (np > 0 && lane < O) ? gr[lane] : 0.f;        // (a row of the lists always holds a pair)
-    const float g1 = (np > 0 && lane + 64 < O) ? gr[lane + 64] : 0.f;
+    return x;
+  };
+  auto stage2 = [&](const S1& x) {
+    S2 y;
+    y.p0 = x.ok ? UNI(x.rec.y) : 0;
+    y.np = x.ok ? UNI(x.nexty - x.rec.y) : 0;
+    const int node = x.ok ? UNI(x.tile * TN + x.rec.x) : 0;
+    y.ps = A.pair_src + x.e8; y.pw = A.pair_w + x.e8;
+    y.sr = 0; y.wr = 0.f; y.g0 = 0.f; y.g1 = 0.f;
+    if (y.np > 0) {                                        // wave-uniform (a row of the lists always holds a pair)
+      const int at0 = y.p0 + min(lane, y.np - 1);          // past the row's end: its last pair again, weight 0
+      y.sr = y.ps[at0];
+      y.wr = lane < y.np ? y.pw[at0] : 0.f;
+      const float* gr = A.g + (size_t)node * A.ldg;
+      y.g0 = lane < O ? gr[lane] : 0.f;
+      y.g1 = lane + 64 < O ? gr[lane + 64] : 0.f;
+    }
+    return y;
+  };
+  auto stage3 = [&](S2& y, int buf) {
+    const int r = wave, np = y.np, p0 = y.p0;
     f2 acc = {0.f, 0.f};
-    {
-      f2 v[8];
+    if (np > 0) {
+      {
+        f2 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        v[u] = *reinterpret_cast<const f2*>(A.feat + (size_t)__builtin_amdgcn_readlane(sr, u) * A.ldf + fo);
+        for (int u = 0; u < 8; ++u)
+          v[u] = *reinterpret_cast<const f2*>(A.feat + (size_t)__builtin_amdgcn_readlane(y.sr, u) * A.ldf + fo);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wr), u));
-        acc = __builtin_elementwise_fma(f2{w, w}, v[u], acc);
+        for (int u = 0; u < 8; ++u) {
+          const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y.wr), u));
+          acc = __builtin_elementwise_fma(f2{w, w}, v[u], acc);
+        }
       }
-    }
-    for (int base = 8; base < np;) {                       // wave-uniform
-      const int next = base < 32 ? 32 : base + 32, len = next - base;
-      if ((base & 63) == 0) {                              // the next 64 records
-        const int at = p0 + min(base + lane, np - 1);
-        sr = ps[at];
-        wr = base + lane < np ? pw[at] : 0.f;
-      }
-      f2 t[32];
+      for (int base = 8; base < np;) {                     // wave-uniform: long rows (hubs)
+        const int next = base < 32 ? 32 : base + 32, len = next - base;
+        if ((base & 63) == 0) {                            // the next 64 records
+          const int at = p0 + min(base + lane, np - 1);
+          y.sr = y.ps[at];
+          y.wr = base + lane < np ? y.pw[at] : 0.f;
+        }
+        f2 t[32];
 #pragma unroll
-      for (int u = 0; u < 32; ++u)
-        t[u] = *reinterpret_cast<const f2*>(A.feat + (size_t)__builtin_amdgcn_readlane(sr, min((base & 63) + u, 63)) * A.ldf + fo);
+        for (int u = 0; u < 32; ++u)
+          t[u] = *reinterpret_cast<const f2*>(A.feat + (size_t)__builtin_amdgcn_readlane(y.sr, min((base & 63) + u, 63)) * A.ldf + fo);
 #pragma unroll
-      for (int u = 0; u < 32; ++u) {
-        float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wr), min((base & 63) + u, 63)));
-        w = u < len ? w : 0.f;                             // (a 24-pair trip: the lanes of the next trip carry live weights)
-        acc = __builtin_elementwise_fma(f2{w, w}, t[u], acc);
+        for (int u = 0; u < 32; ++u) {
+          float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y.wr), min((base & 63) + u, 63)));
+          w = u < len ? w : 0.f;                           // (a 24-pair trip: the lanes of the next trip carry live weights)
+          acc = __builtin_elementwise_fma(f2{w, w}, t[u], acc);
+        }
+        base = next;
       }
-      base = next;
     }
     *reinterpret_cast<f2*>(&a_s[buf][r][2 * lane]) = (live && np > 0) ? acc : f2{0.f, 0.f};      // padding rows: exact zeros
-    g_s[buf][r][lane] = g0; g_s[buf][r][lane + 64] = g1;
+    g_s[buf][r][lane] = y.g0; g_s[buf][r][lane + 64] = y.g1;
   };
 
-  // wave w multiplies 16-row block (w & 7) of A^T by the 16-column blocks 4 (w >> 3) .. + 3 of g
-  const int ib = wave & 7, ob0 = (wave >> 3) * 4;
-  const int IB = (I + 15) >> 4, OB = (O + 15) >> 4;
-  f4v acc[4];
-#pragma unroll
-  for (int y = 0; y < 4; ++y) acc[y] = f4v{0.f, 0.f, 0.f, 0.f};
-  if (nsteps > 0) gather(0, 0);
+  S2 y2;                                                   // the pair records of the step after the one in LDS
+  S1 y1;                                                   // the row record of the step after that
+  {
+    S1 x1 = stage1(0);
+    S2 x2 = stage2(x1);
+    x1 = stage1(1);
+    y1 = stage1(2);
+    y2 = stage2(x1);
+    stage3(x2, 0);
+  }
   __syncthreads();
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nsteps) gather(s + 1, buf ^ 1);
+    if (s + 1 < nsteps) {
+      const S1 z1 = stage1(s + 3);
+      S2 z2 = stage2(y1);
+      stage3(y2, buf ^ 1);
+      y2 = z2; y1 = z1;
+    }
     if (ib < IB && ob0 < OB) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -1266,7 +1369,10 @@ __global__ __launch_bounds__(64 * WG_WAVES) void contconv_wgrad_kernel(const WGA
     }
     __syncthreads();
   }
-  float* dst = A.partial + ((size_t)slab * A.n_cells + k) * (size_t)I * O;
+  }   // tiles of the cell, 64 at a time
+  // the cell is complete as far as this range goes: its block of the result to slot (range + cell) -- ranges and cells
+  // both run in sequence order, so the numbering is unique and independent of timing
+  float* dst = A.partial + (size_t)(range + k) * (size_t)I * O;
   if (ib < IB) {
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
@@ -1277,18 +1383,39 @@ __global__ __launch_bounds__(64 * WG_WAVES) void contconv_wgrad_kernel(const WGA
         const int i = ib * 16 + 4 * (lane >> 4) + v;
         if (i < I && o < O) dst[(size_t)i * O + o] = acc[y][v];
       }
+      acc[y] = f4v{0.f, 0.f, 0.f, 0.f};
     }
   }
+  }   // cells of the range
 }
 
-// dfilters[e] = sum over slabs, in slab order
-__global__ __launch_bounds__(256) void contconv_wgrad_finish_kernel(const float* __restrict__ partial, int slabs, size_t per_slab,
-                                                                    float* __restrict__ out) {
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= per_slab) return;
-  float v = slabs > 0 ? partial[e] : 0.f;                  // no slabs (no nodes): the gradient is zero
-  for (int s = 1; s < slabs; ++s) v += partial[(size_t)s * per_slab + e];
-  out[e] = v;
+// dfilters[cell][e] = the slots (range + cell) of the ranges that visited the cell, in range order. grid (cells, chunks)
+__global__ __launch_bounds__(256) void contconv_wgrad_finish_kernel(const float* __restrict__ partial, const int* __restrict__ ucut,
+                                                                    int n_tiles, int io, float* __restrict__ out) {
+  __shared__ int s_r0, s_r1;
+  const int k = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int r0 = -1, r1 = -2;
+    if (ucut) {
+      const int lo_u = k * n_tiles, hi_u = (k + 1) * n_tiles;
+      int a = 0, b = WG_RANGES - 1;                          // last range starting at or before the cell's first unit
+      while (a < b) { const int m = (a + b + 1) >> 1; if (ucut[m] <= lo_u) a = m; else b = m - 1; }
+      r0 = a; r1 = a;
+      while (r1 + 1 < WG_RANGES && ucut[r1 + 1] < hi_u) ++r1;
+    }
+    s_r0 = r0; s_r1 = r1;
+  }
+  __syncthreads();
+  const int r0 = s_r0, r1 = s_r1, lo_u = k * n_tiles, hi_u = (k + 1) * n_tiles;
+  for (int e = blockIdx.y * 256 + threadIdx.x; e < io; e += gridDim.y * 256) {
+    float v = 0.f;
+    for (int r = r0; r <= r1; ++r) {
+      const int a = ucut[r], b = ucut[r + 1];
+      if (a >= b || b <= lo_u || a >= hi_u) continue;        // empty, or not in this cell after all
+      v += partial[(size_t)(r + k) * io + e];
+    }
+    out[(size_t)k * io + e] = v;
+  }
 }
 
 // dfilters over the FULL grid: cell c of the D^3 grid takes the sum of the slabs of its compact cell cell_map[c], or an
@@ -1338,18 +1465,8 @@ __global__ __launch_bounds__(256) void contconv_shuffle_kernel(const float* __re
   out[idx] = v;
 }
 
-inline void wgrad_plan(int n, int n_cells, int* slabs, int* tiles_per_slab) {
-  const int tiles = ceil_div(n, TN);
-  // enough workgroups to fill the chip, but at least four tiles per slab: every slab writes (and the finishing kernel
-  // reads) a whole cells x I x O partial, which is what a 2 000-node training batch spent its time on with 7 slabs
-  int S = tiles < ceil_div(1024, n_cells) ? tiles : ceil_div(1024, n_cells);
-  if (S > ceil_div(tiles, 4)) S = ceil_div(tiles, 4);
-  int tps = ceil_div(tiles, S);
-  if (tps > WG_MAXT) tps = WG_MAXT;
-  *tiles_per_slab = tps;
-  *slabs = ceil_div(tiles, tps);
-}
-
+constexpr size_t WG_HEADER_BYTES = 4096;      // ucut[WG_RANGES + 1] in front of the partial slots
+static_assert((WG_RANGES + 1) * sizeof(int) <= WG_HEADER_BYTES, "ucut header");
 }  // namespace
 
 extern "C" {
@@ -1542,9 +1659,7 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
 
 size_t nbd_contconv_filter_grad_workspace_bytes(int n, int n_cells, int in_channels, int out_channels) {
   if (n <= 0 || n_cells <= 0 || in_channels <= 0 || out_channels <= 0) return 0;
-  int S, tps;
-  wgrad_plan(n, n_cells, &S, &tps);
-  return S > 1 ? (size_t)S * n_cells * in_channels * out_channels * sizeof(float) : 0;
+  return WG_HEADER_BYTES + (size_t)(WG_RANGES + n_cells) * in_channels * out_channels * sizeof(float);
 }
 
 int nbd_contconv_filter_grad_f32(const float* feat, int ldf, int in_channels, const float* g, int ldg, int out_channels,
@@ -1555,29 +1670,33 @@ int nbd_contconv_filter_grad_f32(const float* feat, int ldf, int in_channels, co
     return NBD_E_BADARG;
   if (!dfilters) return NBD_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  const size_t per_slab = (size_t)n_cells * in_channels * out_channels;
+  const int io = in_channels * out_channels;
+  const dim3 fgrid(n_cells, ceil_div(io, 1024) < 16 ? ceil_div(io, 1024) : 16);
   if (n == 0) {        // no rows: the gradient is zero
-    contconv_wgrad_finish_kernel<<<ceil_div((int)per_slab, 256), 256, 0, st>>>(nullptr, 0, per_slab, dfilters);
+    contconv_wgrad_finish_kernel<<<fgrid, 256, 0, st>>>(nullptr, nullptr, 0, io, dfilters);
     return status();
   }
   if (!feat || !g || !rowptr || !pair_lists || (reinterpret_cast<uintptr_t>(feat) & 7)) return NBD_E_BADARG;
-  int S, tps;
-  wgrad_plan(n, n_cells, &S, &tps);
-  if (S > 1 && (!workspace || workspace_bytes < nbd_contconv_filter_grad_workspace_bytes(n, n_cells, in_channels, out_channels)))
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15) ||
+      workspace_bytes < nbd_contconv_filter_grad_workspace_bytes(n, n_cells, in_channels, out_channels))
     return NBD_E_WORKSPACE;
   const PairsLayout L = pairs_layout(n, edge_capacity, n_cells);
   const char* base = static_cast<const char*>(pair_lists);
   WGArgs A;
   A.feat = feat; A.ldf = ldf; A.I = in_channels; A.g = g; A.ldg = ldg; A.O = out_channels;
-  A.rowptr = rowptr; A.n = n; A.n_tiles = ceil_div(n, TN); A.n_cells = n_cells; A.tiles_per_slab = tps;
+  A.rowptr = rowptr; A.n = n; A.n_tiles = ceil_div(n, TN); A.n_cells = n_cells;
   A.desc = reinterpret_cast<const int2*>(base + L.desc); A.rows = reinterpret_cast<const int2*>(base + L.rows);
   A.pair_src = reinterpret_cast<const int*>(base + L.src); A.pair_w = reinterpret_cast<const float*>(base + L.w);
   A.tile_nsteps = reinterpret_cast<const int*>(base + L.nsteps);
-  A.partial = S > 1 ? static_cast<float*>(workspace) : dfilters;
-  contconv_wgrad_kernel<<<dim3(n_cells, S), 64 * WG_WAVES, 0, st>>>(A);
+  A.ucut = static_cast<int*>(workspace);
+  A.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + WG_HEADER_BYTES);
+  contconv_wplan_kernel<<<1, 1024, 0, st>>>(A);
   int rc = status();
-  if (rc || S == 1) return rc;
-  contconv_wgrad_finish_kernel<<<ceil_div((int)per_slab, 256), 256, 0, st>>>(A.partial, S, per_slab, dfilters);
+  if (rc) return rc;
+  contconv_wgrad_kernel<<<WG_RANGES, 64 * WG_WAVES, 0, st>>>(A);
+  rc = status();
+  if (rc) return rc;
+  contconv_wgrad_finish_kernel<<<fgrid, 256, 0, st>>>(A.partial, A.ucut, A.n_tiles, io, dfilters);
   return status();
 }
 

@@ -339,6 +339,330 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const float* __rest
   }
 }
 
+// ------------------------------------------------------------------ LayerNorm + decoder MLP in one launch
+// out = MLP(LayerNorm(x)) for the decoders of gnn.py:105-114,146-148 / contconv.py:206-216,233-234: LayerNorm over
+// C <= 256 channels, up to two hidden Linear + tanh layers of <= 64 outputs, a last Linear of <= 8 outputs; optionally
+// the caller's half-kick v += c * out in the epilogue (Trainer.step, trainer.py:225-226). At the published ContinuousConv
+// shape (N = 16 384, 256 -> 64 -> 32 -> 3) the four separate launches (LayerNorm 10.5 us, Linear 19 + 9 + 9 us) sat at
+// the END of the rollout step's dependency chain with the chip idle but for them; here a wave takes a row through the
+// whole decoder: the row in registers (lane = channel, 4 per lane), the hidden layers' matrices in LDS as [in][out]
+// (staged once per persistent block, lane = output: conflict-free reads), each input broadcast out of its lane with
+// v_readlane, the last layer's few dot products as wave reductions. w[i] for i < n_layers - 1 is the TRANSPOSED weight
+// ([in][out] contiguous: the caller keeps it with its other derived weights); w[n_layers - 1] is out x in as torch holds it.
+constexpr int kHeadMaxOut = 8;
+struct LnHeadArgs {
+  const float* x; int ldx, c; const float* gamma; const float* beta; float eps;
+  int n_layers; const float* w[3]; const float* b[3]; int dims[4];
+  float* out; int ldout; float* kick_vel; float kick_c; int n;
+};
+__global__ __launch_bounds__(256) void ln_mlp_head_kernel(const LnHeadArgs a) {
+  extern __shared__ float lds_w[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int C = a.c, NL = a.n_layers;
+  const int d1 = a.dims[1], d2 = a.dims[2];
+  // the hidden layers' matrices as [in (padded to a multiple of 8 with zero rows)][out]: the mat-vec loops run in
+  // unrolled batches of 8 inputs (eight LDS reads in flight per wait)
+  const int kp1 = (C + 7) & ~7, kp2 = (d1 + 7) & ~7;
+  float* w1t = lds_w;                                      // [kp1][d1]     (NL >= 2)
+  float* w2t = lds_w + (NL >= 2 ? kp1 * d1 : 0);            // [kp2][d2]     (NL == 3)
+  if (NL >= 2) for (int i = threadIdx.x; i < kp1 * d1; i += 256) w1t[i] = i < C * d1 ? a.w[0][i] : 0.f;
+  if (NL == 3) for (int i = threadIdx.x; i < kp2 * d2; i += 256) w2t[i] = i < d1 * d2 ? a.w[1][i] : 0.f;
+  __syncthreads();
+  const int dl = a.dims[NL - 1], dout = a.dims[NL];         // the last Linear: dl -> dout
+  const float* wl = a.w[NL - 1];
+  const float* bl = a.b[NL - 1];
+  for (int row = blockIdx.x * 4 + wave; row < a.n; row += gridDim.x * 4) {
+    const float* x = a.x + (size_t)row * a.ldx;
+    // ---- LayerNorm, as layernorm_kernel computes it (same operations, same order)
+    float xv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int c = r * 64 + lane; const float t = x[min(c, C - 1)]; xv[r] = c < C ? t : 0.f; }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s += xv[r];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float d = xv[r] - mean; v += (r * 64 + lane < C) ? d * d : 0.f; }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const float rstd = 1.0f / sqrtf(v / (float)C + a.eps);
+    float z[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = r * 64 + lane;
+      float y = (xv[r] - mean) * rstd;
+      if (a.gamma) y = y * a.gamma[min(c, C - 1)];
+      if (a.beta) y = y + a.beta[min(c, C - 1)];
+      z[r] = c < C ? y : 0.f;
+    }
+    // ---- hidden layers: lane = output channel
+    float h = 0.f;                                         // the last hidden activation (lane < dl), when NL >= 2
+    if (NL >= 2) {
+      float acc = 0.f;
+      const int lo = min(lane, d1 - 1);
+      for (int k0 = 0; k0 < kp1; k0 += 8) {                // uniform
+        const int r = k0 >> 6, l0 = k0 & 63;
+        const float zr = r == 0 ? z[0] : r == 1 ? z[1] : r == 2 ? z[2] : z[3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float zk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zr), l0 + u));
+          acc = __builtin_fmaf(zk, w1t[(k0 + u) * d1 + lo], acc);
+        }
+      }
+      h = lane < d1 ? tanhf(acc + (a.b[0] ? a.b[0][lo] : 0.f)) : 0.f;
+      if (NL == 3) {
+        float acc2 = 0.f;
+        const int lo2 = min(lane, d2 - 1);
+        for (int k0 = 0; k0 < kp2; k0 += 8) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float hk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, h), k0 + u));
+            acc2 = __builtin_fmaf(hk, w2t[(k0 + u) * d2 + lo2], acc2);
+          }
+        }
+        h = lane < d2 ? tanhf(acc2 + (a.b[1] ? a.b[1][lo2] : 0.f)) : 0.f;
+      }
+    }
+    // ---- last Linear: dout <= 8 dot products over dl inputs, reduced across the wave together
+    float part[kHeadMaxOut];
+#pragma unroll
+    for (int j = 0; j < kHeadMaxOut; ++j) {
+      part[j] = 0.f;
+      if (j < dout) {                                      // uniform
+        if (NL >= 2) part[j] = lane < dl ? h * wl[(size_t)j * dl + lane] : 0.f;
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int c = r * 64 + lane; if (c < C) part[j] = __builtin_fmaf(z[r], wl[(size_t)j * C + c], part[j]); }
+        }
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int j = 0; j < kHeadMaxOut; ++j)
+        if (j < dout) part[j] += __shfl_xor(part[j], off);
+    }
+#pragma unroll
+    for (int j = 0; j < kHeadMaxOut; ++j) {
+      if (j < dout && lane == 0) {
+        const float o = part[j] + (bl ? bl[j] : 0.f);
+        a.out[(size_t)row * a.ldout + j] = o;
+        if (a.kick_vel) {                                  // v += c * a, rounded as the separate kick kernel rounds it
+          float* vv = a.kick_vel + (size_t)row * dout + j;
+          *vv = __fadd_rn(*vv, __fmul_rn(a.kick_c, o));
+        }
+      }
+    }
+  }
+}
+
+// The same decoder with hidden layers on the matrix pipe: a wave takes 16 rows at a time. The wave-per-row form above
+// (kept for a decoder that is a single small Linear) ran the published 256 -> 64 -> 32 -> 3 decoder in ~110 us at
+// N = 16 384 -- 256 dependent LDS-latency-bound mat-vec steps per row at 8 waves per CU -- against 48 us for the four
+// launches it replaced. Here the normalised rows never leave registers: lane (m = lane & 15, q = lane >> 4) loads, as 16
+// float4, the channels 16 i + 4 q + e of row m -- which IS an A-operand layout of v_mfma_f32_16x16x4_f32 when k-step
+// t = 4 i + e is declared to contract channel 16 i + 4 q + e (the B operand reads the matching row of W^T from LDS) --
+// so LayerNorm is 64 values per lane plus two cross-lane adds, and the first Linear is 64 k-steps x <= 4 column blocks.
+// gamma / beta are folded into the first Linear by the caller (W1 . diag(gamma), b1 + W1 beta: exact algebra), the
+// hidden activations go through a wave-private LDS tile to change from the C/D layout to the A layout, the last
+// (<= 8 outputs) Linear is a dot product reduced over the 16 lanes that share a row. tanh is the exp2 / rcp form the
+// EdgeConv kernels use (abs error <= ~2e-7): libm's tanhf, inlined 24 times per lane with its magnitude branches, was
+// two thirds of the instruction stream (24 000 lines of ISA, 330 branches).
+constexpr int kHeadHP = 68;          // row stride of the wave-private activation tile (floats)
+struct LnHead2Args {
+  const float* x; int ldx, c; float eps;
+  int n_layers;                      // 2 or 3
+  const float* w1t; const float* b1; // [c][d1] (gamma folded in), [d1] (beta folded in)
+  const float* w2t; const float* b2; // [d1][d2], [d2]            (n_layers == 3)
+  const float* wl; const float* bl;  // [dout][dl] as torch holds it, [dout]
+  int d1, d2, dout;
+  float* out; int ldout; float* kick_vel; float kick_c; int n;
+};
+// CB2 = 16-column blocks of the second hidden layer (0: no second hidden layer). The first hidden layer always runs its
+// four column blocks (its matrix is zero-padded to 64 columns in LDS): with run-time block counts every MFMA sat behind
+// its own uniform branch (330 of them), which also fenced the LDS reads -- one exposed LDS round trip per MFMA, 55 us.
+template <int CB2>
+__global__ __launch_bounds__(256) void ln_mlp_head_mfma_kernel(const LnHead2Args a) {
+  extern __shared__ float lds_w[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int C = a.c, d1 = a.d1, d2 = a.d2, dout = a.dout;
+  constexpr int d1p = 64, d2p = CB2 * 16;
+  const int kp1 = (C + 15) & ~15;
+  // LDS row strides: a B-operand read touches, per k-step, the rows r, r + 4, r + 8, r + 12 (first Linear: channel
+  // 16 i + 4 q + e) or r .. r + 3 (second: 4 t + q) at 16 consecutive columns -- s1 = 4 (mod 16) and s2 = 16 (mod 64)
+  // spread those four rows over the 64 banks (with the natural strides 64 / 32 every read was a 4- / 2-way conflict)
+  constexpr int s1 = d1p + 4, s2 = d2p + 16;
+  float* w1t = lds_w;                                       // [kp1][s1], zero padded
+  float* w2t = w1t + kp1 * s1;                              // [d1p][s2]
+  float* hb = w2t + d1p * s2 + wave * 16 * kHeadHP;         // this wave's 16 x 64 activation tile
+  // staging: many loads in flight per thread (a plain one-load-per-iteration loop made the 80 KB of the published decoder
+  // 80 dependent L2 round trips per thread: 60 of the first version's 74 us)
+  auto stage = [&](float* dst, int lds_stride, const float* src, int rows, int cols, int rowsp, int colsp) {
+    if ((cols & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+      const int qpr = colsp / 4, quadsp = rowsp * qpr;                      // float4 per padded row
+      for (int i0 = threadIdx.x; i0 < quadsp; i0 += 256 * 8) {
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + 256 * u, k = i / qpr, o = (i - k * qpr) * 4;
+          const f4 t = *reinterpret_cast<const f4*>(src + (size_t)min(k, rows - 1) * cols + min(o, cols - 4));
+          v[u] = (i < quadsp && k < rows && o < cols) ? t : f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + 256 * u, k = i / qpr, o = (i - k * qpr) * 4;
+          if (i < quadsp) *reinterpret_cast<f4*>(dst + k * lds_stride + o) = v[u];
+        }
+      }
+    } else {
+      for (int i0 = threadIdx.x; i0 < rowsp * colsp; i0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + 256 * u, k = i / colsp, o = i - k * colsp;
+          const float t = src[(size_t)min(k, rows - 1) * cols + min(o, cols - 1)];
+          v[u] = (i < rowsp * colsp && k < rows && o < cols) ? t : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + 256 * u, k = i / colsp, o = i - k * colsp;
+          if (i < rowsp * colsp) dst[k * lds_stride + o] = v[u];
+        }
+      }
+    }
+  };
+  stage(w1t, s1, a.w1t, C, d1, kp1, d1p);
+  if (CB2 > 0) stage(w2t, s2, a.w2t, d1, d2, d1p, d2p);
+  __syncthreads();
+  const int m = lane & 15, q = lane >> 4;
+  const int dl = CB2 ? d2 : d1;                                     // the last Linear's input
+  constexpr int dlp = CB2 ? d2p : d1p;
+  // this lane's entries of the last Linear: column cb * 16 + m of every output row
+  float wl[kHeadMaxOut][4], bl[kHeadMaxOut];
+#pragma unroll
+  for (int j = 0; j < kHeadMaxOut; ++j) {
+    bl[j] = (j < dout && a.bl) ? a.bl[j] : 0.f;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int col = cb * 16 + m;
+      wl[j][cb] = (j < dout && col < dl) ? a.wl[(size_t)j * dl + col] : 0.f;
+    }
+  }
+  float b1v[4], b2v[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int col = cb * 16 + m;
+    b1v[cb] = (col < d1 && a.b1) ? a.b1[col] : 0.f;
+    b2v[cb] = (CB2 > 0 && col < d2 && a.b2) ? a.b2[col] : 0.f;
+  }
+  const bool vec4 = (C & 3) == 0 && (a.ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
+  const int groups = (a.n + 15) >> 4;
+  for (int g = blockIdx.x * 4 + wave; g < groups; g += gridDim.x * 4) {
+    const int row0 = g * 16;
+    const float* xr = a.x + (size_t)min(row0 + m, a.n - 1) * a.ldx;
+    // ---- the row's channels 16 i + 4 q + e, LayerNorm without the affine part
+    f4 zq[16];
+    if (vec4) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {       // unconditional loads at a clamped channel, masked afterwards: a predicate around
+        const int k = 16 * i + 4 * q;        // the load makes hipcc branch and wait per load (16 dependent round trips)
+        const f4 t = *reinterpret_cast<const f4*>(xr + min(k, C - 4));
+        zq[i] = k < C ? t : f4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int k = 16 * i + 4 * q + e; const float t = xr[min(k, C - 1)]; zq[i][e] = k < C ? t : 0.f; }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += (zq[i][0] + zq[i][1]) + (zq[i][2] + zq[i][3]);
+    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+    const float mean = s / (float)C;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = zq[i][e] - mean; v += (16 * i + 4 * q + e < C) ? d * d : 0.f; }
+    v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    const float rstd = 1.0f / sqrtf(v / (float)C + a.eps);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) zq[i][e] = (16 * i + 4 * q + e < C) ? (zq[i][e] - mean) * rstd : 0.f;
+    // ---- first Linear: k-step t = 4 i + e contracts channel 16 i + 4 q + e
+    f4 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (16 * i < kp1) {                                  // uniform: one branch per 16 MFMAs
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* wrow = w1t + (16 * i + 4 * q + e) * s1 + m;
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb)
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(zq[i][e], wrow[cb * 16], acc[cb], 0, 0, 0);
+        }
+      }
+    }
+    // C/D layout: lane holds rows 4 q + v of column cb * 16 + m
+    float hl[4][4];                                        // [cb][v]: the last hidden activation, in the C/D layout
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int vv = 0; vv < 4; ++vv) hl[cb][vv] = (cb * 16 + m < d1) ? fast_tanh(acc[cb][vv] + b1v[cb]) : 0.f;
+    if (CB2 > 0) {
+      // ---- second Linear: the activations change layout through the wave's LDS tile
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) hb[(4 * q + vv) * kHeadHP + cb * 16 + m] = hl[cb][vv];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      f4 acc2[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc2[cb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < d1p / 4; ++t) {
+        const float av = hb[m * kHeadHP + 4 * t + q];
+        const float* wrow = w2t + (4 * t + q) * s2 + m;
+#pragma unroll
+        for (int cb = 0; cb < (CB2 ? CB2 : 1); ++cb)
+          acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[cb * 16], acc2[cb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) hl[cb][vv] = (cb * 16 + m < d2) ? fast_tanh(acc2[cb][vv] + b2v[cb]) : 0.f;
+      __builtin_amdgcn_wave_barrier();                     // the tile is rewritten by the next group
+    }
+    // ---- last Linear: out[row 4 q + v][j] = sum over the row's dl activations, spread over the 16 lanes of its q
+#pragma unroll
+    for (int j = 0; j < kHeadMaxOut; ++j) {
+      if (j >= dout) break;                                // uniform
+#pragma unroll
+      for (int vv = 0; vv < 4; ++vv) {
+        float p = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < dlp / 16; ++cb) p = __builtin_fmaf(hl[cb][vv], wl[j][cb], p);
+        p += __shfl_xor(p, 1); p += __shfl_xor(p, 2); p += __shfl_xor(p, 4); p += __shfl_xor(p, 8);
+        const int row = row0 + 4 * q + vv;
+        if (m == 0 && row < a.n) {
+          const float o = p + bl[j];
+          a.out[(size_t)row * a.ldout + j] = o;
+          if (a.kick_vel) {                                // v += c * a, rounded as the separate kick kernel rounds it
+            float* kv = a.kick_vel + (size_t)row * dout + j;
+            *kv = __fadd_rn(*kv, __fmul_rn(a.kick_c, o));
+          }
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ LayerNorm (one wave per row)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ X, int ldx, int C,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -635,6 +959,63 @@ int nbd_layernorm_f32(const float* x, int ldx, int c, const float* gamma, const 
   if (n == 0) return 0;
   if (!x || !y || ldx < c || ldy < c) return NBD_E_BADARG;
   layernorm_kernel<<<ceil_div(n, 4), 256, 0, (hipStream_t)stream>>>(x, ldx, c, gamma, beta, eps, y, ldy, n);
+  return status();
+}
+
+size_t nbd_ln_mlp_head_lds_bytes(int c, int n_layers, const int* dims) {
+  if (!dims || n_layers < 1 || n_layers > 3 || c <= 0 || c > 256 || dims[0] != c) return 0;
+  for (int i = 1; i < n_layers; ++i) if (dims[i] <= 0 || dims[i] > 64) return 0;
+  if (dims[n_layers] <= 0 || dims[n_layers] > kHeadMaxOut) return 0;
+  if (n_layers == 1) return 16;
+  // the first hidden layer padded to 64 columns, the second to 32 or 64 (ln_mlp_head_mfma_kernel<CB2>)
+  const int kp1 = (c + 15) & ~15, d2p = n_layers == 3 ? (dims[2] <= 32 ? 32 : 64) : 0;
+  return ((size_t)kp1 * (64 + 4) + (size_t)64 * (d2p + 16) + 4 * 16 * kHeadHP) * sizeof(float);
+}
+
+int nbd_ln_mlp_head_f32(const float* x, int ldx, int c, const float* gamma, const float* beta, float eps, int n_layers,
+                        const float* const* w, const float* const* b, const int* dims, float* out, int ldout,
+                        float* kick_vel, float kick_c, int n, nbd_stream_t stream) {
+  if (n < 0 || !dims || !w || !b) return NBD_E_BADARG;
+  const size_t lds = nbd_ln_mlp_head_lds_bytes(c, n_layers, dims);
+  if (lds == 0) return NBD_E_UNSUPPORTED;
+  if (n == 0) return 0;
+  if (!x || !out || ldx < c || ldout < dims[n_layers]) return NBD_E_BADARG;
+  for (int i = 0; i < n_layers; ++i) if (!w[i]) return NBD_E_BADARG;
+  if (n_layers == 1) {                 // LayerNorm + one small Linear: a wave per row, dot products as wave reductions
+    LnHeadArgs a;
+    a.x = x; a.ldx = ldx; a.c = c; a.gamma = gamma; a.beta = beta; a.eps = eps; a.n_layers = 1;
+    for (int i = 0; i < 3; ++i) { a.w[i] = i < 1 ? w[i] : nullptr; a.b[i] = i < 1 ? b[i] : nullptr; }
+    for (int i = 0; i < 4; ++i) a.dims[i] = i <= 1 ? dims[i] : 0;
+    a.out = out; a.ldout = ldout; a.kick_vel = kick_vel; a.kick_c = kick_c; a.n = n;
+    int blocks = ceil_div(n, 4);
+    if (blocks > 2048) blocks = 2048;
+    ln_mlp_head_kernel<<<blocks, 256, 16, (hipStream_t)stream>>>(a);
+    return status();
+  }
+  // hidden layers on the matrix pipe. gamma / beta must have been folded into the first Linear by the caller
+  // (w[0] = (W1 diag(gamma))^T, b[0] = b1 + W1 beta): passing them here as well would apply them twice.
+  if (gamma || beta) return NBD_E_BADARG;
+  LnHead2Args a;
+  a.x = x; a.ldx = ldx; a.c = c; a.eps = eps; a.n_layers = n_layers;
+  a.w1t = w[0]; a.b1 = b[0];
+  a.w2t = n_layers == 3 ? w[1] : nullptr; a.b2 = n_layers == 3 ? b[1] : nullptr;
+  a.wl = w[n_layers - 1]; a.bl = b[n_layers - 1];
+  a.d1 = dims[1]; a.d2 = n_layers == 3 ? dims[2] : 0; a.dout = dims[n_layers];
+  a.out = out; a.ldout = ldout; a.kick_vel = kick_vel; a.kick_c = kick_c; a.n = n;
+  // persistent blocks of 4 waves, 16 rows per wave at a time; every block stages the hidden layers' matrices once
+  int blocks = ceil_div(ceil_div(n, 16), 4);
+  if (blocks > 256) blocks = 256;
+#define NBD_HEAD_LAUNCH(CB2)                                                                                        \
+  do {                                                                                                              \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_mlp_head_mfma_kernel<CB2>),                 \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);                     \
+    if (e != hipSuccess) return (int)e;                                                                             \
+    ln_mlp_head_mfma_kernel<CB2><<<blocks, 256, lds, (hipStream_t)stream>>>(a);                                     \
+  } while (0)
+  if (n_layers == 2) NBD_HEAD_LAUNCH(0);
+  else if (dims[2] <= 32) NBD_HEAD_LAUNCH(2);
+  else NBD_HEAD_LAUNCH(4);
+#undef NBD_HEAD_LAUNCH
   return status();
 }
 

@@ -187,7 +187,10 @@ class GraphModel(torch.nn.Module):
             m = nnops.linear(wpq_n, w2.t().contiguous())                          # (2H, H) = Wpq' W2
             c = nnops.linear(b2.unsqueeze(0).contiguous(), wpq_n).reshape(-1)     # (2H,)  = Wpq' b2
             folded.append((m.t().contiguous(), c.contiguous()))
-        return {"enc": enc, "layers": layers, "head": head_chain(self.output), "fused_t": fused, "folded": folded}
+        head = head_chain(self.output)
+        return {"enc": enc, "layers": layers, "head": head, "fused_t": fused, "folded": folded,
+                "head_plan": nnops.ln_mlp_head_plan(self.layer_norm.normalized_shape[0], head, self.layer_norm.weight.detach(),
+                                                            self.layer_norm.bias.detach())}
 
     # ------------------------------------------------------------------ forward (gnn.py:130-148)
     def forward(self, data):
@@ -253,6 +256,9 @@ class GraphModel(torch.nn.Module):
             s = nnops.edgeconv_aggregate(pq, h, rowptr, src, fixed_k, aggr)
             last = li == len(w["layers"]) - 1
             x = nnops.linear(s, w2, b2, bias_rowscale=brs, out=gnn_view if last else None)
+        if w["head_plan"] is not None:
+            return nnops.ln_mlp_head(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
+                                     self.layer_norm.eps, w["head_plan"])
         ln = nnops.layernorm(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
                              self.layer_norm.eps)
         return run_chain(ln, w["head"])
@@ -518,6 +524,7 @@ class GraphModel(torch.nn.Module):
         from nbd import _lib
         enc = self.node_encoder if isinstance(self.node_encoder, MLP) else None
         if (not self.use_one_call_train or self.aggr == "max" or x_in.shape[0] == 0 or lists.src.numel() == 0
+                or x_in.requires_grad            # a gradient with respect to the input: the per-layer Functions provide it
                 or (enc is not None and (enc.has_norm or (self.training and enc.dropout > 0) or len(enc.lins) > _lib.TRAIN_MAX_MLP))
                 or len(self.gnns) > _lib.GNN_MAX_LAYERS):
             return None

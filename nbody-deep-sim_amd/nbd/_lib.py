@@ -177,6 +177,9 @@ SIGNATURES = {
     "nbd_segment_reduce_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "nbd_layernorm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
                                   c_void_p]),
+    "nbd_ln_mlp_head_lds_bytes": (c_size_t, [c_int, c_int, POINTER(c_int)]),
+    "nbd_ln_mlp_head_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int, POINTER(c_void_p),
+                                    POINTER(c_void_p), POINTER(c_int), c_void_p, c_int, c_void_p, c_float, c_int, c_void_p]),
     "nbd_contconv_bin_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "nbd_contconv_fused_supported": (c_int, [c_int, c_int, c_int]),

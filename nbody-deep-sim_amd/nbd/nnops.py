@@ -130,6 +130,58 @@ def reachable_cells(d: int, radius: float, margin: float = 1e-3):
     return cells, cell_map
 
 
+def ln_mlp_head_plan(c: int, head, gamma=None, beta=None):
+    """What nbd_ln_mlp_head_f32 needs from a decoder chain [(W, b, act)] (gnn.head_chain) over c LayerNorm channels, or
+    None when the shapes are outside the fused kernel (it then runs as layernorm + linears): the hidden layers'
+    weights transposed ([in][out]) -- with hidden layers the LayerNorm's gamma / beta folded into the first Linear
+    (W1 diag(gamma), b1 + W1 beta) --, the ctypes arrays, the tensors to keep alive."""
+    n = len(head)
+    if not 1 <= n <= 3 or any(act != ("tanh" if i < n - 1 else None) for i, (_, _, act) in enumerate(head)):
+        return None
+    dims = [c] + [w.shape[0] for w, _, _ in head]
+    if any(w.shape[1] != d for (w, _, _), d in zip(head, dims[:-1])):
+        return None
+    darr = (ctypes.c_int * (n + 1))(*dims)
+    if _lib.lib().nbd_ln_mlp_head_lds_bytes(c, n, darr) == 0:
+        return None
+    ws = [w for w, _, _ in head]
+    bs = [b for _, b, _ in head]
+    folded = n >= 2
+    if folded:
+        w1, b1 = ws[0], bs[0]
+        if beta is not None:
+            shift = w1 @ beta
+            b1 = shift if b1 is None else b1 + shift
+        if gamma is not None:
+            w1 = w1 * gamma.unsqueeze(0)
+        ws, bs = [w1] + ws[1:], [b1] + bs[1:]
+    ws = [w.t().contiguous() if i < n - 1 else w.contiguous() for i, w in enumerate(ws)]
+    bs = [None if b is None else b.contiguous() for b in bs]
+    return {"n": n, "dims": darr, "out_dim": dims[-1], "keep": (ws, bs), "folded": folded,
+            "w": (ctypes.c_void_p * n)(*[t.data_ptr() for t in ws]),
+            "b": (ctypes.c_void_p * n)(*[_lib.ptr(t) for t in bs])}
+
+
+def ln_mlp_head(x, gamma, beta, eps, plan, out=None, kick_vel=None, kick_c=0.0):
+    """out (n, out_dim) = MLP(LayerNorm(x)) in one launch (nbd_ln_mlp_head_f32); kick_vel += kick_c * out when given.
+    gamma / beta must be the ones the plan was built with (a plan with hidden layers carries them folded)."""
+    n, c = x.shape
+    ldx = _mat(x, "x")
+    od = plan["out_dim"]
+    if out is None or tuple(out.shape) != (n, od) or out.dtype != torch.float32 or out.stride(1) != 1 or out.device != x.device:
+        out = torch.empty((n, od), dtype=torch.float32, device=x.device)
+    if kick_vel is not None and (tuple(kick_vel.shape) != (n, od) or kick_vel.dtype != torch.float32 or not kick_vel.is_contiguous()):
+        raise _lib.NbdError("ln_mlp_head: kick_vel must be a contiguous fp32 (n, out_dim) tensor")
+    g_ptr = None if plan["folded"] else _vec(gamma, c, "gamma")
+    b_ptr = None if plan["folded"] else _vec(beta, c, "beta")
+    with _lib.on_device(x.device):
+        _lib.check(_lib.lib().nbd_ln_mlp_head_f32(x.data_ptr(), ldx, c, g_ptr, b_ptr,
+                                                  float(eps), plan["n"], plan["w"], plan["b"], plan["dims"], out.data_ptr(),
+                                                  out.stride(0), _lib.ptr(kick_vel), float(kick_c), n,
+                                                  _lib.current_stream(x.device)), "nbd_ln_mlp_head_f32")
+    return out
+
+
 def contconv_bin(pos, feat, rowptr, centres, d, radius_sq, out=None, node_begin=0, count=None, cell_map=None,
                  cells_out=None):
     """A (count, cells_out * I): feature-side trilinear binning of ContinuousConv (contconv.py:80-93) for the

@@ -199,6 +199,49 @@ def test_layernorm_matches_torch(gpu_device):
         assert (got - ref).abs().max() < 5e-6
 
 
+@pytest.mark.parametrize("n,dims", [(1000, [256, 64, 32, 3]), (77, [130, 20, 3]), (5, [68, 3]), (300, [4, 7, 64, 8]),
+                                    (2, [256, 64, 64, 1]), (513, [200, 33, 5])])
+def test_layernorm_decoder_in_one_launch_matches_torch(n, dims, gpu_device):
+    """nbd_ln_mlp_head_f32 (LayerNorm + tanh MLP decoder + optional half-kick) against torch fp64, and against the
+    separate launches it replaces; shapes outside it report themselves (plan None)."""
+    from gnn import head_chain, run_chain
+    from nbd import nnops
+    torch.manual_seed(len(dims) * 1000 + n)
+    c = dims[0]
+    x = torch.randn(n, c) * 2 + 0.5
+    ln = torch.nn.LayerNorm(c)
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(torch.nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2:
+            layers.append(torch.nn.Tanh())
+    mlp = torch.nn.Sequential(*layers) if len(layers) > 1 else layers[0]
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-1, 1)
+        ref = mlp.double()(ln.double()(x.double())).float()
+    mlp, ln = mlp.float().cuda(), ln.float().cuda()
+    head = head_chain(mlp)
+    plan = nnops.ln_mlp_head_plan(c, head, ln.weight.detach(), ln.bias.detach())
+    assert plan is not None
+    xg = x.cuda()
+    got = nnops.ln_mlp_head(xg, ln.weight.detach(), ln.bias.detach(), ln.eps, plan)
+    assert (got.cpu() - ref).abs().max() < 1e-5 * max(1.0, float(ref.abs().max()))
+    sep = run_chain(nnops.layernorm(xg, ln.weight.detach(), ln.bias.detach(), ln.eps), head)
+    assert (got - sep).abs().max() < 1e-5 * max(1.0, float(ref.abs().max()))
+    # a column slice of a wider buffer as input, the caller's buffer as output, the half-kick in the epilogue
+    wide = torch.randn(n, c + 5, device="cuda")
+    wide[:, 2:2 + c] = xg
+    vel = torch.randn(n, dims[-1], device="cuda")
+    v0 = vel.clone()
+    out = torch.empty(n, dims[-1], device="cuda")
+    got2 = nnops.ln_mlp_head(wide[:, 2:2 + c], ln.weight.detach(), ln.bias.detach(), ln.eps, plan, out=out, kick_vel=vel, kick_c=0.25)
+    assert got2.data_ptr() == out.data_ptr() and torch.equal(got2, got)
+    assert torch.equal(vel, v0 + 0.25 * got)
+    # outside the kernel's shapes: no plan
+    assert nnops.ln_mlp_head_plan(300, [(torch.zeros(3, 300), None, None)]) is None
+    assert nnops.ln_mlp_head_plan(64, [(torch.zeros(100, 64), None, "tanh"), (torch.zeros(3, 100), None, None)]) is None
+
+
 def _copy_state(dst, src):
     missing = dst.load_state_dict(src.state_dict(), strict=True)
     return missing

@@ -11,12 +11,16 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03f_prof_
 echo bench trace done
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03f_prof_cc -o run -- python3 $R/tools/cc_rollout.py 100 > $R/gpurun_out/r03f_prof_cc.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03f_prof_gnn -o run -- python3 $R/tools/bench_gnn.py 50 > $R/gpurun_out/r03f_prof_gnn.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03f_prof_train -o run -- python3 $R/tools/bench_train.py 20 > $R/gpurun_out/r03f_prof_train.log 2>&1
 echo traces done
 cd $R
+python tools/bench_train.py 20 > gpurun_out/r03f_train_bench.json 2>/dev/null
+python tools/train_phases.py 30 > gpurun_out/r03f_train_phases.json 2>/dev/null
+echo train done
 tools/pmc_run.sh r03f_pmc_cc -- python3 $R/tools/bench_contconv.py 4
 tools/pmc_lds.sh r03f_pmclds_cc -- python3 $R/tools/bench_contconv.py 4
 python tools/summarize_pmc_kernels.py "gpurun_out/r03f_pmc" gpurun_out/r03f_pmc_cc_summary.json contconv_stream_kernel contconv_pairs contconv_stream_finish > /dev/null
-for t in bench cc gnn; do
+for t in bench cc gnn train; do
   f=$(find gpurun_out/r03f_prof_$t -name "*kernel_trace.csv" | head -1)
   python tools/summarize_trace.py $f gpurun_out/r03f_${t}_trace_summary.json > /dev/null
   cp $(find gpurun_out/r03f_prof_$t -name "*kernel_stats.csv" | head -1) gpurun_out/r03f_${t}_kernel_stats.csv
