@@ -483,6 +483,43 @@ int nbd_gnn_train_forward_f32(const nbd_gnn_train_args* args, nbd_stream_t strea
 int nbd_gnn_train_backward_f32(const nbd_gnn_train_args* args, const float* dout, int lddout,
                                const nbd_gnn_train_grads* grads, nbd_stream_t stream);
 
+/* ---- ContinuousConvModel's training step the same way (contconv.py:218-247; csrc/train_model.hip): node encoder (PyG MLP:
+ * Linear -> BatchNorm1d on BATCH statistics (enc_bn = 1; running statistics updated in place when bn_rmean / bn_rvar are
+ * given, momentum bn_momentum) -> tanh per hidden layer, plain last Linear; enc_bn = 0: no norm; n_enc = 0: no encoder), the
+ * ContinuousConv layers (agg sum / mean, tanh) over the caller's pair lists -- pairs_fwd[l] / pairs_adj[l] from
+ * nbd_contconv_pairs_jobs_f32 over the forward (rowptr_fwd, cap_fwd) and adjoint (rowptr_adj, cap_adj) groupings, per
+ * layer's filter resolution; pairs_adj[0] may be NULL without an encoder --, LayerNorm over [encoder output | last layer],
+ * decoder MLP. filt[l]: the layer's (cells_total, in, out) filters as the module holds them; kept[l] (int64 [n_cells]) /
+ * cell_map[l] (int32 [cells_total]) the reachable-cell maps; scale: the 1 / in-degree row scale of a mean aggregation or
+ * NULL. Shapes outside nbd_contconv_fused_supported in either direction: workspace_bytes() returns 0 (the caller keeps the
+ * per-layer path). Same args struct and workspace for both calls. */
+typedef struct nbd_cc_train_args {
+  int n; const float* x; int ldx; int in_ch;
+  int n_enc; const float* enc_w[NBD_TRAIN_MAX_MLP]; const float* enc_b[NBD_TRAIN_MAX_MLP]; int enc_dim[NBD_TRAIN_MAX_MLP + 1];
+  int enc_bn; const float* bn_g[NBD_TRAIN_MAX_MLP]; const float* bn_b[NBD_TRAIN_MAX_MLP]; float bn_eps[NBD_TRAIN_MAX_MLP];
+  float* bn_rmean[NBD_TRAIN_MAX_MLP]; float* bn_rvar[NBD_TRAIN_MAX_MLP]; float bn_momentum[NBD_TRAIN_MAX_MLP];
+  int n_layers; int cdim;
+  const float* filt[NBD_GNN_MAX_LAYERS]; const int64_t* kept[NBD_GNN_MAX_LAYERS]; const int* cell_map[NBD_GNN_MAX_LAYERS];
+  int n_cells[NBD_GNN_MAX_LAYERS]; int cells_total[NBD_GNN_MAX_LAYERS];
+  const void* pairs_fwd[NBD_GNN_MAX_LAYERS]; const void* pairs_adj[NBD_GNN_MAX_LAYERS];
+  const int* rowptr_fwd; int64_t cap_fwd; const int* rowptr_adj; int64_t cap_adj;
+  const float* scale;
+  const float* ln_g; const float* ln_b; float ln_eps;
+  int n_head; const float* head_w[NBD_TRAIN_MAX_MLP]; const float* head_b[NBD_TRAIN_MAX_MLP]; int head_dim[NBD_TRAIN_MAX_MLP + 1];
+  float* out; int ldout;
+  void* workspace; size_t workspace_bytes;
+} nbd_cc_train_args;
+typedef struct nbd_cc_train_grads {
+  float* enc_w[NBD_TRAIN_MAX_MLP]; float* enc_b[NBD_TRAIN_MAX_MLP]; float* bn_g[NBD_TRAIN_MAX_MLP]; float* bn_b[NBD_TRAIN_MAX_MLP];
+  float* filt[NBD_GNN_MAX_LAYERS];
+  float* ln_g; float* ln_b;
+  float* head_w[NBD_TRAIN_MAX_MLP]; float* head_b[NBD_TRAIN_MAX_MLP];
+} nbd_cc_train_grads;
+size_t nbd_cc_train_workspace_bytes(const nbd_cc_train_args* args);
+int nbd_cc_train_forward_f32(const nbd_cc_train_args* args, nbd_stream_t stream);
+int nbd_cc_train_backward_f32(const nbd_cc_train_args* args, const float* dout, int lddout, const nbd_cc_train_grads* grads,
+                              nbd_stream_t stream);
+
 /* ---- ContinuousConv.forward (contconv.py:80-98), block-sparse and fused: only the (node, filter cell) blocks
  * some edge touches are multiplied, and the binned features never reach HBM (csrc/contconv_fused.hip).
  * For in_channels % 4 == 0, in_channels <= 128 (nbd_contconv_fused_supported), inference and training alike (the

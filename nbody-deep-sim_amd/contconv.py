@@ -450,6 +450,56 @@ class ContinuousConvModel(nn.Module):
                 x = torch.nn.functional.dropout(x, p=enc.dropout, training=True)
         return x
 
+    use_one_call_train = True    # forward + backward of the whole model through ONE C-ABI call each (csrc/train_model.hip)
+
+    def _one_call_train(self, x, pos, lists):
+        """The training forward as one autograd node (ag.ContConvModelFn), or None when the configuration is outside what
+        nbd_cc_train_*_f32 covers: a layer off the fused kernels' shapes, max / min aggregation, active dropout, an
+        encoder BatchNorm in (sticky) eval mode, fewer than two nodes."""
+        from nbd import _lib
+        n = x.shape[0]
+        enc = self.node_encoder if isinstance(self.node_encoder, MLP) else None
+        if (not self.use_one_call_train or n < 2 or x.requires_grad or len(self.contconv) > _lib.GNN_MAX_LAYERS
+                or (self.training and (self.continuous_conv_dropout > 0 or self.encoder_dropout > 0))
+                or any(not l.trains_fused() or l.agg not in ("mean", "sum", "add") for l in self.contconv)
+                or len({("mean" if l.agg == "mean" else "sum") for l in self.contconv}) != 1
+                or (enc is not None and (len(enc.lins) > _lib.TRAIN_MAX_MLP or (enc.has_norm and not self.training)))):
+            return None
+        head = [self.output] if isinstance(self.output, nn.Linear) else [m for m in self.output if isinstance(m, nn.Linear)]
+        if len(head) > _lib.TRAIN_MAX_MLP:
+            return None
+        params, bns = [], []
+        if enc is not None:
+            for lin in enc.lins:
+                params += [lin.weight, lin.bias]
+            if enc.has_norm:
+                bns = [h.module for h in enc.norms]
+                if any(b.weight is None or b.bias is None for b in bns):
+                    return None
+                for b in bns:
+                    params += [b.weight, b.bias]
+        layers = []
+        for layer in self.contconv:
+            idx, cmap, nc = layer.cells()
+            layers.append((layer.filter_resolution, idx, cmap, nc))
+            params.append(layer.filters)
+        params += [self.layer_norm.weight, self.layer_norm.bias]
+        for lin in head:
+            params += [lin.weight, lin.bias]
+        if any(p is None for p in params):
+            return None
+        graph = ag.ConvGraph.from_lists(pos, float(np.float32(self.radius ** 2)), lists)
+        wants = []
+        for li, (d, idx, cmap, nc) in enumerate(layers):
+            wants.append((d, cmap, nc, False))
+            if li > 0 or enc is not None:
+                wants.append((d, cmap, nc, True))
+        graph.prebuild(wants)
+        spec = {"enc_dims": enc.channels if enc is not None else None, "bns": bns, "layers": layers,
+                "cdim": self.continuous_conv_dim, "mean": self.contconv[0].agg == "mean", "ln_eps": self.layer_norm.eps,
+                "head_dims": [head[0].in_features] + [lin.out_features for lin in head]}
+        return ag.ContConvModelFn.apply(x, graph, spec, *params)
+
     def _forward_autograd(self, data):
         x7 = data.x
         if not x7.is_cuda:
@@ -459,6 +509,9 @@ class ContinuousConvModel(nn.Module):
         pos = x[:, :3].contiguous()
         lists = graphops.radius_lists(pos, self.radius, getattr(data, "batch", None), loop=self.self_loops,
                                       max_num_neighbors=self.max_num_neighbors)
+        one = self._one_call_train(x, pos, lists)
+        if one is not None:
+            return one
         enc = self._encoder_autograd(x) if isinstance(self.node_encoder, MLP) else x
         h = enc
         # one graph object for all layers: forward lists of every resolution and the adjoint lists of the layers whose

@@ -325,4 +325,265 @@ int nbd_gnn_train_backward_f32(const nbd_gnn_train_args* args, const float* dout
   return status();
 }
 
+
+// ============================================================================================ ContinuousConvModel
+// contconv.py:218-247 the same way: node encoder (PyG MLP: Linear -> BatchNorm1d on BATCH statistics -> tanh per hidden
+// layer, plain last Linear; or no encoder), the ContinuousConv layers on the pair lists of the caller's graph (forward:
+// fused kernel; filters.grad: nbd_contconv_filter_grad_full_f32; feature gradient: the fused kernel over the adjoint
+// lists with every cell's filter transposed), LayerNorm over [enc | h], decoder. The pair lists are the caller's
+// (nbd_contconv_pairs_jobs_f32, once per forward pass for all layers); everything else is enqueued here.
+namespace {
+
+__global__ __launch_bounds__(256) void bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ var, int c,
+                                                         float momentum, float unbias, float* __restrict__ rmean,
+                                                         float* __restrict__ rvar) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= c) return;
+  // torch: running = (1 - momentum) * running + momentum * batch statistic (the variance unbiased, n / (n - 1))
+  rmean[i] = rmean[i] * (1.0f - momentum) + mean[i] * momentum;
+  rvar[i] = rvar[i] * (1.0f - momentum) + var[i] * (momentum * unbias);
+}
+
+struct CcWs {
+  float* enc_lin[NBD_TRAIN_MAX_MLP];     // hidden encoder layers: the Linear's output (BatchNorm's input) ...
+  float* enc_act[NBD_TRAIN_MAX_MLP];     // ... and tanh(BatchNorm(.)) (or tanh(.) without norm)
+  float *bn_mean[NBD_TRAIN_MAX_MLP], *bn_var[NBD_TRAIN_MAX_MLP], *bn_rstd[NBD_TRAIN_MAX_MLP];
+  float* h[NBD_GNN_MAX_LAYERS];          // conv layer outputs but the last (that one lands in zcat[:, E:])
+  float *zcat, *ln, *head_act[NBD_TRAIN_MAX_MLP];
+  float *wf, *g, *g0, *g1, *dz, *wt, *dxa, *dxb;
+  void *fws, *gws; size_t fws_bytes, gws_bytes;
+  Scratch sc;
+  int E, C, M;
+};
+
+bool cc_args_ok(const nbd_cc_train_args& a) {
+  if (a.n <= 0 || a.in_ch <= 0 || a.cdim <= 0 || a.cdim > 128 || a.n_layers < 1 || a.n_layers > NBD_GNN_MAX_LAYERS) return false;
+  if (a.n_enc < 0 || a.n_enc > NBD_TRAIN_MAX_MLP || a.n_head < 1 || a.n_head > NBD_TRAIN_MAX_MLP) return false;
+  if (a.n_enc && a.enc_dim[0] != a.in_ch) return false;
+  const int E = a.n_enc ? a.enc_dim[a.n_enc] : a.in_ch;
+  if (a.head_dim[0] != E + a.cdim || ((E + a.cdim) & 1)) return false;
+  for (int i = 0; i <= a.n_enc && a.n_enc; ++i) if (a.enc_dim[i] <= 0) return false;
+  for (int i = 0; i <= a.n_head; ++i) if (a.head_dim[i] <= 0) return false;
+  for (int l = 0; l < a.n_layers; ++l) {
+    const int I = l == 0 ? E : a.cdim;
+    if (!nbd_contconv_fused_supported(I, a.cdim, a.n_cells[l]) || !nbd_contconv_fused_supported(a.cdim, I, a.n_cells[l])) return false;
+    if (a.cells_total[l] < a.n_cells[l]) return false;
+  }
+  return true;
+}
+
+CcWs cc_layout(const nbd_cc_train_args& a, void* base, size_t* total) {
+  Arena ar{static_cast<char*>(base), 0};
+  CcWs w{};
+  const size_t n = (size_t)a.n;
+  const int O = a.cdim;
+  w.E = a.n_enc ? a.enc_dim[a.n_enc] : a.in_ch;
+  w.C = w.E + O;
+  int M = w.C > O ? w.C : O;
+  for (int i = 0; i <= a.n_enc && a.n_enc; ++i) M = a.enc_dim[i] > M ? a.enc_dim[i] : M;
+  for (int i = 0; i <= a.n_head; ++i) M = a.head_dim[i] > M ? a.head_dim[i] : M;
+  if (a.in_ch > M) M = a.in_ch;
+  w.M = M;
+  for (int i = 0; i + 1 < a.n_enc; ++i) {
+    const int d = a.enc_dim[i + 1];
+    w.enc_lin[i] = a.enc_bn ? ar.take(n * d) : nullptr;
+    w.enc_act[i] = ar.take(n * d);
+    w.bn_mean[i] = ar.take(d); w.bn_var[i] = ar.take(d); w.bn_rstd[i] = ar.take(d);
+  }
+  for (int l = 0; l + 1 < a.n_layers; ++l) w.h[l] = ar.take(n * O);
+  w.zcat = ar.take(n * w.C); w.ln = ar.take(n * w.C);
+  for (int i = 0; i + 1 < a.n_head; ++i) w.head_act[i] = ar.take(n * a.head_dim[i + 1]);
+  size_t wf_floats = 0, fws = 0, gws = 0;
+  for (int l = 0; l < a.n_layers; ++l) {
+    const int I = l == 0 ? w.E : O;
+    const size_t f1 = nbd_contconv_filter_floats(I, O, a.n_cells[l]), f2 = nbd_contconv_filter_floats(O, I, a.n_cells[l]);
+    wf_floats = f1 > wf_floats ? f1 : wf_floats; wf_floats = f2 > wf_floats ? f2 : wf_floats;
+    const size_t b1 = nbd_contconv_fused_workspace_bytes(a.n, a.n_cells[l], O), b2 = nbd_contconv_fused_workspace_bytes(a.n, a.n_cells[l], I);
+    fws = b1 > fws ? b1 : fws; fws = b2 > fws ? b2 : fws;
+    const size_t g1 = (size_t)a.n_cells[l] * I * O * sizeof(float) + nbd_contconv_filter_grad_workspace_bytes(a.n, a.n_cells[l], I, O);
+    gws = g1 > gws ? g1 : gws;
+  }
+  w.wf = ar.take(wf_floats + 16);
+  w.g = ar.take(n * M); w.g0 = ar.take(n * M); w.g1 = ar.take(n * M); w.dz = ar.take(n * w.C);
+  w.wt = ar.take((size_t)M * M); w.dxa = ar.take(n * M); w.dxb = ar.take(n * M);
+  w.fws_bytes = fws; w.fws = ar.take(fws / sizeof(float) + 64);
+  w.gws_bytes = gws; w.gws = ar.take(gws / sizeof(float) + 64);
+  size_t sb = (size_t)32 * M * (M + 1) * sizeof(float);
+  const size_t cs = nbd_colsum_workspace_bytes(a.n, 2 * M), ls = nbd_layernorm_bwd_workspace_bytes(a.n, w.C);
+  const size_t lw = nbd_linear_workspace_bytes(a.n, M, M), bw = nbd_batchnorm_train_workspace_bytes(a.n, M);
+  sb = cs > sb ? cs : sb; sb = ls > sb ? ls : sb; sb = lw > sb ? lw : sb; sb = bw > sb ? bw : sb;
+  w.sc.bytes = sb;
+  w.sc.p = ar.take(sb / sizeof(float) + 64);
+  if (total) *total = ar.off + 256;
+  return w;
+}
+
+}  // namespace
+
+size_t nbd_cc_train_workspace_bytes(const nbd_cc_train_args* args) {
+  if (!args || !cc_args_ok(*args)) return 0;
+  size_t total = 0;
+  cc_layout(*args, nullptr, &total);
+  return total;
+}
+
+int nbd_cc_train_forward_f32(const nbd_cc_train_args* args, nbd_stream_t stream) {
+  if (!args || !cc_args_ok(*args)) return NBD_E_BADARG;
+  const nbd_cc_train_args& a = *args;
+  if (!a.x || a.ldx < a.in_ch || !a.out || !a.rowptr_fwd || !a.workspace || (reinterpret_cast<uintptr_t>(a.workspace) & 255))
+    return NBD_E_BADARG;
+  size_t need = 0;
+  const CcWs w = cc_layout(a, a.workspace, &need);
+  if (a.workspace_bytes < need) return NBD_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int n = a.n, O = a.cdim, E = w.E, C = w.C;
+  int rc = 0;
+  // ---- node encoder (contconv.py:135-143,222): Linear -> BatchNorm (batch statistics) -> tanh ... plain last Linear
+  if (a.n_enc == 0) {
+    copy2d_kernel<<<(unsigned)(((size_t)n * E + 255) / 256), 256, 0, st>>>(a.x, a.ldx, w.zcat, C, n, E);
+  } else {
+    const float* cur = a.x;
+    int ld = a.ldx;
+    for (int i = 0; i < a.n_enc; ++i) {
+      const bool last = i == a.n_enc - 1;
+      const Lin L{a.enc_w[i], a.enc_b[i], a.enc_dim[i], a.enc_dim[i + 1]};
+      if (last) {
+        rc = lin_fwd(cur, ld, L, 0, nullptr, w.zcat, C, n, w.sc, stream);
+        if (rc) return rc;
+      } else if (a.enc_bn) {
+        rc = lin_fwd(cur, ld, L, 0, nullptr, w.enc_lin[i], L.out, n, w.sc, stream);
+        if (rc) return rc;
+        rc = nbd_batchnorm_train_fwd_f32(w.enc_lin[i], L.out, n, L.out, a.bn_g[i], a.bn_b[i], a.bn_eps[i], 1, w.enc_act[i], L.out,
+                                         w.bn_mean[i], w.bn_var[i], w.bn_rstd[i], w.sc.p, w.sc.bytes, stream);
+        if (rc) return rc;
+        if (a.bn_rmean[i] && a.bn_rvar[i])     // running statistics, as torch updates them in training mode
+          bn_running_kernel<<<ceil_div(L.out, 256), 256, 0, st>>>(w.bn_mean[i], w.bn_var[i], L.out, a.bn_momentum[i],
+                                                                  n > 1 ? (float)n / (float)(n - 1) : 1.0f, a.bn_rmean[i],
+                                                                  a.bn_rvar[i]);
+        cur = w.enc_act[i]; ld = L.out;
+        continue;
+      } else {
+        rc = lin_fwd(cur, ld, L, 1, nullptr, w.enc_act[i], L.out, n, w.sc, stream);
+        if (rc) return rc;
+      }
+      cur = last ? w.zcat : w.enc_act[i]; ld = last ? C : L.out;
+    }
+  }
+  // ---- ContinuousConv layers (contconv.py:80-98,225-231): h = tanh(scale * sum_cells A . F)
+  const float* feat = w.zcat;
+  int ldf = C;
+  for (int l = 0; l < a.n_layers; ++l) {
+    const int I = l == 0 ? E : O;
+    const bool last = l == a.n_layers - 1;
+    rc = nbd_contconv_shuffle_filters_f32(a.filt[l], a.kept[l], a.n_cells[l], I, O, 0, w.wf, stream);
+    if (rc) return rc;
+    float* ho = last ? w.zcat + E : w.h[l];
+    const int ldo = last ? C : O;
+    rc = nbd_contconv_fused_f32(feat, ldf, I, a.rowptr_fwd, n, a.cap_fwd, a.pairs_fwd[l], w.wf, a.n_cells[l], O, a.scale, 1, ho, ldo,
+                                w.fws, w.fws_bytes, stream);
+    if (rc) return rc;
+    feat = ho; ldf = ldo;
+  }
+  // ---- LayerNorm over [enc | h] and the decoder (contconv.py:233-234)
+  rc = nbd_layernorm_f32(w.zcat, C, C, a.ln_g, a.ln_b, a.ln_eps, w.ln, C, n, stream);
+  if (rc) return rc;
+  const float* cur = w.ln;
+  int ld = C;
+  for (int i = 0; i < a.n_head; ++i) {
+    const bool last = i == a.n_head - 1;
+    const Lin L{a.head_w[i], a.head_b[i], a.head_dim[i], a.head_dim[i + 1]};
+    float* y = last ? a.out : w.head_act[i];
+    const int ldy = last ? a.ldout : L.out;
+    if (last && a.ldout < L.out) return NBD_E_BADARG;
+    rc = lin_fwd(cur, ld, L, last ? 0 : 1, nullptr, y, ldy, n, w.sc, stream);
+    if (rc) return rc;
+    cur = y; ld = ldy;
+  }
+  return status();
+}
+
+int nbd_cc_train_backward_f32(const nbd_cc_train_args* args, const float* dout, int lddout, const nbd_cc_train_grads* grads,
+                              nbd_stream_t stream) {
+  if (!args || !grads || !cc_args_ok(*args)) return NBD_E_BADARG;
+  const nbd_cc_train_args& a = *args;
+  const nbd_cc_train_grads& gr = *grads;
+  if (!a.workspace || (reinterpret_cast<uintptr_t>(a.workspace) & 255)) return NBD_E_BADARG;
+  size_t need = 0;
+  const CcWs w = cc_layout(a, a.workspace, &need);
+  if (a.workspace_bytes < need) return NBD_E_WORKSPACE;
+  if (!dout || lddout < a.head_dim[a.n_head]) return NBD_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int n = a.n, O = a.cdim, E = w.E, C = w.C;
+  int rc = 0;
+  // ---- decoder, last Linear first
+  const float* dy = dout;
+  int lddy = lddout;
+  for (int i = a.n_head - 1; i >= 0; --i) {
+    const bool last = i == a.n_head - 1;
+    const Lin L{a.head_w[i], a.head_b[i], a.head_dim[i], a.head_dim[i + 1]};
+    const float* x = i == 0 ? w.ln : w.head_act[i - 1];
+    const int ldx = i == 0 ? C : a.head_dim[i];
+    const float* y = last ? a.out : w.head_act[i];
+    const int ldy = last ? a.ldout : L.out;
+    float* dx = (i & 1) ? w.dxa : w.dxb;
+    rc = lin_bwd(dy, lddy, y, ldy, last ? 0 : 1, x, ldx, L, nullptr, w.g0, gr.head_w[i], gr.head_b[i], dx, L.in, w.wt, n, w.sc, stream);
+    if (rc) return rc;
+    dy = dx; lddy = L.in;
+  }
+  rc = nbd_layernorm_bwd_f32(w.zcat, C, C, a.ln_g, a.ln_eps, dy, lddy, w.dz, C, gr.ln_g, gr.ln_b, n, w.sc.p, w.sc.bytes, stream);
+  if (rc) return rc;
+  // ---- ContinuousConv layers, last first. dz = [d enc | d h_L]
+  const float* dh = w.dz + E;
+  int lddh = C;
+  for (int l = a.n_layers - 1; l >= 0; --l) {
+    const int I = l == 0 ? E : O;
+    const bool last = l == a.n_layers - 1;
+    const float* hl = last ? w.zcat + E : w.h[l];
+    const int ldh = last ? C : O;
+    const float* fin = l == 0 ? w.zcat : (l - 1 == a.n_layers - 1 ? w.zcat + E : w.h[l - 1]);
+    const int ldfin = l == 0 ? C : O;
+    // g = scale * (1 - h^2) * dh
+    rc = nbd_act_bwd_f32(dh, lddh, hl, ldh, 1, a.scale, w.g, O, n, O, stream);
+    if (rc) return rc;
+    rc = nbd_contconv_filter_grad_full_f32(fin, ldfin, I, w.g, O, O, a.rowptr_fwd, n, a.cap_fwd, a.pairs_fwd[l], a.n_cells[l],
+                                           a.cell_map[l], a.cells_total[l], gr.filt[l], w.gws, w.gws_bytes, stream);
+    if (rc) return rc;
+    const bool need_dx = l > 0 || a.n_enc > 0;
+    if (need_dx) {
+      if (!a.pairs_adj[l] || !a.rowptr_adj) return NBD_E_BADARG;
+      rc = nbd_contconv_shuffle_filters_f32(a.filt[l], a.kept[l], a.n_cells[l], I, O, 1, w.wf, stream);
+      if (rc) return rc;
+      float* dfin = (l & 1) ? w.dxa : w.dxb;
+      rc = nbd_contconv_fused_f32(w.g, O, O, a.rowptr_adj, n, a.cap_adj, a.pairs_adj[l], w.wf, a.n_cells[l], I, nullptr, 0, dfin, I,
+                                  w.fws, w.fws_bytes, stream);
+      if (rc) return rc;
+      if (l > 0) { dh = dfin; lddh = O; }
+      else add2d_kernel<<<(unsigned)(((size_t)n * E + 255) / 256), 256, 0, st>>>(w.dz, C, dfin, E, n, E);   // enc feeds layer 0 and the concatenation
+    }
+  }
+  // ---- node encoder
+  dy = w.dz; lddy = C;
+  for (int i = a.n_enc - 1; i >= 0; --i) {
+    const bool last = i == a.n_enc - 1;
+    const Lin L{a.enc_w[i], a.enc_b[i], a.enc_dim[i], a.enc_dim[i + 1]};
+    const float* x = i == 0 ? a.x : w.enc_act[i - 1];
+    const int ldx = i == 0 ? a.ldx : a.enc_dim[i];
+    float* dx = i > 0 ? ((i & 1) ? w.dxa : w.dxb) : nullptr;
+    if (last) {
+      rc = lin_bwd(dy, lddy, nullptr, 0, 0, x, ldx, L, nullptr, w.g1, gr.enc_w[i], gr.enc_b[i], dx, L.in, w.wt, n, w.sc, stream);
+    } else if (a.enc_bn) {
+      // y = tanh(BatchNorm(t)), t = Linear(x): dt, dgamma, dbeta from dy; then the Linear
+      rc = nbd_batchnorm_train_bwd_f32(w.enc_lin[i], L.out, n, L.out, a.bn_g[i], w.bn_mean[i], w.bn_rstd[i], 1, w.enc_act[i], L.out,
+                                       dy, lddy, w.g1, L.out, gr.bn_g[i], gr.bn_b[i], w.sc.p, w.sc.bytes, stream);
+      if (rc) return rc;
+      rc = lin_bwd(w.g1, L.out, nullptr, 0, 0, x, ldx, L, nullptr, w.g0, gr.enc_w[i], gr.enc_b[i], dx, L.in, w.wt, n, w.sc, stream);
+    } else {
+      rc = lin_bwd(dy, lddy, w.enc_act[i], L.out, 1, x, ldx, L, nullptr, w.g1, gr.enc_w[i], gr.enc_b[i], dx, L.in, w.wt, n, w.sc, stream);
+    }
+    if (rc) return rc;
+    dy = dx; lddy = L.in;
+  }
+  return status();
+}
+
 }  // extern "C"

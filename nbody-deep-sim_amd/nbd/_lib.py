@@ -82,6 +82,27 @@ class GnnTrainGrads(ctypes.Structure):
                 ("ln_g", c_void_p), ("ln_b", c_void_p), ("head_w", _PF), ("head_b", _PF)]
 
 
+class CcTrainArgs(ctypes.Structure):
+    """Mirror of `nbd_cc_train_args` (include/nbd.h), field for field."""
+    _fields_ = [("n", c_int), ("x", c_void_p), ("ldx", c_int), ("in_ch", c_int),
+                ("n_enc", c_int), ("enc_w", _PF), ("enc_b", _PF), ("enc_dim", c_int * (TRAIN_MAX_MLP + 1)),
+                ("enc_bn", c_int), ("bn_g", _PF), ("bn_b", _PF), ("bn_eps", c_float * TRAIN_MAX_MLP),
+                ("bn_rmean", _PF), ("bn_rvar", _PF), ("bn_momentum", c_float * TRAIN_MAX_MLP),
+                ("n_layers", c_int), ("cdim", c_int),
+                ("filt", _PL), ("kept", _PL), ("cell_map", _PL), ("n_cells", c_int * GNN_MAX_LAYERS),
+                ("cells_total", c_int * GNN_MAX_LAYERS), ("pairs_fwd", _PL), ("pairs_adj", _PL),
+                ("rowptr_fwd", c_void_p), ("cap_fwd", c_int64), ("rowptr_adj", c_void_p), ("cap_adj", c_int64),
+                ("scale", c_void_p), ("ln_g", c_void_p), ("ln_b", c_void_p), ("ln_eps", c_float),
+                ("n_head", c_int), ("head_w", _PF), ("head_b", _PF), ("head_dim", c_int * (TRAIN_MAX_MLP + 1)),
+                ("out", c_void_p), ("ldout", c_int), ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
+class CcTrainGrads(ctypes.Structure):
+    """Mirror of `nbd_cc_train_grads` (include/nbd.h), field for field."""
+    _fields_ = [("enc_w", _PF), ("enc_b", _PF), ("bn_g", _PF), ("bn_b", _PF), ("filt", _PL),
+                ("ln_g", c_void_p), ("ln_b", c_void_p), ("head_w", _PF), ("head_b", _PF)]
+
+
 class CcPairsJob(ctypes.Structure):
     """Mirror of `nbd_cc_pairs_job` (include/nbd.h), field for field."""
     _fields_ = [("rowptr", c_void_p), ("centres", c_void_p), ("deg", c_void_p), ("edge_capacity", c_int64),
@@ -203,6 +224,9 @@ SIGNATURES = {
                                        c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "nbd_degree_scale_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nbd_gnn_forward_f32": (c_int, [c_void_p, c_void_p]),
+    "nbd_cc_train_workspace_bytes": (c_size_t, [POINTER(CcTrainArgs)]),
+    "nbd_cc_train_forward_f32": (c_int, [POINTER(CcTrainArgs), c_void_p]),
+    "nbd_cc_train_backward_f32": (c_int, [POINTER(CcTrainArgs), c_void_p, c_int, POINTER(CcTrainGrads), c_void_p]),
     "nbd_gnn_train_workspace_bytes": (c_size_t, [POINTER(GnnTrainArgs)]),
     "nbd_gnn_train_forward_f32": (c_int, [POINTER(GnnTrainArgs), c_void_p]),
     "nbd_gnn_train_backward_f32": (c_int, [POINTER(GnnTrainArgs), c_void_p, c_int, POINTER(GnnTrainGrads), c_void_p]),

@@ -421,3 +421,109 @@ class GnnModelFn(Function):
             _lib.check(_lib.lib().nbd_gnn_train_backward_f32(ctypes.byref(a), dout.data_ptr(), dout.stride(0), ctypes.byref(g),
                                                              _lib.current_stream(dev)), "nbd_gnn_train_backward_f32")
         return (None, None, None, *grads)
+
+
+class ContConvModelFn(Function):
+    """ContinuousConvModel.forward (contconv.py:218-234) as ONE autograd node over nbd_cc_train_forward_f32 /
+    nbd_cc_train_backward_f32 (csrc/train_model.hip); the pair lists come from the caller's ConvGraph (one launch for all
+    layers and both groupings). spec: dict built by ContinuousConvModel._one_call_train."""
+
+    @staticmethod
+    def forward(ctx, x, graph, spec, *params):
+        import ctypes
+        from . import _lib
+        n, dev = x.shape[0], x.device
+        p = [t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float() for t in params]
+        a = _lib.CcTrainArgs()
+        a.n, a.x, a.ldx, a.in_ch = n, x.data_ptr(), x.stride(0), x.shape[1]
+        k = 0
+        enc_dims = spec["enc_dims"]
+        a.n_enc = len(enc_dims) - 1 if enc_dims else 0
+        for i in range(a.n_enc):
+            a.enc_w[i], a.enc_b[i] = p[k].data_ptr(), p[k + 1].data_ptr()
+            k += 2
+        for i, d in enumerate(enc_dims or []):
+            a.enc_dim[i] = d
+        a.enc_bn = 1 if spec["bns"] else 0
+        for i, bn in enumerate(spec["bns"] or []):
+            a.bn_g[i], a.bn_b[i], a.bn_eps[i] = p[k].data_ptr(), p[k + 1].data_ptr(), float(bn.eps)
+            k += 2
+            if bn.track_running_stats and bn.running_mean is not None:
+                bn.num_batches_tracked += 1
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                a.bn_rmean[i], a.bn_rvar[i], a.bn_momentum[i] = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(mom)
+        layers = spec["layers"]                  # [(d, idx int64, cmap int32, n_cells)]
+        a.n_layers, a.cdim = len(layers), spec["cdim"]
+        keep = []
+        for l, (d, idx, cmap, nc) in enumerate(layers):
+            a.filt[l] = p[k].data_ptr()
+            k += 1
+            a.kept[l], a.cell_map[l], a.n_cells[l], a.cells_total[l] = idx.data_ptr(), cmap.data_ptr(), nc, d * d * d
+            pf, cap_f = graph.pairs(d, cmap, nc)
+            a.pairs_fwd[l] = pf.data_ptr()
+            keep.append(pf)
+            if l > 0 or a.n_enc > 0:
+                pa, cap_a = graph.pairs(d, cmap, nc, adjoint=True)
+                a.pairs_adj[l] = pa.data_ptr()
+                a.cap_adj = cap_a
+                keep.append(pa)
+            a.cap_fwd = cap_f
+        a.rowptr_fwd = graph.rows().data_ptr()
+        if graph.adj is not None:
+            a.rowptr_adj = graph.rows(adjoint=True).data_ptr()
+        scale = None
+        if spec["mean"]:
+            d0, _, cmap0, nc0 = layers[0]
+            pb, cap_e = graph.pairs(d0, cmap0, nc0)
+            scale = nnops.contconv_pairs_inv_degree(pb, n, cap_e, nc0)
+            a.scale = scale.data_ptr()
+        a.ln_g, a.ln_b, a.ln_eps = p[k].data_ptr(), p[k + 1].data_ptr(), float(spec["ln_eps"])
+        k += 2
+        a.n_head = len(spec["head_dims"]) - 1
+        for i in range(a.n_head):
+            a.head_w[i], a.head_b[i] = p[k].data_ptr(), p[k + 1].data_ptr()
+            k += 2
+        for i, d in enumerate(spec["head_dims"]):
+            a.head_dim[i] = d
+        out = torch.empty((n, spec["head_dims"][-1]), dtype=torch.float32, device=dev)
+        a.out, a.ldout = out.data_ptr(), out.stride(0)
+        L = _lib.lib()
+        need = L.nbd_cc_train_workspace_bytes(ctypes.byref(a))
+        if need == 0:
+            raise _lib.NbdError("nbd_cc_train_workspace_bytes: configuration rejected")
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), need
+        with _lib.on_device(dev):
+            _lib.check(L.nbd_cc_train_forward_f32(ctypes.byref(a), _lib.current_stream(dev)), "nbd_cc_train_forward_f32")
+        ctx.args, ctx.keep, ctx.spec = a, (x, ws, p, graph, keep, scale), spec
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        import ctypes
+        from . import _lib
+        a, (x, ws, p, graph, keep, scale), spec = ctx.args, ctx.keep, ctx.spec
+        dev = x.device
+        dout = dout if (dout.stride(1) == 1 and dout.dtype == torch.float32) else dout.contiguous().float()
+        grads = [torch.empty_like(t) for t in p]
+        g = _lib.CcTrainGrads()
+        k = 0
+        for i in range(a.n_enc):
+            g.enc_w[i], g.enc_b[i] = grads[k].data_ptr(), grads[k + 1].data_ptr()
+            k += 2
+        for i in range(len(spec["bns"] or [])):
+            g.bn_g[i], g.bn_b[i] = grads[k].data_ptr(), grads[k + 1].data_ptr()
+            k += 2
+        for l in range(a.n_layers):
+            g.filt[l] = grads[k].data_ptr()
+            k += 1
+        g.ln_g, g.ln_b = grads[k].data_ptr(), grads[k + 1].data_ptr()
+        k += 2
+        for i in range(a.n_head):
+            g.head_w[i], g.head_b[i] = grads[k].data_ptr(), grads[k + 1].data_ptr()
+            k += 2
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().nbd_cc_train_backward_f32(ctypes.byref(a), dout.data_ptr(), dout.stride(0), ctypes.byref(g),
+                                                            _lib.current_stream(dev)), "nbd_cc_train_backward_f32")
+        return (None, None, None, *grads)
