@@ -590,7 +590,7 @@ int nbd_contconv_filter_grad_full_f32(const float* feat, int ldf, int in_channel
 int nbd_contconv_shuffle_filters_f32(const float* filters, const int64_t* kept_cells, int n_cells, int in_channels,
                                      int out_channels, int transposed, float* filters_shuffled, nbd_stream_t stream);
 /* Byte offsets of the sections of a pair-list buffer (for reports and tests; the layout is otherwise opaque):
- * [0] per-(tile, cell) descriptors, [1] rows, [2] pair sources, [3] pair weights, [4] step records (int4 per 16-row
+ * [0] per-(tile, cell) descriptors, [1] rows, [2] pair records (int2 {source, weight bits}), [3] = [4], [4] step records (int4 per 16-row
  * step), [5] steps per tile (int32 [tiles], tiles = ceil(n / NBD_CC_TILE)), [6] cost per tile (int32 [tiles]),
  * [7] total bytes, [8] float [n]: 1 / max(in-degree, 1), the row scale of a mean aggregation (what
  * nbd_degree_scale_f32 mode 0 returns, written by the pair kernel as a by-product). offsets: 9 entries. The fused

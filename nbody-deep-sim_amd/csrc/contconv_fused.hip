@@ -156,8 +156,8 @@ struct PairJob {
   float sign;           // +1 forward lists, -1 adjoint lists (see edge_geo)
   const int* cell_map;
   int2 *desc, *rows;
-  int* pair_src;        // [8 * edge_capacity] source node of every (edge, corner) pair ...
-  float* pair_w;        // ... and its window * trilinear weight
+  int2* pair;           // [8 * edge_capacity] {source node, bits of window * trilinear weight} of every (edge, corner) pair: ONE
+                        // 8-byte record (two arrays at first: the placement phase is bound by the issue of its scattered stores)
   int4* steps;          // per tile (at step_base): {first row, cell | rows << 8 | steps left in the cell << 16, first pair, 0}
   int* tile_nsteps;     // [tiles]
   float* inv_deg;       // [n] 1 / max(in-degree, 1): the row scale of a mean aggregation, a by-product (saves a launch)
@@ -184,8 +184,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
   const float sign = job.sign;
   int2* __restrict__ desc = job.desc;
   int2* __restrict__ rows = job.rows;
-  int* __restrict__ psrc = job.pair_src;
-  float* __restrict__ pwgt = job.pair_w;
+  int2* __restrict__ prec = job.pair;
   const int kc = (n_cells + 3) & ~3;                       // padded cell count (even: two u16 per word)
   unsigned* cnt32 = smem;                                   // [TN][kc/2]
   unsigned* pwithin = cnt32 + TN * kc / 2;                  // [TN][kc]
@@ -367,7 +366,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
         if (k < 0) continue;
         const int slot = (int)((old[corner] >> (16 * (k & 1))) & 0xffffu) - 1;
         const size_t at = (size_t)pair_base + cell_pairbase[k] + pwithin[nl * kc + k] + slot;
-        psrc[at] = c_cur; pwgt[at] = ww[corner];
+        prec[at] = make_int2(c_cur, __float_as_int(ww[corner]));
       }
     }
   }
@@ -540,7 +539,7 @@ __host__ __device__ inline int range_begin(long long T, int w, int G) { return (
 
 struct CCArgs {
   const float* feat; int ldf, I; const int* rowptr; int n, n_tiles;
-  const int2* rows; const int* pair_src; const float* pair_w; const int4* steps; const int* tile_nsteps; const int* tile_cost;
+  const int2* rows; const int2* pair; const int4* steps; const int* tile_nsteps; const int* tile_cost;
   const int* cuts;     // [CC_GRID + 1] first step of every workgroup's range ...
   const int* tile_base;   // ... and [tiles + 1] first step of every tile: the plan, computed once per pair list (contconv_plan_kernel)
   const f4* filt; int n_cells, kq_count, colblocks, OP; float* partial;
@@ -630,8 +629,9 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
     f.rinfo = (A.rows + e8 + r.y)[r.z + min(lane, (r.x >> 8) & 31)];
     const int np = pr.y - pr.x;
     const int at0 = pr.x + min(lane, np - 1), at1 = pr.x + min(64 + lane, np - 1);
-    f.s0 = (A.pair_src + e8)[at0]; f.w0 = (A.pair_w + e8)[at0];
-    f.s1 = (A.pair_src + e8)[at1]; f.w1 = (A.pair_w + e8)[at1];
+    const int2 r0 = (A.pair + e8)[at0], r1 = (A.pair + e8)[at1];
+    f.s0 = r0.x; f.w0 = __int_as_float(r0.y);
+    f.s1 = r1.x; f.w1 = __int_as_float(r1.y);
   };
   int qbase = 0;
   for (int p0 = g0; p0 < g1; p0 += CC_CAP) {
@@ -733,8 +733,9 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
       for (int b0 = 0; !done; b0 += 16) {                            // one segment = 16 batches = 128 pairs
         if (b0 > 0) {
           const size_t at0 = e8 + pb + min(PB * b0 + lane, np - 1), at1 = e8 + pb + min(PB * b0 + 64 + lane, np - 1);
-          rs0 = A.pair_src[at0]; rw0 = A.pair_w[at0];
-          rs1 = A.pair_src[at1]; rw1 = A.pair_w[at1];
+          const int2 r0 = A.pair[at0], r1 = A.pair[at1];
+          rs0 = r0.x; rw0 = __int_as_float(r0.y);
+          rs1 = r1.x; rw1 = __int_as_float(r1.y);
         }
         __builtin_amdgcn_wave_barrier();
 #if defined(NBD_CC_ABL) && NBD_CC_ABL == 2          /* timing only: every row from a 64 KiB table (L1 / L2 hits) */
@@ -1146,7 +1147,7 @@ constexpr int WG_MAXT = 64;      // tiles per slab (one wave scans their row cou
 struct WGArgs {
   const float* feat; int ldf, I; const float* g; int ldg, O;
   const int* rowptr; int n, n_tiles, n_cells;
-  const int2* desc; const int2* rows; const int* pair_src; const float* pair_w; const int* tile_nsteps;
+  const int2* desc; const int2* rows; const int2* pair; const int* tile_nsteps;
   int* ucut;                   // [WG_RANGES + 1] first unit of every workgroup's range (contconv_wplan_kernel)
   float* partial;              // [(range + cell) < WG_RANGES + cells][I][O]
 };
@@ -1262,7 +1263,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void contconv_wgrad_kernel(const WGA
   // source index broadcast out of its lane (v_readlane): the first 8 at once, then 24, then 32 per trip -- every trip
   // inside one 64-record chunk, pairs summed in list order.
   struct S1 { int2 rec; int nexty, tile; long long e8; bool ok; };
-  struct S2 { int p0, np, sr; float wr, g0, g1; const int* ps; const float* pw; };
+  struct S2 { int p0, np, sr; float wr, g0, g1; const int2* pr; };
   auto stage1 = [&](int s) {
     S1 x;
     x.rec = make_int2(0, 0); x.nexty = 0; x.tile = 0; x.e8 = 0; x.ok = false;
@@ -1283,12 +1284,13 @@ __global__ __launch_bounds__(64 * WG_WAVES) void contconv_wgrad_kernel(const WGA
     y.p0 = x.ok ? UNI(x.rec.y) : 0;
     y.np = x.ok ? UNI(x.nexty - x.rec.y) : 0;
     const int node = x.ok ? UNI(x.tile * TN + x.rec.x) : 0;
-    y.ps = A.pair_src + x.e8; y.pw = A.pair_w + x.e8;
+    y.pr = A.pair + x.e8;
     y.sr = 0; y.wr = 0.f; y.g0 = 0.f; y.g1 = 0.f;
     if (y.np > 0) {                                        // wave-uniform (a row of the lists always holds a pair)
       const int at0 = y.p0 + min(lane, y.np - 1);          // past the row's end: its last pair again, weight 0
-      y.sr = y.ps[at0];
-      y.wr = lane < y.np ? y.pw[at0] : 0.f;
+      const int2 rec = y.pr[at0];
+      y.sr = rec.x;
+      y.wr = lane < y.np ? __int_as_float(rec.y) : 0.f;
       const float* gr = A.g + (size_t)node * A.ldg;
       y.g0 = lane < O ? gr[lane] : 0.f;
       y.g1 = lane + 64 < O ? gr[lane + 64] : 0.f;
@@ -1314,8 +1316,9 @@ __global__ __launch_bounds__(64 * WG_WAVES) void contconv_wgrad_kernel(const WGA
         const int next = base < 32 ? 32 : base + 32, len = next - base;
         if ((base & 63) == 0) {                            // the next 64 records
           const int at = p0 + min(base + lane, np - 1);
-          y.sr = y.ps[at];
-          y.wr = base + lane < np ? y.pw[at] : 0.f;
+          const int2 rec = y.pr[at];
+          y.sr = rec.x;
+          y.wr = base + lane < np ? __int_as_float(rec.y) : 0.f;
         }
         f2 t[32];
 #pragma unroll
@@ -1493,8 +1496,8 @@ PairsLayout pairs_layout(int n, int64_t edge_capacity, int n_cells) {
   size_t at = 0;
   L.desc = at; at += up(tiles * n_cells * sizeof(int2));
   L.rows = at; at += up(((size_t)8 * edge_capacity + tiles) * sizeof(int2));
-  L.src = at; at += up((size_t)8 * edge_capacity * sizeof(int));
-  L.w = at; at += up((size_t)8 * edge_capacity * sizeof(float));
+  L.src = at; at += up((size_t)8 * edge_capacity * sizeof(int2));      // {source, weight} records
+  L.w = at;                                                             // (no separate weight array any more)
   L.steps = at; at += up((step_base((int)tiles, (int)edge_capacity, n_cells) + 2) * sizeof(int4));
   L.nsteps = at; at += up(tiles * sizeof(int));
   L.cost = at; at += up(tiles * sizeof(int));
@@ -1543,7 +1546,7 @@ int nbd_contconv_pairs_jobs_f32(const float* pos, int n, float radius_sq, int n_
     const PairsLayout L = pairs_layout(n, q.edge_capacity, nc);
     char* base = static_cast<char*>(q.pair_lists);
     j.desc = reinterpret_cast<int2*>(base + L.desc); j.rows = reinterpret_cast<int2*>(base + L.rows);
-    j.pair_src = reinterpret_cast<int*>(base + L.src); j.pair_w = reinterpret_cast<float*>(base + L.w);
+    j.pair = reinterpret_cast<int2*>(base + L.src);
     j.steps = reinterpret_cast<int4*>(base + L.steps); j.tile_nsteps = reinterpret_cast<int*>(base + L.nsteps);
     j.tile_cost = reinterpret_cast<int*>(base + L.cost);
     j.inv_deg = reinterpret_cast<float*>(base + L.scale);
@@ -1625,8 +1628,7 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
   const PairsLayout L = pairs_layout(n, edge_capacity, n_cells);
   const char* base = static_cast<const char*>(pair_lists);
   const int2* rows = reinterpret_cast<const int2*>(base + L.rows);
-  const int* pair_src = reinterpret_cast<const int*>(base + L.src);
-  const float* pair_w = reinterpret_cast<const float*>(base + L.w);
+  const int2* pair = reinterpret_cast<const int2*>(base + L.src);
   const int4* steps = reinterpret_cast<const int4*>(base + L.steps);
   const int* tile_nsteps = reinterpret_cast<const int*>(base + L.nsteps);
   const int* tile_cost = reinterpret_cast<const int*>(base + L.cost);
@@ -1638,7 +1640,7 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
   const int kq_count = ceil_div(in_channels, 16);
   CCArgs A;
   A.feat = feat; A.ldf = ldf; A.I = in_channels; A.rowptr = rowptr; A.n = n; A.n_tiles = tiles;
-  A.rows = rows; A.pair_src = pair_src; A.pair_w = pair_w; A.steps = steps; A.tile_nsteps = tile_nsteps; A.tile_cost = tile_cost; A.cuts = cuts; A.tile_base = tile_base;
+  A.rows = rows; A.pair = pair; A.steps = steps; A.tile_nsteps = tile_nsteps; A.tile_cost = tile_cost; A.cuts = cuts; A.tile_base = tile_base;
   A.filt = reinterpret_cast<const f4*>(filters_shuffled); A.n_cells = n_cells; A.kq_count = kq_count;
   A.colblocks = ceil_div(out_channels, 16); A.OP = OP; A.partial = partial;
 #define CC_LAUNCH(K)                                                                                                \
@@ -1686,7 +1688,7 @@ int nbd_contconv_filter_grad_f32(const float* feat, int ldf, int in_channels, co
   A.feat = feat; A.ldf = ldf; A.I = in_channels; A.g = g; A.ldg = ldg; A.O = out_channels;
   A.rowptr = rowptr; A.n = n; A.n_tiles = ceil_div(n, TN); A.n_cells = n_cells;
   A.desc = reinterpret_cast<const int2*>(base + L.desc); A.rows = reinterpret_cast<const int2*>(base + L.rows);
-  A.pair_src = reinterpret_cast<const int*>(base + L.src); A.pair_w = reinterpret_cast<const float*>(base + L.w);
+  A.pair = reinterpret_cast<const int2*>(base + L.src);
   A.tile_nsteps = reinterpret_cast<const int*>(base + L.nsteps);
   A.ucut = static_cast<int*>(workspace);
   A.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + WG_HEADER_BYTES);

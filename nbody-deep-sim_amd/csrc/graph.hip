@@ -564,10 +564,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void radius_transpose_cached_k
     for (int q = 0; q < 4; ++q) take(c[q], ok[q]);
   }
   if (wd >= wcap) {
-    for (int base = wnbr[(size_t)j * wcap + wcap - 1] + 1; base < n; base += 64) {
-      const int c = base + lane;
-      const bool ok = c < n && dist2(pos, c, xj, yj, zj) < r2 && (loop || c != j) && j <= last[c];
-      take(c, ok);
+    // a truncated candidate list (a body of a dense clump): the row is completed by a scan behind the list's last index --
+    // 256 indices per trip (their positions and `last` in flight together), and only until the row is FULL: its length is
+    // known (the search counted the in-degrees that rowptr was scanned from), and rows are in ascending index, so nothing
+    // can follow the last entry. (64 per trip to the end of the index range, the first form, was the kernel's whole tail.)
+    const int want = rowptr[j + 1] - rowptr[j];
+    for (int base = wnbr[(size_t)j * wcap + wcap - 1] + 1; base < n && cnt < want; base += 256) {
+      bool ok[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = base + 64 * q + lane, cc = min(c, n - 1);
+        ok[q] = c < n && dist2(pos, cc, xj, yj, zj) < r2 && (loop || cc != j) && j <= last[cc];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) take(base + 64 * q + lane, ok[q]);
     }
   }
 }

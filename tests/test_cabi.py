@@ -70,6 +70,28 @@ def test_host_only_queries():
     assert L.nbd_shard_plan(1000, 990, 20, a, b, cc, d) == -1                           # range outside the system
     assert L.nbd_contconv_fused_supported(128, 128, 160) == 1 and L.nbd_contconv_fused_supported(70, 40, 27) == 0
     assert L.nbd_contconv_fused_supported(128, 128, 216) == 0                            # pair-list LDS tables: <= 160 cells
+    # round 3: the training-side queries
+    assert L.nbd_contconv_filter_grad_workspace_bytes(2034, 160, 128, 128) == 4096 + (512 + 160) * 128 * 128 * 4
+    assert L.nbd_contconv_filter_grad_workspace_bytes(0, 160, 128, 128) == 0
+    dims = (ctypes.c_int * 4)(256, 64, 32, 3)
+    assert L.nbd_ln_mlp_head_lds_bytes(256, 3, dims) > 0                                 # the published ContinuousConv decoder
+    assert L.nbd_ln_mlp_head_lds_bytes(300, 3, dims) == 0                                # dims[0] must be c, c <= 256
+    wide = (ctypes.c_int * 3)(64, 100, 3)
+    assert L.nbd_ln_mlp_head_lds_bytes(64, 2, wide) == 0                                 # hidden width <= 64
+    ga = _lib.GnnTrainArgs()
+    assert L.nbd_gnn_train_workspace_bytes(ctypes.byref(ga)) == 0                        # an all-zero configuration is rejected
+    ga.n, ga.f, ga.h, ga.n_layers, ga.n_head, ga.fixed_k = 100, 4, 64, 2, 1, 10
+    ga.head_dim[0], ga.head_dim[1] = 68, 3
+    assert L.nbd_gnn_train_workspace_bytes(ctypes.byref(ga)) > 100 * (68 + 2 * 128) * 4
+    ca = _lib.CcTrainArgs()
+    assert L.nbd_cc_train_workspace_bytes(ctypes.byref(ca)) == 0
+    ca.n, ca.in_ch, ca.cdim, ca.n_layers, ca.n_head = 500, 4, 64, 1, 1
+    ca.n_cells[0], ca.cells_total[0] = 64, 64
+    ca.head_dim[0], ca.head_dim[1] = 68, 3
+    assert L.nbd_cc_train_workspace_bytes(ctypes.byref(ca)) > 0
+    ca.cdim = 66                                                                        # out_channels % 4: the adjoint direction
+    ca.head_dim[0] = 70
+    assert L.nbd_cc_train_workspace_bytes(ctypes.byref(ca)) == 0
 
 
 def test_bad_arguments_are_rejected_without_touching_the_gpu():
@@ -81,6 +103,15 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert L.nbd_kick_f32(None, None, 3, 0.1, None) == -1
     assert L.nbd_leapfrog_step_f32(None, None, None, None, None, 8, 0.1, 0.1, 0.01, 1.0, None, None, 0, None) == -1
     assert L.nbd_energy_f32(None, None, 4, 0.1, 1.0, None, None, 0, None) == -1
+    assert L.nbd_contconv_pairs_jobs_f32(None, 5, 1.0, 0, None, None) == -1
+    assert L.nbd_contconv_filter_grad_f32(None, 128, 128, None, 128, 128, None, 5, 100, None, 160, None, None, 0, None) == -1
+    assert L.nbd_contconv_filter_grad_f32(None, 127, 127, None, 128, 128, None, 5, 100, None, 160, None, None, 0, None) == -1
+    assert L.nbd_contconv_shuffle_filters_f32(None, None, 4, 8, 8, 0, None, None) == -1
+    assert L.nbd_linear_wgrad_bias_f32(None, 4, None, 4, None, 10, 4, 4, None, 4, None, None, 0, None) == -1
+    assert L.nbd_rowptr_sorted_i64(None, 5, 3, None, None) == -1
+    assert L.nbd_gnn_train_forward_f32(None, None) == -1 and L.nbd_cc_train_forward_f32(None, None) == -1
+    dims = (ctypes.c_int * 2)(300, 3)
+    assert L.nbd_ln_mlp_head_f32(None, 300, 300, None, None, 1e-5, 1, None, None, dims, None, 3, None, 0.0, 4, None) == -1
     # n == 0 is a no-op, not an error
     assert L.nbd_pack_posm_f32(None, None, 0, None, None) == 0
     assert L.nbd_kick_f32(None, None, 0, 0.1, None) == 0
