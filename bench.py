@@ -226,7 +226,7 @@ def main():
             new_acc = torch.empty_like(sim.accelerations)
             direct.leapfrog_step(sim.positions, sim.velocities, sim.accelerations, new_acc, sim.masses,
                                  direct.f32(0.5 * sim.dt), direct.f32(sim.dt), sim._eps2, sim._g,
-                                 sim._posm, sim._ws, ev_begin=e0, ev_end=e1)
+                                 sim._posm, sim._ws, ev_begin=e0, ev_end=e1, uniform=getattr(sim, "_uniform", None))
             sim.accelerations = new_acc
         else:                                          # sharded step: events around BOTH force launches
             half, dt = direct.f32(0.5 * sim.dt), direct.f32(sim.dt)
@@ -310,11 +310,15 @@ def main():
             "bound": "mfma", "compute_unit": "fp32 VALU (v_pk_fma_f32 / v_rsq_f32), no MFMA instructions",
             "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-            "kernel": "accel_kernel<false,8>", "kernel_ms": k_ms, "flop_per_pair": FLOP_PER_PAIR,
+            "kernel": ("accel_kernel<false,8,uniform mass>" if getattr(sim, "_uniform", None) is not None
+                       else "accel_kernel<false,8>"),
+            "kernel_ms": k_ms, "flop_per_pair": FLOP_PER_PAIR,
             "pairs_per_launch": pairs_per_launch,
             "note": "compute-bound on fp32 VALU issue (no dense contraction: MFMA not applicable); peak = fp32 "
-                    "vector peak = fp32 MFMA peak. 20 flop/pair accounting; the instruction stream's own ceiling "
-                    "is 2 pairs/clk/SIMD = 62% of this peak at 2.4 GHz",
+                    "vector peak = fp32 MFMA peak. 20 flop/pair accounting (SURVEY 8d; what the kernel executes is "
+                    "fewer: equal masses factor out of the sum, 11 packed ops + 2 rsq per source and pair of targets). "
+                    "The instruction stream's own ceiling is 128 pairs per 60 issue cycles per SIMD = 66% of this peak "
+                    "at 2.4 GHz (general masses: 64 cycles, 62%)",
         },
     }
     if strong_leg is not None:

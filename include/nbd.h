@@ -140,6 +140,16 @@ int nbd_leapfrog_step_ev_f32(float* pos, float* vel, const float* acc_in, float*
                              const float* mass, int n, float dt_half, float dt, float softening_sq,
                              float g_const, float* posm, void* workspace, size_t workspace_bytes,
                              nbd_stream_t stream, void* ev_force_begin, void* ev_force_end);
+/* The same step for a system whose bodies all have the SAME mass (round 3; the published configurations: Plummer,
+ * m = 1 / N): the mass factors out of the force sum, a = (G m) sum_j d_ij s_ij^3, so the force kernel drops its per-pair
+ * multiply by m_j (11 packed fp32 ops + 2 v_rsq_f32 per source and pair of targets instead of 12 + 2) and g_const *
+ * mass_value is applied once, to the finished sum. The differences r_j - r_i stay the exact fp32 subtractions of
+ * simulation.py:80; one multiplication per sum rounds differently from one per term. The caller vouches that every
+ * entry of `mass` equals mass_value. Workspace: nbd_step_workspace_bytes(n). */
+int nbd_leapfrog_step_uniform_f32(float* pos, float* vel, const float* acc_in, float* acc_out, const float* mass,
+                                  float mass_value, int n, float dt_half, float dt, float softening_sq, float g_const,
+                                  float* posm, void* workspace, size_t workspace_bytes, nbd_stream_t stream,
+                                  void* ev_force_begin, void* ev_force_end);
 
 /* One whole EulerSimulator.step (simulation.py:173-187): force -> kick(dt) -> drift(dt). */
 int nbd_euler_step_f32(float* pos, float* vel, float* acc_out, const float* mass, int n, float dt,

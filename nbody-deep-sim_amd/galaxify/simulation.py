@@ -95,6 +95,12 @@ class BaseSimulator:
         # scratch owned by the simulator: packed sources (all ranks' bodies), slabs, energy partials
         self._posm = direct.alloc_posm(self.n, self.device)
         self._posm.zero_()
+        # equal masses (the published configurations): the leapfrog force kernel without its per-pair mass multiply, the
+        # common factor applied once to the finished sum. Checked here, once; NBD_UNIFORM_MASS=0 keeps the
+        # general kernel. The sharded step, the Euler step and compute_accelerations() use the general kernel.
+        self._uniform = (direct.uniform_mass(self.masses)
+                         if (not self._sharded and isinstance(self, LeapFrogSimulator)
+                             and os.environ.get("NBD_UNIFORM_MASS", "1") != "0") else None)
         if not self._sharded:
             self._ws = direct.step_workspace(max(self.n, 1), self.device)
             self._posm_local, self._mass_local, self._gather = self._posm, self.masses, None
@@ -256,7 +262,7 @@ class BaseSimulator:
         dt = direct.f32(self.dt)
         if isinstance(self, LeapFrogSimulator):
             direct.leapfrog_step(self.positions, self.velocities, acc, acc, self.masses, direct.f32(0.5 * self.dt), dt,
-                                 self._eps2, self._g, self._posm, self._ws)
+                                 self._eps2, self._g, self._posm, self._ws, uniform=self._uniform)
         else:
             direct.euler_step(self.positions, self.velocities, acc, self.masses, dt, self._eps2, self._g, self._posm,
                               self._ws)
@@ -345,7 +351,7 @@ class LeapFrogSimulator(BaseSimulator):
         if not self._sharded:
             new_acc = torch.empty_like(self.accelerations)
             direct.leapfrog_step(self.positions, self.velocities, self.accelerations, new_acc, self.masses,
-                                 half, dt, self._eps2, self._g, self._posm, self._ws)
+                                 half, dt, self._eps2, self._g, self._posm, self._ws, uniform=self._uniform)
             self.accelerations = new_acc
             return
         # sharded: kick+drift+pack of the own bodies -> all-gather in flight || own x own force block ->

@@ -144,6 +144,9 @@ SIGNATURES = {
     "nbd_leapfrog_step_ev_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                          c_float, c_float, c_float, c_float, c_void_p, c_void_p,
                                          c_size_t, c_void_p, c_void_p, c_void_p]),
+    "nbd_leapfrog_step_uniform_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                              c_float, c_float, c_float, c_float, c_void_p, c_void_p,
+                                              c_size_t, c_void_p, c_void_p, c_void_p]),
     "nbd_euler_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
                                    c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nbd_energy_workspace_bytes": (c_size_t, [c_int]),

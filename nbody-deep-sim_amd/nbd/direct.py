@@ -193,15 +193,34 @@ def snapshot(pos, vel, acc, out) -> None:
                                                _lib.current_stream(pos.device)), "nbd_snapshot_f32")
 
 
+def uniform_mass(mass: torch.Tensor):
+    """The common mass as a Python float when every body has the same, finite, positive mass -- what
+    nbd_leapfrog_step_uniform_f32 asks its caller to vouch for -- else None. One device read-back: call it once."""
+    if mass.numel() == 0:
+        return None
+    lo, hi = torch.aminmax(mass)
+    lo, hi = float(lo), float(hi)
+    return lo if (lo == hi and lo > 0.0 and lo != float("inf")) else None
+
+
 def leapfrog_step(pos, vel, acc_in, acc_out, mass, dt_half: float, dt: float, softening_sq: float,
-                  g_const: float, posm, workspace, ev_begin=None, ev_end=None) -> None:
+                  g_const: float, posm, workspace, ev_begin=None, ev_end=None, uniform=None) -> None:
     """One fused step; ev_begin/ev_end: optional torch.cuda.Event (already recorded once, so the
-    handle exists) recorded around the force kernel -- bench.py's roofline hook."""
+    handle exists) recorded around the force kernel -- bench.py's roofline hook. uniform: the bodies' common mass
+    (uniform_mass(mass)) -> the force kernel without its per-pair mass multiply (nbd_leapfrog_step_uniform_f32)."""
     n = pos.shape[0]
     for t, nm in ((pos, "pos"), (vel, "vel"), (acc_in, "acc_in"), (acc_out, "acc_out")):
         _chk(t, (n, 3), nm)
     _chk(mass, (n,), "mass"); _chk(posm, (padded_len(n), 4), "posm")
     with _lib.on_device(pos.device):
+        if uniform is not None:
+            _lib.check(_lib.lib().nbd_leapfrog_step_uniform_f32(
+                pos.data_ptr(), vel.data_ptr(), acc_in.data_ptr(), acc_out.data_ptr(), mass.data_ptr(), float(uniform), n,
+                dt_half, dt, softening_sq, g_const, posm.data_ptr(), workspace.data_ptr(), _nbytes(workspace),
+                _lib.current_stream(pos.device),
+                None if ev_begin is None else ev_begin.cuda_event,
+                None if ev_end is None else ev_end.cuda_event), "nbd_leapfrog_step_uniform_f32")
+            return
         _lib.check(_lib.lib().nbd_leapfrog_step_ev_f32(
             pos.data_ptr(), vel.data_ptr(), acc_in.data_ptr(), acc_out.data_ptr(), mass.data_ptr(), n,
             dt_half, dt, softening_sq, g_const, posm.data_ptr(), workspace.data_ptr(), _nbytes(workspace),

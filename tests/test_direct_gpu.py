@@ -167,6 +167,43 @@ def test_deterministic_and_partition_invariant(gpu_device):
     assert torch.isfinite(a0).all() and row_rel(_np(b), _np(a0)) < 2e-6
 
 
+def test_uniform_mass_leapfrog_step_matches_general_step_and_f64(gpu_device, monkeypatch):
+    """nbd_leapfrog_step_uniform_f32 (equal masses: the factor applied once to the finished sum, no per-pair multiply)
+    against the general fused step on the same state and against an fp64 evaluation; N a multiple of 64 and not (the
+    padded tail chunk takes the masked path); tiny softening (index-masked kernel) too; bit-identical run to run; the
+    simulator picks it only for equal, positive masses and NBD_UNIFORM_MASS=0 switches it off."""
+    from galaxify import simulation
+    from nbd.plummer import generate_plummer
+    for n, eps in ((4096, 0.05), (1000, 0.01), (193, 0.1), (130, 0.0)):
+        p, v, m = generate_plummer(n, seed=21 + n)
+        assert m.min() == m.max()
+        kw = dict(positions=p, velocities=v, masses=m, g_const=0.7, softening=eps, dt=0.01, calc_energy=False, device="cuda")
+        a = simulation.LeapFrogSimulator(**kw)
+        a2 = simulation.LeapFrogSimulator(**kw)
+        monkeypatch.setenv("NBD_UNIFORM_MASS", "0")
+        b = simulation.LeapFrogSimulator(**kw)
+        monkeypatch.delenv("NBD_UNIFORM_MASS")
+        assert a._uniform == float(np.float32(m[0])) and b._uniform is None
+        for _ in range(3):
+            a.step(); a2.step(); b.step()
+        for key in ("positions", "velocities", "accelerations"):
+            assert torch.equal(getattr(a, key), getattr(a2, key)), key
+            assert row_rel(_np(getattr(a, key)), _np(getattr(b, key))) < 2e-6, (n, key)
+        x = a.positions.double().cpu().numpy()
+        d = x[None, :, :] - x[:, None, :]
+        r2 = (d ** 2).sum(-1) + eps ** 2
+        np.fill_diagonal(r2, 1.0)
+        w = float(m[0]) * r2 ** -1.5
+        np.fill_diagonal(w, 0.0)
+        ref = 0.7 * (w[:, :, None] * d).sum(1)
+        assert row_rel(_np(a.accelerations), ref) < 2e-6 and row_rel(_np(b.accelerations), ref) < 2e-6
+    p, v, m = generate_plummer(256, seed=2)
+    m2 = m.copy(); m2[3] *= 2
+    assert simulation.LeapFrogSimulator(positions=p, velocities=v, masses=m2, device="cuda", calc_energy=False)._uniform is None
+    assert simulation.LeapFrogSimulator(positions=p, velocities=v, masses=0 * m, device="cuda", calc_energy=False)._uniform is None
+    assert simulation.EulerSimulator(positions=p, velocities=v, masses=m, device="cuda", calc_energy=False)._uniform is None
+
+
 def test_linearity_in_mass_and_g(gpu_device):
     """a is linear in the source masses and in G: size-independent property, no oracle needed."""
     from nbd import direct
