@@ -238,9 +238,9 @@ def main():
             loc = sim._posm_local[:direct.padded_len(pt.n_local)]
             acc = torch.empty_like(sim.accelerations)
             e0.record()
-            direct.shard_force_local(loc, pt.n_local, sim.n, pt.lo, sim._eps2, sim._ws)
+            direct.shard_force_local(loc, pt.n_local, sim.n, pt.lo, sim._eps2, sim._ws, uniform=getattr(sim, "_uniform", None))
             direct.shard_force_remote(sim._posm, sim.n, loc, pt.n_local, pt.lo, sim._eps2, sim._g, acc,
-                                      sim.velocities, half, sim._ws)
+                                      sim.velocities, half, sim._ws, uniform=getattr(sim, "_uniform", None))
             e1.record()
             sim.accelerations = acc
         evs.append((e0, e1))

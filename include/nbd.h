@@ -102,6 +102,14 @@ int nbd_shard_force_local_f32(const float* posm_local, int n_local, float soften
 int nbd_shard_force_remote_f32(const float* posm_all, int n_total, const float* posm_local, int n_local, int lo,
                                float softening_sq, float g_const, float* acc_out, float* vel, float c_kick,
                                void* workspace, size_t workspace_bytes, nbd_stream_t stream);
+/* The same two launches for a system of EQUAL masses (see nbd_leapfrog_step_uniform_f32): the force kernels without their
+ * per-pair mass multiply, g_const * mass_value applied once by the finishing pass. The caller vouches that every body's
+ * mass equals mass_value. */
+int nbd_shard_force_local_uniform_f32(const float* posm_local, int n_local, float softening_sq, void* workspace,
+                                      size_t workspace_bytes, int n_total, int lo, nbd_stream_t stream);
+int nbd_shard_force_remote_uniform_f32(const float* posm_all, int n_total, const float* posm_local, int n_local, int lo,
+                                       float softening_sq, float g_const, float mass_value, float* acc_out, float* vel,
+                                       float c_kick, void* workspace, size_t workspace_bytes, nbd_stream_t stream);
 
 /* v += c_kick * a ; x += c_drift * v ; posm = pack(x, m)   (in place on pos, vel)
  * LeapFrogSimulator.step first half, simulation.py:164,166 with c_kick = (float)(0.5*dt),

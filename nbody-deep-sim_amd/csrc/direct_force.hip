@@ -702,6 +702,42 @@ int nbd_shard_force_remote_f32(const float* posm_all, int n_total, const float* 
   return launch_status();
 }
 
+// The two force launches of the range-sharded step for a system of EQUAL masses (see nbd_leapfrog_step_uniform_f32): the
+// kernels without their per-pair mass multiply, g_const * mass_value applied once by the finishing kernel.
+int nbd_shard_force_local_uniform_f32(const float* posm_local, int n_local, float softening_sq, void* workspace,
+                                      size_t workspace_bytes, int n_total, int lo, nbd_stream_t stream) {
+  if (n_local < 0 || n_total < 0 || lo < 0 || lo + n_local > n_total) return NBD_E_BADARG;
+  if (n_local == 0) return 0;
+  if (!posm_local || misaligned16(posm_local)) return NBD_E_BADARG;
+  if (!workspace || workspace_bytes < nbd_shard_workspace_bytes(n_total, lo, n_local)) return NBD_E_WORKSPACE;
+  const ShardPlan sp = plan_shard(n_total, lo, n_local);
+  return launch_accel(posm_local, full_view(n_local, sp.local), posm_local, n_local, 0, softening_sq, 1.0f,
+                      static_cast<float*>(workspace), sp.local, (hipStream_t)stream, true);
+}
+
+int nbd_shard_force_remote_uniform_f32(const float* posm_all, int n_total, const float* posm_local, int n_local, int lo,
+                                       float softening_sq, float g_const, float mass_value, float* acc_out, float* vel,
+                                       float c_kick, void* workspace, size_t workspace_bytes, nbd_stream_t stream) {
+  if (n_local < 0 || n_total < 0 || lo < 0 || lo + n_local > n_total) return NBD_E_BADARG;
+  if (n_local == 0) return 0;
+  if (!posm_all || !posm_local || !acc_out || misaligned16(posm_all) || misaligned16(posm_local)) return NBD_E_BADARG;
+  if (!workspace || workspace_bytes < nbd_shard_workspace_bytes(n_total, lo, n_local)) return NBD_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const ShardPlan sp = plan_shard(n_total, lo, n_local);
+  float* slabs = static_cast<float*>(workspace);
+  const int n3 = 3 * n_local;
+  if (sp.remote.slabs > 0) {
+    SrcView sv;
+    excluded_view(n_total, lo, lo + n_local, &sv);
+    int rc = launch_accel(posm_all, sv, posm_local, n_local, lo, softening_sq, 1.0f,
+                          slabs + (size_t)sp.local.slabs * n3, sp.remote, st, true);
+    if (rc) return rc;
+  }
+  finish_kernel<<<ceil_div(n3, 64), 256, 0, st>>>(slabs, sp.local.slabs + sp.remote.slabs, (size_t)n3, g_const * mass_value,
+                                                   acc_out, vel, c_kick, n3);
+  return launch_status();
+}
+
 int nbd_kick_drift_f32(float* pos, float* vel, const float* acc, const float* mass, int n,
                        float c_kick, float c_drift, float* posm, nbd_stream_t stream) {
   if (n < 0 || (n > 0 && (!pos || !vel)) || (posm && (!mass || misaligned16(posm)))) return NBD_E_BADARG;

@@ -95,11 +95,13 @@ class BaseSimulator:
         # scratch owned by the simulator: packed sources (all ranks' bodies), slabs, energy partials
         self._posm = direct.alloc_posm(self.n, self.device)
         self._posm.zero_()
-        # equal masses (the published configurations): the leapfrog force kernel without its per-pair mass multiply, the
-        # common factor applied once to the finished sum. Checked here, once; NBD_UNIFORM_MASS=0 keeps the
-        # general kernel. The sharded step, the Euler step and compute_accelerations() use the general kernel.
+        # equal masses (the published configurations): the force kernel without its per-pair mass multiply, the common
+        # factor applied once to the finished sum -- in the fused leapfrog step and in both launches of the
+        # range-sharded force. Checked here, once (the masses are replicated on every rank: all ranks decide alike);
+        # NBD_UNIFORM_MASS=0 keeps the general kernel. The un-sharded Euler step and compute_accelerations() use the
+        # general kernel.
         self._uniform = (direct.uniform_mass(self.masses)
-                         if (not self._sharded and isinstance(self, LeapFrogSimulator)
+                         if ((self._sharded or isinstance(self, LeapFrogSimulator))
                              and os.environ.get("NBD_UNIFORM_MASS", "1") != "0") else None)
         if not self._sharded:
             self._ws = direct.step_workspace(max(self.n, 1), self.device)
@@ -138,11 +140,11 @@ class BaseSimulator:
         acc = torch.empty((p.n_local, 3), dtype=torch.float32, device=self.device)
         if p.n_local:
             local = self._posm_local[:direct.padded_len(p.n_local)]
-            direct.shard_force_local(local, p.n_local, self.n, p.lo, self._eps2, self._ws)
+            direct.shard_force_local(local, p.n_local, self.n, p.lo, self._eps2, self._ws, uniform=self._uniform)
         self._gather.finish(handle, self._posm)
         if p.n_local:
             direct.shard_force_remote(self._posm, self.n, local, p.n_local, p.lo, self._eps2, self._g, acc,
-                                      vel, c_kick, self._ws)
+                                      vel, c_kick, self._ws, uniform=self._uniform)
         return acc
 
     def compute_accelerations(self) -> torch.Tensor:

@@ -132,6 +132,9 @@ SIGNATURES = {
     "nbd_shard_force_local_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "nbd_shard_force_remote_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_float, c_void_p,
                                            c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    "nbd_shard_force_local_uniform_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "nbd_shard_force_remote_uniform_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_float, c_float,
+                                                   c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "nbd_kick_drift_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
                                    c_void_p, c_void_p]),
     "nbd_kick_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p]),

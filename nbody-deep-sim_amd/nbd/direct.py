@@ -114,18 +114,20 @@ def shard_workspace(n_total: int, lo: int, n_local: int, device) -> torch.Tensor
 
 
 def shard_force_local(posm_local: torch.Tensor, n_local: int, n_total: int, lo: int, softening_sq: float,
-                      workspace: torch.Tensor) -> None:
-    """First launch of the sharded force: own bodies as sources (runs while the all-gather is in flight)."""
+                      workspace: torch.Tensor, uniform=None) -> None:
+    """First launch of the sharded force: own bodies as sources (runs while the all-gather is in flight).
+    uniform: the bodies' common mass (uniform_mass) -> the kernel without its per-pair mass multiply."""
     _chk(posm_local, (padded_len(n_local), 4), "posm_local")
     with _lib.on_device(posm_local.device):
-        _lib.check(_lib.lib().nbd_shard_force_local_f32(
+        fn = _lib.lib().nbd_shard_force_local_f32 if uniform is None else _lib.lib().nbd_shard_force_local_uniform_f32
+        _lib.check(fn(
             posm_local.data_ptr(), n_local, float(softening_sq), workspace.data_ptr(), _nbytes(workspace),
             n_total, lo, _lib.current_stream(posm_local.device)), "nbd_shard_force_local_f32")
 
 
 def shard_force_remote(posm_all: torch.Tensor, n_total: int, posm_local: torch.Tensor, n_local: int, lo: int,
                        softening_sq: float, g_const: float, acc_out: torch.Tensor, vel: torch.Tensor | None,
-                       c_kick: float, workspace: torch.Tensor) -> None:
+                       c_kick: float, workspace: torch.Tensor, uniform=None) -> None:
     """Second launch: every other body as a source, then acc = G * sum(slabs) and v += c_kick * acc."""
     _chk(posm_all, (padded_len(n_total), 4), "posm_all")
     _chk(posm_local, (padded_len(n_local), 4), "posm_local")
@@ -133,6 +135,12 @@ def shard_force_remote(posm_all: torch.Tensor, n_total: int, posm_local: torch.T
     if vel is not None:
         _chk(vel, (n_local, 3), "vel")
     with _lib.on_device(posm_all.device):
+        if uniform is not None:
+            _lib.check(_lib.lib().nbd_shard_force_remote_uniform_f32(
+                posm_all.data_ptr(), n_total, posm_local.data_ptr(), n_local, lo, float(softening_sq),
+                float(g_const), float(uniform), acc_out.data_ptr(), _lib.ptr(vel), float(c_kick), workspace.data_ptr(),
+                _nbytes(workspace), _lib.current_stream(posm_all.device)), "nbd_shard_force_remote_uniform_f32")
+            return
         _lib.check(_lib.lib().nbd_shard_force_remote_f32(
             posm_all.data_ptr(), n_total, posm_local.data_ptr(), n_local, lo, float(softening_sq),
             float(g_const), acc_out.data_ptr(), _lib.ptr(vel), float(c_kick), workspace.data_ptr(),

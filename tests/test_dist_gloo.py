@@ -74,13 +74,16 @@ def _install_cpu_standins():
             inv.fill_diagonal_(0.0)
         return (diff * inv.unsqueeze(2) * src_mass.unsqueeze(0).unsqueeze(2)).sum(1)
 
-    def shard_force_local(posm_local, n_local, n_total, lo, eps2, ws):
+    def shard_force_local(posm_local, n_local, n_total, lo, eps2, ws, uniform=None):
         assert state["local"] is None, "local block issued twice without a remote block"
         own = posm_local[:n_local]
+        # uniform: the caller's claim that every body has this mass (the HIP kernels then drop their per-pair multiply)
+        assert uniform is None or bool((own[:, 3] == np.float32(uniform)).all()), "uniform-mass claim is false"
         state["local"] = partial(own[:, :3], own[:, 3], own[:, :3], 1.0, eps2, True)
 
-    def shard_force_remote(posm_all, n_total, posm_local, n_local, lo, eps2, g, acc_out, vel, c_kick, ws):
+    def shard_force_remote(posm_all, n_total, posm_local, n_local, lo, eps2, g, acc_out, vel, c_kick, ws, uniform=None):
         assert state["local"] is not None, "remote block issued before the local block"
+        assert uniform is None or bool((posm_all[:n_total, 3] == np.float32(uniform)).all()), "uniform-mass claim is false"
         assert torch.equal(posm_all[lo:lo + n_local], posm_local[:n_local]), "gather must have completed"
         assert not posm_all[n_total:].any() and not posm_local[n_local:].any(), "padding must stay zero"
         keep = torch.ones(n_total, dtype=torch.bool); keep[lo:lo + n_local] = False

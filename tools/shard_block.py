@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--rank", type=int, default=3)
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--general", action="store_true", help="the general-mass kernels (default: the equal-mass ones, as the simulator picks them for a Plummer sphere)")
     args = ap.parse_args()
     n, world, rank = args.n, args.world, args.rank
     n_loc = n // world
@@ -43,9 +44,10 @@ def main():
     acc = torch.zeros((n_loc, 3), device=dev)
     eps2, g = direct.f32(0.01), 1.0
     half, dt = direct.f32(0.005), direct.f32(0.01)
+    uni = None if args.general else direct.uniform_mass(mass_all)
     direct.pack_posm(pos, mass, out=posm_local)
-    direct.shard_force_local(posm_local, n_loc, n, lo, eps2, ws)
-    direct.shard_force_remote(posm, n, posm_local, n_loc, lo, eps2, g, acc, None, 0.0, ws)
+    direct.shard_force_local(posm_local, n_loc, n, lo, eps2, ws, uniform=uni)
+    direct.shard_force_remote(posm, n, posm_local, n_loc, lo, eps2, g, acc, None, 0.0, ws, uniform=uni)
 
     def step(events=None):
         if events: events[0].record()
@@ -53,9 +55,9 @@ def main():
         if events: events[1].record()
         posm[lo:lo + n_loc].copy_(posm_local[:n_loc])            # stands in for the all-gather's arrival
         if events: events[2].record()
-        direct.shard_force_local(posm_local, n_loc, n, lo, eps2, ws)
+        direct.shard_force_local(posm_local, n_loc, n, lo, eps2, ws, uniform=uni)
         if events: events[3].record()
-        direct.shard_force_remote(posm, n, posm_local, n_loc, lo, eps2, g, acc, vel, half, ws)
+        direct.shard_force_remote(posm, n, posm_local, n_loc, lo, eps2, g, acc, vel, half, ws, uniform=uni)
         if events: events[4].record()
 
     t0 = time.perf_counter()
