@@ -17,9 +17,11 @@ cd $R
 python tools/bench_train.py 20 > gpurun_out/r03f_train_bench.json 2>/dev/null
 python tools/train_phases.py 30 > gpurun_out/r03f_train_phases.json 2>/dev/null
 echo train done
+tools/pmc_run.sh r03f_pmc_bench -- python3 $R/bench.py --steps 10 --warmup 5 --prewarm-seconds 0.2 --cpu-seconds 0 --no-surrogates
+python tools/summarize_pmc_kernels.py "gpurun_out/r03f_pmc_bench" gpurun_out/r03f_pmc_bench_summary.json accel_kernel finish_kernel kick_drift > /dev/null
 tools/pmc_run.sh r03f_pmc_cc -- python3 $R/tools/bench_contconv.py 4
 tools/pmc_lds.sh r03f_pmclds_cc -- python3 $R/tools/bench_contconv.py 4
-python tools/summarize_pmc_kernels.py "gpurun_out/r03f_pmc" gpurun_out/r03f_pmc_cc_summary.json contconv_stream_kernel contconv_pairs contconv_stream_finish > /dev/null
+python tools/summarize_pmc_kernels.py "gpurun_out/r03f_pmc_cc" gpurun_out/r03f_pmc_cc_summary.json contconv_stream_kernel contconv_pairs contconv_stream_finish > /dev/null
 for t in bench cc gnn train; do
   f=$(find gpurun_out/r03f_prof_$t -name "*kernel_trace.csv" | head -1)
   python tools/summarize_trace.py $f gpurun_out/r03f_${t}_trace_summary.json > /dev/null
