@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/nbd.h"
 
@@ -131,7 +132,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_kernel(
 // overflows (only possible with hundreds of exactly tied distances) the wave falls back to the
 // insertion form for that centre.
 constexpr int kSelCap = 512;     // LDS list entries per wave
-constexpr int kBU = 4;           // candidate chunks (of 64) whose position loads are in flight together in scan B
+constexpr int kBU2 = 2;          // candidate double-chunks (of 128) whose position loads are in flight together in scan B
+typedef float f2v __attribute__((ext_vector_type(2)));
 
 template <int R, int RI>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_select_kernel(
@@ -214,29 +216,61 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_select_kernel(
     hinted = bound < inf;
   }
   if (!hinted) bound = phase_a();
-  // B: compact everything within the bound
-  auto phase_b = [&](float bnd) -> int {
+  // B: compact everything within the bound. The kernel is bound by VALU issue (r02 counters: 0.5 VALU instructions per
+  // candidate, 0.125 of them the distance), so the scan is written for instruction count: a lane tests TWO candidates
+  // (j and j + 64) with packed fp32 operations -- v_pk_add / v_pk_mul are IEEE per element and un-fused, so d2 is the
+  // specification's (dx*dx + dy*dy) + dz*dz bit for bit -- whole 128-candidate chunks need no bound checks, the
+  // self-exclusion test exists only in the loop = 0 instance, and the compaction runs only behind a non-empty mask. Chunk j..j+63 is compacted before j+64..j+127, so the list stays in ascending j (phase C's tie rule).
+  auto scan_b = [&](float bnd, auto kLoop) -> int {
   int count = 0;
-  for (int c0 = lo; c0 < hi; c0 += 64 * kBU) {
-    float px[kBU], py[kBU], pz[kBU];
+  // `hit` is the lane's own bit of `mask`; a list that would overflow is not written at all (the count still is, and
+  // count > kSelCap sends the centre to the insertion form below)
+  auto compact = [&](unsigned long long mask, bool hit, float d, int j) {
+    if (mask) {
+      const int pop = __builtin_popcountll(mask);
+      if (count + pop <= kSelCap) {
+        const int slot = count + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        if (hit) { ld[w][slot] = d; lj[w][slot] = j; }
+      }
+      count += pop;
+    }
+  };
+  f2v xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
+  asm volatile("" : "+v"(xi2), "+v"(yi2), "+v"(zi2));        // VGPR operands: an SGPR source halves v_pk issue
+  int c0 = lo;
+  for (; c0 + 128 * kBU2 <= hi; c0 += 128 * kBU2) {
+    f2v px[kBU2], py[kBU2], pz[kBU2];
 #pragma unroll
-    for (int u = 0; u < kBU; ++u) {
-      const int jc = min(c0 + 64 * u + lane, hi - 1);
-      px[u] = pos[3 * jc]; py[u] = pos[3 * jc + 1]; pz[u] = pos[3 * jc + 2];
+    for (int u = 0; u < kBU2; ++u) {
+      const float* q = pos + 3 * (size_t)(c0 + 128 * u + lane);
+      px[u] = f2v{q[0], q[192]}; py[u] = f2v{q[1], q[193]}; pz[u] = f2v{q[2], q[194]};
     }
 #pragma unroll
-    for (int u = 0; u < kBU; ++u) {
-      const int j = c0 + 64 * u + lane;
-      const float dx = px[u] - xi, dy = py[u] - yi, dz = pz[u] - zi;
-      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      const bool hit = j < hi && (loop || j != i) && d <= bnd;
-      const unsigned long long mask = __ballot(hit);
-      const int slot = count + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-      if (hit && slot < kSelCap) { ld[w][slot] = d; lj[w][slot] = j; }
-      count += __builtin_popcountll(mask);
+    for (int u = 0; u < kBU2; ++u) {
+      f2v d;
+      {
+#pragma clang fp contract(off)
+        const f2v dx = px[u] - xi2, dy = py[u] - yi2, dz = pz[u] - zi2;
+        d = (dx * dx + dy * dy) + dz * dz;
+      }
+      const int j = c0 + 128 * u + lane;
+      const bool h0 = d.x <= bnd && (kLoop || j != i), h1 = d.y <= bnd && (kLoop || j + 64 != i);
+      compact(__ballot(h0), h0, d.x, j);
+      compact(__ballot(h1), h1, d.y, j + 64);
     }
   }
+  for (; c0 < hi; c0 += 64) {                 // ragged end of the segment: one chunk at a time, loads clamped
+    const int j = c0 + lane;
+    const int jc = min(j, hi - 1);
+    const float dx = pos[3 * jc] - xi, dy = pos[3 * jc + 1] - yi, dz = pos[3 * jc + 2] - zi;
+    const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    const bool h = j < hi && d <= bnd && (kLoop || j != i);
+    compact(__ballot(h), h, d, j);
+  }
   return count;
+  };
+  auto phase_b = [&](float bnd) -> int {
+    return loop ? scan_b(bnd, std::true_type{}) : scan_b(bnd, std::false_type{});
   };
   int count = phase_b(bound);
   if (hinted && count < kk) {              // the hint was not kk distinct neighbours: do the full first scan
@@ -266,6 +300,327 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void knn_select_kernel(
       edge_index[e_total + base + rank] = i;
     }
   }
+}
+
+// ---- kNN, selection form with the positions resident in LDS (one un-segmented system of n <= kStagedMaxN bodies: the
+// rollout's search, gnn.py:205-215). The form above fetches every candidate chunk from L2 inside its scan and decides
+// chunk by chunk with scalar branches; in-kernel stamps at N = 4096, k = 50 (tools/knn_trace.py) put 7 us of its 15 into
+// the scan and 3.7 into the ranking, both chains of VALU -> SGPR -> branch round trips rather than arithmetic. Here a
+// 16-wave workgroup copies the position array into LDS once and every later phase is straight-line vector code:
+//   stage  4 bodies per thread: three 128-bit loads, three 128-bit LDS writes (layout below); the tail is padded with
+//          NaN, so the scan needs no bound checks (NaN <= bound is false)
+//   bound  from the hint (the previous step's own list) or, without one, phase A of the form above
+//   scan   256 candidates per trip, two per lane in packed fp32 (un-fused: d2 is the specification's bit for bit); the
+//          four ballot masks of a trip are parked with v_writelane in the lane whose number is the chunk's -- no
+//          branch, no compaction inside the loop
+//   expand lane c owns chunk c's mask: an exclusive prefix over the lanes' population counts gives its first list
+//          slot; it walks its set bits (a handful), recomputes d2 and writes (key = d2 bits : slot, j) -- ascending j
+//   rank   every listed entry counts the smaller keys, read back as 128-bit LDS broadcasts (two keys per read, one
+//          64-bit compare + one add-with-carry per key); d2 >= +0, so its bit pattern orders like the value and the
+//          slot in the low word is the tie rule (lower j first)
+// Same ordering rule and the same output as the form above (tested against it and the insertion form).
+#ifdef NBD_KNN_TRACE
+__device__ long long* g_knn_trace = nullptr;      // probe build (tools/build_probe.sh): 8 stamps per wave
+#define KT(s) if (lane == 0 && g_knn_trace) g_knn_trace[(size_t)(blockIdx.x * kLW + w) * 8 + (s)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define KT(s)
+#endif
+constexpr int kLW = 16;              // waves (= centres) per workgroup
+constexpr int kLCap = 256;           // list entries per wave; beyond: the insertion form on global memory
+constexpr int kStagedMaxN = 8192;    // 12 B * n + 12 B * kLW * kLCap <= 144 KiB of the CU's 160
+// LDS layout: per 128 bodies (two chunks c, c+1 of 64) x_c[64] x_c+1[64] y_c[64] y_c+1[64] z_c[64] z_c+1[64], 384 floats
+// -- one lane address serves a whole trip of the scan and ds_read2st64_b32 with immediate offsets (0,1) (2,3) (4,5)
+// delivers x, y, z of candidates j and j + 64 straight into the register pairs the packed arithmetic wants (with
+// x[64] y[64] z[64] per chunk hipcc paired the reads the other way and spent ten v_mov per trip re-pairing them).
+constexpr int kSC = 128;             // float stride between the components of a body in that layout
+__device__ __forceinline__ int staged_at(int j) { return (j >> 7) * 384 + (j & 127); }
+__device__ __forceinline__ int jl_of(const unsigned long long* key, int h) { return reinterpret_cast<const int*>(key)[2 * h]; }
+
+// Inclusive scans across the wave on DPP moves (row_shr 1/2/4/8 inside a row of 16, then row_bcast 15 and 31): six VALU
+// steps, no LDS round trips (__shfl_up is a ds_bpermute per step). Lanes a move does not reach keep the identity.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_move(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROWS, 0xf, false);
+}
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += dpp_move<0x111, 0xf>(0, v); v += dpp_move<0x112, 0xf>(0, v); v += dpp_move<0x114, 0xf>(0, v); v += dpp_move<0x118, 0xf>(0, v);
+  v += dpp_move<0x142, 0xa>(0, v); v += dpp_move<0x143, 0xc>(0, v);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float x) {       // the maximum over the wave, in every lane
+  const int ninf = __builtin_bit_cast(int, -__builtin_inff());
+  auto step = [&](int moved) { x = fmaxf(x, __builtin_bit_cast(float, moved)); };
+  step(dpp_move<0x111, 0xf>(ninf, __builtin_bit_cast(int, x))); step(dpp_move<0x112, 0xf>(ninf, __builtin_bit_cast(int, x)));
+  step(dpp_move<0x114, 0xf>(ninf, __builtin_bit_cast(int, x))); step(dpp_move<0x118, 0xf>(ninf, __builtin_bit_cast(int, x)));
+  step(dpp_move<0x142, 0xa>(ninf, __builtin_bit_cast(int, x))); step(dpp_move<0x143, 0xc>(ninf, __builtin_bit_cast(int, x)));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
+template <int R, int RI>
+__global__ __launch_bounds__(64 * kLW) void knn_select_staged_kernel(
+    const float* __restrict__ pos, int n, int k, int loop, int64_t e_total, int64_t* edge_index, const int64_t* hint,
+    int np) {                                          // np: floats of the position block (384 per 128 bodies)
+  extern __shared__ float sm[];
+  const int w = wave_id();
+  const int lane = threadIdx.x & 63;
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(sm + np) + w * kLCap;      // (d2 bits : j), one list per wave
+  unsigned* dd = reinterpret_cast<unsigned*>(sm + np + 2 * kLW * kLCap) + w * kLCap;        // the d2 bits alone, for the ranking
+  const int i = blockIdx.x * kLW + w;
+  const int kk = min(k, n - (loop ? 0 : 1));           // > 0: checked by the launcher
+  const float inf = __builtin_inff();
+  KT(0)
+  // the hint's entries are requested first: their round trip hides behind the staging
+  int hj[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int t = 64 * q + lane;
+    hj[q] = (hint && i < n && t < kk) ? (int)hint[(int64_t)i * kk + t] : -1;
+  }
+  {
+    const float4* p4 = reinterpret_cast<const float4*>(pos);
+    const int ngrp = n >> 2;                           // groups of 4 bodies = 48 B = three aligned float4
+    constexpr int kRounds = kStagedMaxN / 4 / (64 * kLW);
+    float4 a[kRounds][3];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {                // every load is issued before the first LDS write
+      const int g = min((int)threadIdx.x + 64 * kLW * r, max(ngrp - 1, 0));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a[r][c] = p4[3 * g + c];
+    }
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int g = threadIdx.x + 64 * kLW * r;
+      if (g < ngrp) {
+        float* d = sm + staged_at(4 * g);              // bodies 4g .. 4g+3 sit in one chunk: three 128-bit writes
+        *reinterpret_cast<float4*>(d) = make_float4(a[r][0].x, a[r][0].w, a[r][1].z, a[r][2].y);
+        *reinterpret_cast<float4*>(d + kSC) = make_float4(a[r][0].y, a[r][1].x, a[r][1].w, a[r][2].z);
+        *reinterpret_cast<float4*>(d + 2 * kSC) = make_float4(a[r][0].z, a[r][1].y, a[r][2].x, a[r][2].w);
+      }
+    }
+    const int n_pad = (n + 127) & ~127;
+    for (int j = 4 * ngrp + threadIdx.x; j < n_pad; j += 64 * kLW) {      // the last n % 4 bodies, then the padding (x = +inf)
+      float* d = sm + staged_at(j);
+      d[0] = j < n ? pos[3 * j] : inf; d[kSC] = j < n ? pos[3 * j + 1] : 0.f; d[2 * kSC] = j < n ? pos[3 * j + 2] : 0.f;
+    }
+  }
+  KT(1)
+  __syncthreads();
+  KT(2)
+  if (i >= n) return;                                  // no barrier below
+  const float xi = sm[staged_at(i)], yi = sm[staged_at(i) + kSC], zi = sm[staged_at(i) + 2 * kSC];
+
+  auto phase_a = [&]() -> float {
+    float m[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) m[r] = inf;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = c0 + 64 * u + lane;
+        const float* q = sm + staged_at(min(j, n - 1));
+        const float dx = q[0] - xi, dy = q[kSC] - yi, dz = q[2 * kSC] - zi;
+        float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        if (j >= n || (!loop && j == i)) d = inf;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const float lo_v = fminf(m[r], d); d = fmaxf(m[r], d); m[r] = lo_v; }
+      }
+    }
+    float bound = inf;
+    if (kk <= 64 * R) {
+      int rank[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) rank[r] = 0;
+      for (int l = 0; l < 64; ++l) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m[q]), l));
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            rank[r] += (v < m[r] || (v == m[r] && (q * 64 + l) < (r * 64 + lane))) ? 1 : 0;
+        }
+      }
+      float cand = -inf;
+#pragma unroll
+      for (int r = 0; r < R; ++r) cand = rank[r] == kk - 1 ? m[r] : cand;
+      const unsigned long long who = __ballot(cand != -inf);
+      bound = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand), __builtin_ctzll(who)));
+    }
+    return bound;
+  };
+
+  float bound = inf;
+  bool hinted = false;
+  if (hint) {
+    float hm = -inf;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (64 * q < kk) {                               // wave-uniform
+        const int j = hj[q];
+        const bool ok = j >= 0 && j < n && (loop || j != i);
+        const float* g = sm + staged_at(ok ? j : 0);
+        const float dx = g[0] - xi, dy = g[kSC] - yi, dz = g[2 * kSC] - zi;
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        hm = fmaxf(hm, 64 * q + lane < kk ? (ok ? d : inf) : -inf);
+      }
+    }
+    bound = wave_max(hm);
+    hinted = bound < inf;
+  }
+  if (!hinted) bound = phase_a();
+  KT(3)
+
+  // scan + expand; returns the list length (entries beyond kLCap are counted, not written). bnd is finite.
+  auto phase_b = [&](float bnd) -> int {
+    f2v xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi}, bnd2 = {bnd, bnd};
+    asm volatile("" : "+v"(xi2), "+v"(yi2), "+v"(zi2), "+v"(bnd2));      // VGPR operands: an SGPR source halves v_pk issue
+    // candidates 128 b + 2 lane and + 1 of block b: one ds_read_b64 per component (256 B/clk; ds_read2_b32 is 128)
+    auto far_pair = [&](const float* blk) -> f2v {      // bnd - d2 per candidate: sign bit set <=> d2 > bnd (exact)
+#pragma clang fp contract(off)
+      const f2v px = *reinterpret_cast<const f2v*>(blk + 2 * lane), py = *reinterpret_cast<const f2v*>(blk + kSC + 2 * lane),
+                pz = *reinterpret_cast<const f2v*>(blk + 2 * kSC + 2 * lane);
+      const f2v dx = px - xi2, dy = py - yi2, dz = pz - zi2;
+      return bnd2 - ((dx * dx + dy * dy) + dz * dz);
+    };
+    // The decisions stay in the lane: the sign bits of its candidates are shifted into hw[] (v_alignbit), 32 candidates =
+    // 16 blocks per word. No compare, no SGPR, no LDS store in the loop (parking ballot masks in LDS made the LDS pipe the
+    // bound: a ds_write2_b64 costs 13 LDS-path cycles, four per trip and wave). Padding bodies sit at x = +inf: d2 = inf,
+    // bnd - inf = -inf, "far".
+    // (plain shifts: hipcc folds them into one v_alignbit_b32; __builtin_amdgcn_alignbit on the elements of the packed
+    // result read the .x register for both elements in this toolchain)
+    auto push_sign = [](unsigned a, float v) -> unsigned { return (a << 1) | (__builtin_bit_cast(unsigned, v) >> 31); };
+    const int n_blocks = (n + 127) >> 7;
+    constexpr int kHW = kStagedMaxN / 128 / 16;         // words of 16 blocks
+    unsigned hw[kHW];
+#pragma unroll
+    for (int q = 0; q < kHW; ++q) {
+      unsigned acc = ~0u;                               // blocks past the end read as "far"
+      const int b_end = min(n_blocks, 16 * (q + 1));
+      int blk = 16 * q;
+      for (; blk + 2 <= b_end; blk += 2) {              // 256 candidates per trip: six 64-bit LDS reads in flight
+        const f2v f0 = far_pair(sm + blk * 384), f1 = far_pair(sm + blk * 384 + 384);
+        acc = push_sign(acc, f0.x);
+        acc = push_sign(acc, f0.y);
+        acc = push_sign(acc, f1.x);
+        acc = push_sign(acc, f1.y);
+      }
+      if (blk < b_end) {
+        const f2v f0 = far_pair(sm + blk * 384);
+        acc = push_sign(acc, f0.x);
+        acc = push_sign(acc, f0.y);
+        ++blk;
+      }
+      // bit p of ~acc <-> the (2 * done - 1 - p)-th candidate of this word, done = blocks scanned into it
+      const int done = max(blk - 16 * q, 0);
+      hw[q] = done > 0 ? (~acc) & (done >= 16 ? ~0u : ((1u << (2 * done)) - 1u)) : 0u;
+      if (!loop && done > 0 && (i >> 11) == q && lane == ((i & 127) >> 1))         // the centre itself (d2 = 0) is no candidate
+        hw[q] &= ~(1u << (2 * done - 1 - (2 * ((i >> 7) - 16 * q) + (i & 1))));
+    }
+    KT(7)
+    // expand: a lane first only NAMES its hits -- it walks its set bits (highest = lowest candidate first) and writes j to
+    // its run of list slots, found by a prefix sum over the lanes' population counts; no gather in that divergent loop.
+    // Then list entry h is finished by lane h, all lanes at once: one gather of the position, d2 again, key = (d2 : j).
+    int count = 0;
+    int* jl = reinterpret_cast<int*>(key);               // the names live in the low words of the keys-to-be
+#pragma unroll
+    for (int q = 0; q < kHW; ++q) {
+      if (16 * q >= n_blocks) break;                    // wave-uniform
+      unsigned m = hw[q];
+      const int done = min(n_blocks - 16 * q, 16);
+      const int pop = __builtin_popcount(m);
+      const int incl = wave_incl_scan(pop);
+      int off = count + incl - pop;
+      count += __builtin_amdgcn_readlane(incl, 63);
+      while (__ballot(m != 0)) {
+        if (m) {
+          const int p = 31 - __builtin_clz(m);
+          m &= ~(1u << p);
+          const int cand = 2 * done - 1 - p;            // candidate number inside the word: 2 * block + parity
+          if (off < kLCap) jl[2 * off] = 128 * (16 * q + (cand >> 1)) + 2 * lane + (cand & 1);
+          ++off;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int h = lane; h < min(count, kLCap); h += 64) {
+      const int j = jl[2 * h];
+      const float* g = sm + staged_at(j);
+      const float dx = g[0] - xi, dy = g[kSC] - yi, dz = g[2 * kSC] - zi;
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      jl[2 * h + 1] = __builtin_bit_cast(int, d);       // high word: d2 >= +0 orders like its bit pattern
+      dd[h] = __builtin_bit_cast(unsigned, d);
+    }
+    return count;
+  };
+  const int64_t base = (int64_t)i * kk;
+  if (!(bound < inf)) {                                // positions that overflow fp32: not this kernel's business
+    knn_insert_centre<RI>(pos, i, 0, n, kk, loop, base, e_total, edge_index);
+    return;
+  }
+  int count = phase_b(bound);
+  KT(4)
+  if (hinted && count < kk) {                          // the hint was not kk distinct neighbours
+    __builtin_amdgcn_wave_barrier();
+    bound = phase_a();
+    count = bound < inf ? phase_b(bound) : kLCap + 1;
+  }
+  if (count > kLCap) {                                 // cannot happen with distinct distances; massive ties can
+    knn_insert_centre<RI>(pos, i, 0, n, kk, loop, base, e_total, edge_index);
+    return;
+  }
+  // rank: entry h counts the entries with a smaller d2 -- 16 of them per trip, read as four 128-bit LDS broadcasts, one
+  // 32-bit compare + one add-with-carry each. Without equal distances that is the rank; equal distances make the ranks'
+  // sum fall short of count (count - 1) / 2, and only then the (d2 : j) keys are compared (ties -> lower j).
+  if (lane < 16 && count + lane < ((count + 15) & ~15)) { dd[count + lane] = ~0u; key[count + lane] = ~0ull; }   // kLCap % 16 == 0
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int rank[kLCap / 64];
+  int rank_sum = 0;
+#pragma unroll
+  for (int r = 0; r < kLCap / 64; ++r) {
+    rank[r] = 0;
+    if (64 * r >= count) break;                        // wave-uniform
+    const int h = 64 * r + lane;
+    const unsigned dh = h < count ? dd[h] : 0u;
+    int rk = 0;
+    for (int t0 = 0; t0 < count; t0 += 16) {
+      const uint4* dp = reinterpret_cast<const uint4*>(dd + t0);      // wave-uniform address
+      const uint4 a0 = dp[0], a1 = dp[1], a2 = dp[2], a3 = dp[3];
+      rk += (a0.x < dh) + (a0.y < dh) + (a0.z < dh) + (a0.w < dh) + (a1.x < dh) + (a1.y < dh) + (a1.z < dh) + (a1.w < dh) +
+            (a2.x < dh) + (a2.y < dh) + (a2.z < dh) + (a2.w < dh) + (a3.x < dh) + (a3.y < dh) + (a3.z < dh) + (a3.w < dh);
+    }
+    rank[r] = rk;
+    rank_sum += rk;
+  }
+  rank_sum = __builtin_amdgcn_readlane(wave_incl_scan(rank_sum), 63);
+  if (rank_sum != count * (count - 1) / 2) {           // equal distances in the list: the exact order
+#pragma unroll
+    for (int r = 0; r < kLCap / 64; ++r) {
+      if (64 * r >= count) break;
+      const int h = 64 * r + lane;
+      const unsigned long long kh = h < count ? key[h] : 0ull;
+      int rk = 0;
+      for (int t0 = 0; t0 < count; t0 += 8) {
+        const ulonglong2* kp = reinterpret_cast<const ulonglong2*>(key + t0);
+        const ulonglong2 k0 = kp[0], k1 = kp[1], k2 = kp[2], k3 = kp[3];
+        rk += (k0.x < kh) + (k0.y < kh) + (k1.x < kh) + (k1.y < kh) + (k2.x < kh) + (k2.y < kh) + (k3.x < kh) + (k3.y < kh);
+      }
+      rank[r] = rk;
+    }
+  }
+  KT(5)
+#pragma unroll
+  for (int r = 0; r < kLCap / 64; ++r) {
+    if (64 * r >= count) break;
+    const int h = 64 * r + lane;
+    if (h < count && rank[r] < kk) {
+      edge_index[base + rank[r]] = (int64_t)jl_of(key, h);
+      edge_index[e_total + base + rank[r]] = i;
+    }
+  }
+  KT(6)
 }
 
 // ---- radius: first `cap` hits in index order -> ELL lists nbr[n][cap], deg[n], last[n]
@@ -790,6 +1145,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void key_sort_kernel(const int
 
 extern "C" {
 
+#ifdef NBD_KNN_TRACE
+int nbd_debug_knn_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_knn_trace), &buf, sizeof(buf)); }
+#endif
+
 int nbd_knn_graph_f32(const float* pos, int n, int k, int loop, const int* seg_lo, const int* seg_hi,
                       const int64_t* out_off, int64_t num_edges, int64_t* edge_index, nbd_stream_t stream) {
   return nbd_knn_graph_hint_f32(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index, nullptr, stream);
@@ -809,6 +1168,27 @@ int nbd_knn_graph_hint_f32(const float* pos, int n, int k, int loop, const int* 
   // selection form by default; R = kept minima per lane (bound tightness), RI = insertion fallback width.
   // NBD_KNN_INSERTION=1 forces the insertion form (cross-check / comparison).
   static const bool force_insert = [] { const char* e = getenv("NBD_KNN_INSERTION"); return e && e[0] == '1'; }();
+  // one un-segmented system that fits LDS: the staged form (NBD_KNN_STAGED=0: the form that scans L2, for comparison)
+  static const bool staged_ok = [] { const char* e = getenv("NBD_KNN_STAGED"); return !(e && e[0] == '0'); }();
+  const int kk_all = k < n - (loop ? 0 : 1) ? k : n - (loop ? 0 : 1);
+  if (!force_insert && staged_ok && !seg_lo && !out_off && n <= kStagedMaxN && k <= 200 && kk_all > 0 &&
+      num_edges == (int64_t)n * kk_all && (reinterpret_cast<uintptr_t>(pos) & 15) == 0) {
+    const int np = (n + 127) / 128 * 384;
+    const size_t lds = ((size_t)np + 3 * kLW * kLCap) * sizeof(float);      // positions + the waves' 64-bit keys + d2 words
+    dim3 g2(ceil_div(n, kLW)), b2(64 * kLW);
+    using Kern = void (*)(const float*, int, int, int, int64_t, int64_t*, const int64_t*, int);
+    static const Kern kerns[4] = {knn_select_staged_kernel<1, 1>, knn_select_staged_kernel<2, 1>,
+                                  knn_select_staged_kernel<2, 2>, knn_select_staged_kernel<4, 4>};
+    static bool raised[4] = {false, false, false, false};      // > 64 KiB of dynamic LDS needs the attribute, once per kernel
+    const int v = k <= 40 ? 0 : k <= 64 ? 1 : k <= 100 ? 2 : 3;
+    if (!raised[v]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return status();
+      raised[v] = true;
+    }
+    kerns[v]<<<g2, b2, lds, st>>>(pos, n, k, loop, num_edges, edge_index, hint, np);
+    return status();
+  }
   if (!force_insert && k <= 40)
     knn_select_kernel<1, 1><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index, hint);
   else if (!force_insert && k <= 64)
