@@ -381,6 +381,15 @@ typedef struct nbd_gnn_layer_args {
   int ldout;
   float* kick_vel;        /* FINAL_HEAD only, or NULL: vel[n][ep_out] += kick_c * out_i, the second half-kick of  */
   float kick_c;           /* Trainer.step (trainer.py:225) in the layer's epilogue (multiply, then add)           */
+  /* Exponential tables (optional, h <= 64): tanh(P_i + Q_j) = 1 - 2 / (EP_i EQ_j + 1) with EP = 2^(c P), EQ = 2^(c Q),
+   * c = 2 log2 e -- one reciprocal per edge and channel instead of an exponential and a reciprocal, the edge loop's
+   * bound. epq [n][ldepq] = [EP (h) | EQ (h)] belongs to the SAME P/Q that pq (or x, wpq, bpq) describe: an entry whose
+   * |c v| exceeds 100 holds NaN, and a node that meets one is recomputed from pq / x exactly as without tables, so the
+   * result never depends on the tables' range. out_epq (NEXT_PQ*): the epilogue also writes the table of its `out`. */
+  const float* epq;
+  int ldepq;
+  float* out_epq;
+  int ldout_epq;
 } nbd_gnn_layer_args;
 int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream);
 
@@ -396,8 +405,29 @@ typedef struct nbd_gnn_forward_args {
   int64_t* edge_index;    /* [2][n * kk] */
   int n_layers;
   nbd_gnn_layer_args layers[NBD_GNN_MAX_LAYERS];
+  void* workspace;        /* optional, nbd_gnn_forward_workspace_bytes(): room for the layers' exponential tables (see  */
+  size_t workspace_bytes; /* nbd_gnn_layer_args.epq); with it and h <= 64, first layer formed from x, n <= 8192, the    */
+                          /* search kernel also emits the first layer's tables (nbd_knn_graph_hint_pq_f32) and every    */
+                          /* NEXT_PQ* epilogue the next one's. NULL / too small: the layers run without tables.         */
 } nbd_gnn_forward_args;
+size_t nbd_gnn_forward_workspace_bytes(const nbd_gnn_forward_args* args);    /* 0: this configuration uses no tables */
 int nbd_gnn_forward_f32(const nbd_gnn_forward_args* args, nbd_stream_t stream);
+
+/* nbd_knn_graph_hint_f32 for ONE un-segmented system (n <= 8192, k <= 200, pos 16-byte aligned; NBD_E_UNSUPPORTED
+ * otherwise, nothing launched) whose search kernel, one wave per centre, also writes that centre's row of the first
+ * EdgeConv layer's tables: epq[i] = [2^(c P_i) | 2^(c Q_i)], P = wpq[0:h] x_i + bpq, Q = wpq[h:2h] x_i (the fma order of
+ * nbd_gnn_layer_f32's on-the-fly form; h <= 64, f <= 8; |c v| > 100 -> NaN, see nbd_gnn_layer_args.epq). Replaces
+ * torch_cluster.knn (gnn.py:13) plus the first Linear of gnn.py:140-141 for the rollout. */
+typedef struct nbd_knn_pq_args {
+  const float* x;         /* [n][ldx], first f columns */
+  int ldx, f, h;
+  const float* wpq;       /* [2h][f] */
+  const float* bpq;       /* [h] */
+  float* epq;             /* [n][ldepq] = [EP (h) | EQ (h)] */
+  int ldepq;
+} nbd_knn_pq_args;
+int nbd_knn_graph_hint_pq_f32(const float* pos, int n, int k, int loop, int64_t num_edges, int64_t* edge_index,
+                              const int64_t* hint, const nbd_knn_pq_args* pq, nbd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Backward kernels: what `loss.backward()` executes in the reference's training step

@@ -41,6 +41,14 @@ __device__ __forceinline__ float fast_tanh(float x) {
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
+// the exponential-table form (nbd.h, nbd_gnn_layer_args.epq): 2^(c v), c = 2 log2 e; NaN marks an entry outside the range
+// in which EP * EQ can neither be inf * 0 nor lose a factor to a denormal
+constexpr float kExpScale = 2.8853900817779268f;
+__device__ __forceinline__ float exp_entry(float v) {
+  const float t = v * kExpScale;
+  return fabsf(t) <= 100.f ? __builtin_amdgcn_exp2f(t) : __builtin_nanf("");
+}
+typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float wave_sum(float v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
@@ -132,9 +140,53 @@ __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) s[r] = 0.f;
+    // With tables: tanh(P_i + Q_j) = 1 - 2 / (EP_i EQ_j + 1), summed as deg - 2 sum 1 / (EP_i EQ_j + 1). Per edge and channel
+    // ONE quarter-rate instruction (v_rcp_f32) and 1.5 packed ones (two edges per v_pk_mul / v_pk_add) where the form below
+    // spends two quarter-rate and five full-rate ones -- 22 issue cycles per edge against 52; the rows gathered are EQ_j.
+    bool exact = true;
+    if constexpr (R == 1) {
+      if (a.epq) {
+        const int hl = min(lane, H - 1);                // lanes past H redo channel H-1 (never stored)
+        const float ep = a.epq[(size_t)node * a.ldepq + hl];
+        const int eqo = H + hl;                         // row base uniform (SGPR), lane offset in a VGPR: saddr loads
+        const f2 ep2 = {ep, ep}, one2 = {1.f, 1.f};
+        f2 acc = {0.f, 0.f};
+        for (int eb = e0; eb < e1; eb += 64) {
+          const int cnt = min(64, e1 - eb);
+          const int jv = lane < cnt ? (int)a.src[eb + lane] : 0;
+          int t = 0;
+          for (; t + kEF <= cnt; t += kEF) {            // whole groups: kEF rows in flight, no masks
+            float q[kEF];
+#pragma unroll
+            for (int u = 0; u < kEF; ++u) q[u] = (a.epq + (size_t)__builtin_amdgcn_readlane(jv, t + u) * a.ldepq)[eqo];
+#pragma unroll
+            for (int u = 0; u < kEF; u += 2) {
+              const f2 d = ep2 * f2{q[u], q[u + 1]} + one2;
+              acc += f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+            }
+          }
+          for (; t < cnt; t += 4) {                     // the rest, four at a time: a missing edge is EQ = +inf, 1 / inf = 0
+            float q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const float v = (a.epq + (size_t)__builtin_amdgcn_readlane(jv, min(t + u, cnt - 1)) * a.ldepq)[eqo];
+              q[u] = t + u < cnt ? v : __builtin_inff();
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u += 2) {
+              const f2 d = ep2 * f2{q[u], q[u + 1]} + one2;
+              acc += f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+            }
+          }
+        }
+        s[0] = (float)deg - 2.0f * (acc.x + acc.y);
+        exact = __ballot(s[0] != s[0]) != 0;            // a marked table entry (or inf * 0) somewhere in this node's edges
+        if (exact) s[0] = 0.f;
+      }
+    }
     // edges in chunks of 64: one coalesced index load, then wave-uniform j's, kEF neighbour rows in flight
     // (the loop is a chain of L2 round trips at 2 waves/SIMD: depth is what hides them)
-    for (int eb = e0; eb < e1; eb += 64) {
+    for (int eb = e0; exact && eb < e1; eb += 64) {
       const int cnt = min(64, e1 - eb);
       const int jv = lane < cnt ? (int)a.src[eb + lane] : 0;
       for (int t = 0; a.pq && t < cnt; t += kEF) {
@@ -196,7 +248,13 @@ __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer
       for (int r = 0; r < 2 * R; ++r) { const int c = r * 64 + lane; o[r] = c < n_ep ? __builtin_fmaf(beta, a.b2[c], a.b_ep[c]) : 0.f; }
       matvec<R, 2 * R>(s, ept, n_ep, lane, o);
 #pragma unroll
-      for (int r = 0; r < 2 * R; ++r) { const int c = r * 64 + lane; if (c < n_ep) a.out[(size_t)node * a.ldout + c] = o[r]; }
+      for (int r = 0; r < 2 * R; ++r) {
+        const int c = r * 64 + lane;
+        if (c < n_ep) {
+          a.out[(size_t)node * a.ldout + c] = o[r];
+          if (a.out_epq) a.out_epq[(size_t)node * a.ldout_epq + c] = exp_entry(o[r]);
+        }
+      }
       GT(3)
       continue;
     }
@@ -215,7 +273,13 @@ __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer
       for (int r = 0; r < 2 * R; ++r) { const int c = r * 64 + lane; o[r] = c < n_ep ? a.b_ep[c] : 0.f; }
       matvec<R, 2 * R>(y, ept, n_ep, lane, o);
 #pragma unroll
-      for (int r = 0; r < 2 * R; ++r) { const int c = r * 64 + lane; if (c < n_ep) a.out[(size_t)node * a.ldout + c] = o[r]; }
+      for (int r = 0; r < 2 * R; ++r) {
+        const int c = r * 64 + lane;
+        if (c < n_ep) {
+          a.out[(size_t)node * a.ldout + c] = o[r];
+          if (a.out_epq) a.out_epq[(size_t)node * a.ldout_epq + c] = exp_entry(o[r]);
+        }
+      }
     } else {
       // LayerNorm over [enc (E) || y (H)] without materialising the concatenation
       const int E = a.e, C = E + H;
@@ -312,6 +376,8 @@ int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
   if (a.pq) { if (a.ldpq < 2 * a.h) return NBD_E_BADARG; }
   else { if (!a.x || !a.wpq || !a.bpq || a.f <= 0 || a.ldx < a.f) return NBD_E_BADARG; if (a.f > kFMax) return NBD_E_UNSUPPORTED; }
   if (a.kick_vel && a.epilogue != NBD_GNN_FINAL_HEAD) return NBD_E_BADARG;
+  if (a.epq && (a.h > 64 || a.ldepq < 2 * a.h)) return NBD_E_BADARG;
+  if (a.out_epq && ((a.epilogue != NBD_GNN_NEXT_PQ && a.epilogue != NBD_GNN_NEXT_PQ_FOLDED) || a.ldout_epq < a.ep_out)) return NBD_E_BADARG;
   int n_ep = 0;
   switch (a.epilogue) {
     case NBD_GNN_WRITE_X: if (a.ldout < a.h) return NBD_E_BADARG; break;
@@ -357,6 +423,24 @@ int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
 // kNN search (hinted by the buffer's previous content when asked) and the fused layers on its result. The host side of
 // an eager rollout step was five ctypes calls, each marshalling a 30-field struct, around 66 us of kernels; now it fills
 // this struct once per (model, n, k) and patches a handful of pointers per call.
+// the exponential tables of a forward pass: one [n][2h] block per layer, in args->workspace
+static bool forward_uses_tables(const nbd_gnn_forward_args& a) {
+  if (a.n <= 0 || a.n > 8192 || a.k > 200 || a.n_layers < 1 || a.n_layers > NBD_GNN_MAX_LAYERS) return false;
+  const nbd_gnn_layer_args& l0 = a.layers[0];
+  if (l0.pq || !l0.x || l0.f <= 0 || l0.f > kFMax || l0.h <= 0 || l0.h > 64) return false;
+  for (int l = 0; l < a.n_layers; ++l) {
+    const nbd_gnn_layer_args& la = a.layers[l];
+    if (la.h != l0.h) return false;
+    if (l + 1 < a.n_layers && !((la.epilogue == NBD_GNN_NEXT_PQ || la.epilogue == NBD_GNN_NEXT_PQ_FOLDED) && la.ep_out == 2 * la.h &&
+                                a.layers[l + 1].pq == la.out && a.layers[l + 1].ldpq == la.ldout)) return false;
+  }
+  return true;
+}
+size_t nbd_gnn_forward_workspace_bytes(const nbd_gnn_forward_args* args) {
+  if (!args || !forward_uses_tables(*args)) return 0;
+  return (size_t)args->n_layers * args->n * 2 * args->layers[0].h * sizeof(float);
+}
+
 int nbd_gnn_forward_f32(const nbd_gnn_forward_args* args, nbd_stream_t stream) {
   if (!args) return NBD_E_BADARG;
   const nbd_gnn_forward_args& a = *args;
@@ -366,12 +450,30 @@ int nbd_gnn_forward_f32(const nbd_gnn_forward_args* args, nbd_stream_t stream) {
   const int avail = a.n - (a.loop ? 0 : 1);
   const int kk = a.k < avail ? a.k : (avail > 0 ? avail : 0);
   const int64_t e = (int64_t)a.n * kk;
-  int rc = nbd_knn_graph_hint_f32(a.pos, a.n, a.k, a.loop, nullptr, nullptr, nullptr, e, a.edge_index,
-                                  a.use_hint ? a.edge_index : nullptr, stream);
-  if (rc) return rc;
+  const size_t need = nbd_gnn_forward_workspace_bytes(args);
+  bool tables = need > 0 && a.workspace && a.workspace_bytes >= need && kk > 0;
+  float* tab = static_cast<float*>(a.workspace);
+  const int h = a.layers[0].h;
+  int rc = NBD_E_UNSUPPORTED;
+  if (tables) {
+    const nbd_gnn_layer_args& l0 = a.layers[0];
+    const nbd_knn_pq_args pq = {l0.x, l0.ldx, l0.f, h, l0.wpq, l0.bpq, tab, 2 * h};
+    rc = nbd_knn_graph_hint_pq_f32(a.pos, a.n, a.k, a.loop, e, a.edge_index, a.use_hint ? a.edge_index : nullptr, &pq, stream);
+    if (rc == NBD_E_UNSUPPORTED) tables = false;
+    else if (rc) return rc;
+  }
+  if (!tables) {
+    rc = nbd_knn_graph_hint_f32(a.pos, a.n, a.k, a.loop, nullptr, nullptr, nullptr, e, a.edge_index,
+                                a.use_hint ? a.edge_index : nullptr, stream);
+    if (rc) return rc;
+  }
   for (int l = 0; l < a.n_layers; ++l) {
     nbd_gnn_layer_args la = a.layers[l];
     la.rowptr = nullptr; la.src = a.edge_index; la.fixed_k = kk; la.n = a.n;      // edge_index[0]: the sources, kk per node
+    if (tables) {
+      la.epq = tab + (size_t)l * a.n * 2 * h; la.ldepq = 2 * h;
+      if (l + 1 < a.n_layers) { la.out_epq = tab + (size_t)(l + 1) * a.n * 2 * h; la.ldout_epq = 2 * h; }
+    }
     rc = nbd_gnn_layer_f32(&la, stream);
     if (rc) return rc;
   }

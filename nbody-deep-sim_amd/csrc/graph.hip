@@ -326,6 +326,11 @@ __device__ long long* g_knn_trace = nullptr;      // probe build (tools/build_pr
 #define KT(s)
 #endif
 constexpr int kLW = 16;              // waves (= centres) per workgroup
+// the exponential tables of nbd_gnn_layer_args.epq: 2^(c v), c = 2 log2 e; NaN beyond |c v| = 100 (csrc/gnn_fused.hip)
+__device__ __forceinline__ float exp_entry(float v) {
+  const float t = v * 2.8853900817779268f;
+  return fabsf(t) <= 100.f ? __builtin_amdgcn_exp2f(t) : __builtin_nanf("");
+}
 constexpr int kLCap = 256;           // list entries per wave; beyond: the insertion form on global memory
 constexpr int kStagedMaxN = 8192;    // 12 B * n + 12 B * kLW * kLCap <= 144 KiB of the CU's 160
 // LDS layout: per 128 bodies (two chunks c, c+1 of 64) x_c[64] x_c+1[64] y_c[64] y_c+1[64] z_c[64] z_c+1[64], 384 floats
@@ -359,7 +364,7 @@ __device__ __forceinline__ float wave_max(float x) {       // the maximum over t
 template <int R, int RI>
 __global__ __launch_bounds__(64 * kLW) void knn_select_staged_kernel(
     const float* __restrict__ pos, int n, int k, int loop, int64_t e_total, int64_t* edge_index, const int64_t* hint,
-    int np) {                                          // np: floats of the position block (384 per 128 bodies)
+    int np, const nbd_knn_pq_args pq) {                // np: floats of the position block (384 per 128 bodies)
   extern __shared__ float sm[];
   const int w = wave_id();
   const int lane = threadIdx.x & 63;
@@ -375,6 +380,32 @@ __global__ __launch_bounds__(64 * kLW) void knn_select_staged_kernel(
   for (int q = 0; q < 4; ++q) {
     const int t = 64 * q + lane;
     hj[q] = (hint && i < n && t < kk) ? (int)hint[(int64_t)i * kk + t] : -1;
+  }
+  // ... and so are the operands of the centre's row of the first EdgeConv layer's tables (nbd_knn_graph_hint_pq_f32)
+  constexpr int kPF = 8;
+  float pw[kPF], qw[kPF], px[kPF], pb = 0.f;
+#pragma unroll
+  for (int f = 0; f < kPF; ++f) pw[f] = qw[f] = px[f] = 0.f;
+  if (pq.x) {
+    const int hl = min(lane, pq.h - 1), ic = min(i, n - 1);
+    pb = pq.bpq[hl];
+    if (pq.f == 4 && (pq.ldx & 3) == 0 && ((reinterpret_cast<uintptr_t>(pq.x) | reinterpret_cast<uintptr_t>(pq.wpq)) & 15) == 0) {
+      // the published shape (velocity + mass): three 16-byte loads per lane instead of 24 scalar ones in front of the staging
+      const float4 a = reinterpret_cast<const float4*>(pq.wpq)[hl], b = reinterpret_cast<const float4*>(pq.wpq)[pq.h + hl];
+      const float4 c = *reinterpret_cast<const float4*>(pq.x + (size_t)ic * pq.ldx);
+      pw[0] = a.x; pw[1] = a.y; pw[2] = a.z; pw[3] = a.w;
+      qw[0] = b.x; qw[1] = b.y; qw[2] = b.z; qw[3] = b.w;
+      px[0] = c.x; px[1] = c.y; px[2] = c.z; px[3] = c.w;
+    } else {
+#pragma unroll
+      for (int f = 0; f < kPF; ++f) {
+        if (f < pq.f) {                                  // wave-uniform
+          pw[f] = pq.wpq[(size_t)hl * pq.f + f];
+          qw[f] = pq.wpq[(size_t)(pq.h + hl) * pq.f + f];
+          px[f] = pq.x[(size_t)ic * pq.ldx + f];
+        }
+      }
+    }
   }
   {
     const float4* p4 = reinterpret_cast<const float4*>(pos);
@@ -407,6 +438,15 @@ __global__ __launch_bounds__(64 * kLW) void knn_select_staged_kernel(
   __syncthreads();
   KT(2)
   if (i >= n) return;                                  // no barrier below
+  if (pq.x) {                                          // P_i = b + Wp x_i, Q_i = Wq x_i in the layer kernel's own fma order
+    float pv = pb, qv = 0.f;
+#pragma unroll
+    for (int f = 0; f < kPF; ++f) { pv = __builtin_fmaf(pw[f], px[f], pv); qv = __builtin_fmaf(qw[f], px[f], qv); }
+    if (lane < pq.h) {
+      pq.epq[(size_t)i * pq.ldepq + lane] = exp_entry(pv);
+      pq.epq[(size_t)i * pq.ldepq + pq.h + lane] = exp_entry(qv);
+    }
+  }
   const float xi = sm[staged_at(i)], yi = sm[staged_at(i) + kSC], zi = sm[staged_at(i) + 2 * kSC];
 
   auto phase_a = [&]() -> float {
@@ -1143,6 +1183,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void key_sort_kernel(const int
 
 }  // namespace
 
+// the staged search (knn_select_staged_kernel); NBD_E_UNSUPPORTED, nothing launched, when the system is not its kind
+static int launch_staged(const float* pos, int n, int k, int loop, int64_t num_edges, int64_t* edge_index,
+                         const int64_t* hint, const nbd_knn_pq_args* pq, hipStream_t st) {
+  static const bool staged_ok = [] { const char* e = getenv("NBD_KNN_STAGED"); return !(e && e[0] == '0'); }();
+  const int kk_all = k < n - (loop ? 0 : 1) ? k : n - (loop ? 0 : 1);
+  if (!staged_ok || n > kStagedMaxN || k > 200 || kk_all <= 0 || num_edges != (int64_t)n * kk_all ||
+      (reinterpret_cast<uintptr_t>(pos) & 15) != 0)
+    return NBD_E_UNSUPPORTED;
+  const int np = (n + 127) / 128 * 384;
+  const size_t lds = ((size_t)np + 3 * kLW * kLCap) * sizeof(float);      // positions + the waves' 64-bit keys + d2 words
+  dim3 g2(ceil_div(n, kLW)), b2(64 * kLW);
+  using Kern = void (*)(const float*, int, int, int, int64_t, int64_t*, const int64_t*, int, const nbd_knn_pq_args);
+  static const Kern kerns[4] = {knn_select_staged_kernel<1, 1>, knn_select_staged_kernel<2, 1>,
+                                knn_select_staged_kernel<2, 2>, knn_select_staged_kernel<4, 4>};
+  static bool raised[4] = {false, false, false, false};      // > 64 KiB of dynamic LDS needs the attribute, once per kernel
+  const int v = k <= 40 ? 0 : k <= 64 ? 1 : k <= 100 ? 2 : 3;
+  if (!raised[v]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return status();
+    raised[v] = true;
+  }
+  nbd_knn_pq_args none = {};
+  kerns[v]<<<g2, b2, lds, st>>>(pos, n, k, loop, num_edges, edge_index, hint, np, pq ? *pq : none);
+  return status();
+}
+
 extern "C" {
 
 #ifdef NBD_KNN_TRACE
@@ -1169,25 +1235,9 @@ int nbd_knn_graph_hint_f32(const float* pos, int n, int k, int loop, const int* 
   // NBD_KNN_INSERTION=1 forces the insertion form (cross-check / comparison).
   static const bool force_insert = [] { const char* e = getenv("NBD_KNN_INSERTION"); return e && e[0] == '1'; }();
   // one un-segmented system that fits LDS: the staged form (NBD_KNN_STAGED=0: the form that scans L2, for comparison)
-  static const bool staged_ok = [] { const char* e = getenv("NBD_KNN_STAGED"); return !(e && e[0] == '0'); }();
-  const int kk_all = k < n - (loop ? 0 : 1) ? k : n - (loop ? 0 : 1);
-  if (!force_insert && staged_ok && !seg_lo && !out_off && n <= kStagedMaxN && k <= 200 && kk_all > 0 &&
-      num_edges == (int64_t)n * kk_all && (reinterpret_cast<uintptr_t>(pos) & 15) == 0) {
-    const int np = (n + 127) / 128 * 384;
-    const size_t lds = ((size_t)np + 3 * kLW * kLCap) * sizeof(float);      // positions + the waves' 64-bit keys + d2 words
-    dim3 g2(ceil_div(n, kLW)), b2(64 * kLW);
-    using Kern = void (*)(const float*, int, int, int, int64_t, int64_t*, const int64_t*, int);
-    static const Kern kerns[4] = {knn_select_staged_kernel<1, 1>, knn_select_staged_kernel<2, 1>,
-                                  knn_select_staged_kernel<2, 2>, knn_select_staged_kernel<4, 4>};
-    static bool raised[4] = {false, false, false, false};      // > 64 KiB of dynamic LDS needs the attribute, once per kernel
-    const int v = k <= 40 ? 0 : k <= 64 ? 1 : k <= 100 ? 2 : 3;
-    if (!raised[v]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return status();
-      raised[v] = true;
-    }
-    kerns[v]<<<g2, b2, lds, st>>>(pos, n, k, loop, num_edges, edge_index, hint, np);
-    return status();
+  if (!force_insert && !seg_lo && !out_off) {
+    const int rc = launch_staged(pos, n, k, loop, num_edges, edge_index, hint, nullptr, st);
+    if (rc != NBD_E_UNSUPPORTED) return rc;
   }
   if (!force_insert && k <= 40)
     knn_select_kernel<1, 1><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index, hint);
@@ -1204,6 +1254,16 @@ int nbd_knn_graph_hint_f32(const float* pos, int n, int k, int loop, const int* 
   else
     knn_kernel<4><<<grid, block, 0, st>>>(pos, n, k, loop, seg_lo, seg_hi, out_off, num_edges, edge_index);
   return status();
+}
+
+int nbd_knn_graph_hint_pq_f32(const float* pos, int n, int k, int loop, int64_t num_edges, int64_t* edge_index,
+                              const int64_t* hint, const nbd_knn_pq_args* pq, nbd_stream_t stream) {
+  if (n < 0 || k < 0 || num_edges < 0 || !pq) return NBD_E_BADARG;
+  if (!pq->x || !pq->wpq || !pq->bpq || !pq->epq || pq->f <= 0 || pq->h <= 0 || pq->ldx < pq->f || pq->ldepq < 2 * pq->h) return NBD_E_BADARG;
+  if (pq->f > 8 || pq->h > 64) return NBD_E_UNSUPPORTED;
+  if (n == 0) return 0;
+  if (!pos || !edge_index) return NBD_E_BADARG;
+  return launch_staged(pos, n, k, loop, num_edges, edge_index, hint, pq, (hipStream_t)stream);
 }
 
 int nbd_radius_search_f32(const float* pos, int n, float radius_sq, int loop, int max_num_neighbors,

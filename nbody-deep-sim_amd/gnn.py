@@ -19,6 +19,7 @@ torch.optim optimiser steps on the `.grad` fields.
 from __future__ import annotations
 
 import ctypes
+import os
 import time
 
 import torch
@@ -157,6 +158,7 @@ class GraphModel(torch.nn.Module):
         self._brs_const = None
         self._knn_buf = None
         self._one_call = None          # cached nbd_gnn_forward_args of predict() (see _one_call_plan)
+        self.use_exp_tables = os.environ.get("NBD_GNN_EXP_TABLES", "1") != "0"   # 0: the one-call pass without tables
         self.use_one_call = True       # predict(): search + layers through ONE C-ABI call when the configuration allows
         self.to(device)
 
@@ -386,6 +388,12 @@ class GraphModel(torch.nn.Module):
         fa.n, fa.k, fa.loop, fa.n_layers = n, k, 0, n_layers
         fa.layers[n_layers - 1].ldenc = ldx
         fa.layers[n_layers - 1].ldout = head[0][0].shape[0]
+        # room for the layers' exponential tables (include/nbd.h: nbd_gnn_layer_args.epq) where the configuration has them
+        need = _lib.lib().nbd_gnn_forward_workspace_bytes(ctypes.byref(fa)) if self.use_exp_tables else 0
+        if need:
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            keep.append(ws)
+            fa.workspace, fa.workspace_bytes = ws.data_ptr(), need
         return {"fa": fa, "keep": keep, "out_dim": head[0][0].shape[0]}
 
     def _predict_one_call(self, x_in, pos, k, out=None, kick=None):

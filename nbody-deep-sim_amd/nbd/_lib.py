@@ -47,7 +47,8 @@ class GnnLayerArgs(ctypes.Structure):
                 ("h", c_int), ("aggr", c_int), ("w2t", c_void_p), ("b2", c_void_p),
                 ("epilogue", c_int), ("w_ep", c_void_p), ("b_ep", c_void_p), ("ep_out", c_int),
                 ("enc", c_void_p), ("ldenc", c_int), ("e", c_int), ("ln_g", c_void_p), ("ln_b", c_void_p),
-                ("ln_eps", c_float), ("out", c_void_p), ("ldout", c_int), ("kick_vel", c_void_p), ("kick_c", c_float)]
+                ("ln_eps", c_float), ("out", c_void_p), ("ldout", c_int), ("kick_vel", c_void_p), ("kick_c", c_float),
+                ("epq", c_void_p), ("ldepq", c_int), ("out_epq", c_void_p), ("ldout_epq", c_int)]
 
 
 GNN_MAX_LAYERS = 8
@@ -56,7 +57,14 @@ GNN_MAX_LAYERS = 8
 class GnnForwardArgs(ctypes.Structure):
     """Mirror of `nbd_gnn_forward_args` (include/nbd.h), field for field."""
     _fields_ = [("pos", c_void_p), ("n", c_int), ("k", c_int), ("loop", c_int), ("use_hint", c_int),
-                ("edge_index", c_void_p), ("n_layers", c_int), ("layers", GnnLayerArgs * GNN_MAX_LAYERS)]
+                ("edge_index", c_void_p), ("n_layers", c_int), ("layers", GnnLayerArgs * GNN_MAX_LAYERS),
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
+class KnnPqArgs(ctypes.Structure):
+    """Mirror of `nbd_knn_pq_args` (include/nbd.h), field for field."""
+    _fields_ = [("x", c_void_p), ("ldx", c_int), ("f", c_int), ("h", c_int), ("wpq", c_void_p), ("bpq", c_void_p),
+                ("epq", c_void_p), ("ldepq", c_int)]
 
 
 TRAIN_MAX_MLP = 8
@@ -237,6 +245,9 @@ SIGNATURES = {
     "nbd_gnn_train_forward_f32": (c_int, [POINTER(GnnTrainArgs), c_void_p]),
     "nbd_gnn_train_backward_f32": (c_int, [POINTER(GnnTrainArgs), c_void_p, c_int, POINTER(GnnTrainGrads), c_void_p]),
     "nbd_gnn_layer_f32": (c_int, [POINTER(GnnLayerArgs), c_void_p]),
+    "nbd_gnn_forward_workspace_bytes": (c_size_t, [POINTER(GnnForwardArgs)]),
+    "nbd_knn_graph_hint_pq_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, POINTER(KnnPqArgs),
+                                          c_void_p]),
     # --- backward kernels (csrc/train.hip) and the transposed adjacency they gather over
     "nbd_csr_by_key_i64": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),

@@ -399,28 +399,59 @@ def test_contconv_extreme_aggregations_match_oracle(agg, D, I, O, gpu_device):
 
 def test_gnn_predict_through_one_cabi_call_equals_the_per_kernel_path(gpu_device):
     """predict() enqueues the kNN search and the fused layers through nbd_gnn_forward_f32 (one ctypes call) from its
-    second call on: same graph, same kernels, same bits as the per-kernel calls, over a drifting sequence."""
+    second call on: same graph, and -- without the exponential tables -- same kernels, same bits as the per-kernel
+    calls, over a drifting sequence. With the tables (the default: tanh(P + Q) as 1 - 2 / (2^(cP) 2^(cQ) + 1), the
+    first layer's rows written by the search kernel) the graph is still identical and the output within the 1e-5 bar."""
     import gnn
     torch.manual_seed(4)
     pos, vel, m = _plummer_pos(700, 12)
     pos, vel, m1 = pos.cuda(), vel.cuda(), (m * 700)[:, None].cuda()
     a = gnn.GraphModel(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", device="cuda")
     b = gnn.GraphModel(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", device="cuda")
+    t = gnn.GraphModel(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", device="cuda")
     b.load_state_dict(a.state_dict())
+    t.load_state_dict(a.state_dict())
+    a.use_exp_tables = False
     b.use_one_call = False
     for step in range(5):
         feat = torch.cat([vel, m1], 1)
-        ya, yb = a.predict(pos, feat), b.predict(pos, feat)
+        ya, yb, yt = a.predict(pos, feat), b.predict(pos, feat), t.predict(pos, feat)
         assert torch.equal(ya, yb), step
-        assert torch.equal(a._knn_buf, b._knn_buf)
+        assert torch.equal(a._knn_buf, b._knn_buf) and torch.equal(t._knn_buf, b._knn_buf)
+        assert (yt - yb).abs().max() <= TOL * max(1.0, float(yb.abs().max())), step
         if step:
             assert a._one_call is not None and b._one_call is None
+            assert t._one_call["fa"].workspace_bytes > 0 and a._one_call["fa"].workspace_bytes == 0
         pos = pos + 0.01 * vel
     # k override and a changed n re-plan instead of reusing stale pointers
-    assert torch.equal(a.predict(pos[:300].contiguous(), feat[:300].contiguous(), neighbors=7),
-                       b.predict(pos[:300].contiguous(), feat[:300].contiguous(), neighbors=7))
-    assert torch.equal(a.predict(pos[:300].contiguous(), feat[:300].contiguous(), neighbors=7),
-                       b.predict(pos[:300].contiguous(), feat[:300].contiguous(), neighbors=7))
+    for mdl in (a, t):
+        for _ in range(2):
+            got = mdl.predict(pos[:300].contiguous(), feat[:300].contiguous(), neighbors=7)
+            ref = b.predict(pos[:300].contiguous(), feat[:300].contiguous(), neighbors=7)
+            assert torch.equal(got, ref) if mdl is a else (got - ref).abs().max() <= TOL * max(1.0, float(ref.abs().max()))
+
+
+def test_gnn_exponential_tables_survive_preactivations_out_of_their_range(gpu_device):
+    """An entry of the tables whose |2 log2(e) v| exceeds 100 holds NaN, and a node that meets one is recomputed from
+    P / Q exactly as without tables: scaled-up first-layer weights (pre-activations in the hundreds, opposite signs
+    cancelling inside tanh) must give the per-kernel path's result."""
+    import gnn
+    torch.manual_seed(9)
+    pos, vel, m = _plummer_pos(600, 5)
+    pos, vel, m1 = pos.cuda(), vel.cuda(), (m * 600)[:, None].cuda()
+    t = gnn.GraphModel(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", device="cuda")
+    with torch.no_grad():
+        for p in t.gnns[0].parameters():            # first EdgeConv: both Linears of its message MLP
+            p.mul_(60.0)
+    b = gnn.GraphModel(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", device="cuda")
+    b.load_state_dict(t.state_dict())
+    b.use_one_call = False
+    feat = torch.cat([vel * 30.0, m1], 1)
+    for step in range(3):
+        yt, yb = t.predict(pos, feat), b.predict(pos, feat)
+        assert torch.isfinite(yt).all()
+        assert (yt - yb).abs().max() <= TOL * max(1.0, float(yb.abs().max())), step
+    assert t._one_call is not None and t._one_call["fa"].workspace_bytes > 0
 
 
 def test_contconv_fused_refuses_a_row_beyond_its_16_bit_counters_loudly(gpu_device):
@@ -860,8 +891,14 @@ def test_gnn_full_size_config_matches_oracle(gpu_device):
     ref = ora.predict(pos, feat, k=32)
     got = model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu()
     assert global_rel(got, ref) < TOL and row_rel(got, ref) < 10 * TOL
-    again = model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu()            # second call: hinted kNN, in place
-    assert torch.equal(again, got)
+    # second call on: hinted search in place, one C-ABI call, tanh through the exponential tables -- the same bar against
+    # the oracle, and bit-identical from call to call
+    again = model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu()
+    assert model._one_call is not None and model._one_call["fa"].workspace_bytes > 0
+    assert global_rel(again, ref) < TOL and row_rel(again, ref) < 10 * TOL
+    assert torch.equal(model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu(), again)
+    model.use_exp_tables, model._one_call = False, None                           # without the tables: the first call's bits
+    assert torch.equal(model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu(), got)
 
 
 def test_contconv_full_size_config_rows_match_oracle_and_layer_is_linear(gpu_device):
