@@ -19,6 +19,7 @@
 // conflict-free; the per-node mat-vecs broadcast the k-th input with v_readlane (no LDS, no shuffles).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/nbd.h"
 
@@ -79,9 +80,130 @@ __device__ __forceinline__ void matvec(const float (&in)[RIN], const float* __re
 
 namespace {
 
+// S_i = sum_j tanh(P_i + Q_j) over the edges [e0, e1) of `node`, lane = channel (R channels per lane): the edge loop of
+// both layer kernels below.
+template <int R, int FM>
+__device__ __forceinline__ void edge_aggregate(const nbd_gnn_layer_args& a, int node, int lane, int H, int e0, int e1,
+                                               const float (&wp)[R][FM], const float (&wq)[R][FM], const float (&bp)[R],
+                                               float (&s)[R]) {
+  const int deg = e1 - e0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) s[r] = 0.f;
+  // With tables: tanh(P_i + Q_j) = 1 - 2 / (EP_i EQ_j + 1), summed as deg - 2 sum 1 / (EP_i EQ_j + 1). Per edge and channel
+  // ONE quarter-rate instruction (v_rcp_f32) and 1.5 packed ones (two edges per v_pk_mul / v_pk_add) where the form below
+  // spends two quarter-rate and five full-rate ones -- 22 issue cycles per edge against 52; the rows gathered are EQ_j.
+  bool exact = true;
+  if constexpr (R == 1) {
+    if (a.epq) {
+      const int hl = min(lane, H - 1);                // lanes past H redo channel H-1 (never stored)
+      const float ep = a.epq[(size_t)node * a.ldepq + hl];
+      const int eqo = H + hl;                         // row base uniform (SGPR), lane offset in a VGPR: saddr loads
+      const f2 ep2 = {ep, ep}, one2 = {1.f, 1.f};
+      f2 acc = {0.f, 0.f};
+      for (int eb = e0; eb < e1; eb += 64) {
+        const int cnt = min(64, e1 - eb);
+        const int jv = lane < cnt ? (int)a.src[eb + lane] : 0;
+        int t = 0;
+        for (; t + kEF <= cnt; t += kEF) {            // whole groups: kEF rows in flight, no masks
+          float q[kEF];
+#pragma unroll
+          for (int u = 0; u < kEF; ++u) q[u] = (a.epq + (size_t)__builtin_amdgcn_readlane(jv, t + u) * a.ldepq)[eqo];
+#pragma unroll
+          for (int u = 0; u < kEF; u += 2) {
+            const f2 d = ep2 * f2{q[u], q[u + 1]} + one2;
+            acc += f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+          }
+        }
+        for (; t < cnt; t += 4) {                     // the rest, four at a time: a missing edge is EQ = +inf, 1 / inf = 0
+          float q[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float v = (a.epq + (size_t)__builtin_amdgcn_readlane(jv, min(t + u, cnt - 1)) * a.ldepq)[eqo];
+            q[u] = t + u < cnt ? v : __builtin_inff();
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u += 2) {
+            const f2 d = ep2 * f2{q[u], q[u + 1]} + one2;
+            acc += f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+          }
+        }
+      }
+      s[0] = (float)deg - 2.0f * (acc.x + acc.y);
+      exact = __ballot(s[0] != s[0]) != 0;            // a marked table entry (or inf * 0) somewhere in this node's edges
+      if (exact) s[0] = 0.f;
+    }
+  }
+  if (!exact) return;
+  float p[R];
+  if (a.pq) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; p[r] = h < H ? a.pq[(size_t)node * a.ldpq + h] : 0.f; }
+  } else {
+    float xi[FM];
+#pragma unroll
+    for (int f = 0; f < FM; ++f) xi[f] = f < a.f ? a.x[(size_t)node * a.ldx + f] : 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float acc = bp[r];
+#pragma unroll
+      for (int f = 0; f < FM; ++f) acc = __builtin_fmaf(wp[r][f], xi[f], acc);
+      p[r] = acc;
+    }
+  }
+  // edges in chunks of 64: one coalesced index load, then wave-uniform j's, kEF neighbour rows in flight
+  // (the loop is a chain of L2 round trips at 2 waves/SIMD: depth is what hides them)
+  for (int eb = e0; eb < e1; eb += 64) {
+    const int cnt = min(64, e1 - eb);
+    const int jv = lane < cnt ? (int)a.src[eb + lane] : 0;
+    for (int t = 0; a.pq && t < cnt; t += kEF) {
+      int j[kEF];
+#pragma unroll
+      for (int u = 0; u < kEF; ++u) j[u] = __builtin_amdgcn_readlane(jv, min(t + u, cnt - 1));
+      {
+        float q[kEF][R];
+#pragma unroll
+        for (int u = 0; u < kEF; ++u)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int h = r * 64 + lane;
+            q[u][r] = h < H ? a.pq[(size_t)j[u] * a.ldpq + H + h] : 0.f;
+          }
+#pragma unroll
+        for (int u = 0; u < kEF; ++u)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float v = fast_tanh(__fadd_rn(p[r], q[u][r]));
+            s[r] += (t + u < cnt) ? v : 0.f;
+          }
+      }
+    }
+    if (!a.pq) {
+      // first layer: every lane fetches ONE neighbour's features (a single gather latency for the whole
+      // chunk), then neighbour t's row is broadcast out of lane t; Q is formed on the fly
+      float xv[FM];
+#pragma unroll
+      for (int f = 0; f < FM; ++f) xv[f] = (lane < cnt && f < a.f) ? a.x[(size_t)jv * a.ldx + f] : 0.f;
+      for (int t = 0; t < cnt; ++t) {
+        float xj[FM];
+#pragma unroll
+        for (int f = 0; f < FM; ++f)
+          xj[f] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv[f]), t));
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float q = 0.f;
+#pragma unroll
+          for (int f = 0; f < FM; ++f) q = __builtin_fmaf(wq[r][f], xj[f], q);
+          s[r] += fast_tanh(__fadd_rn(p[r], q));
+        }
+      }
+    }
+  }
+}
+
 #ifdef NBD_GNN_TRACE
 __device__ long long* g_gnn_trace = nullptr;
-#define GT(i) if (lane == 0 && g_gnn_trace) g_gnn_trace[((size_t)blockIdx.x * WPB + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();
+__device__ int g_gnn_trace_epi = -1;        // trace only launches with this epilogue (-1: all; the last writer wins)
+#define GT(i) if (lane == 0 && g_gnn_trace && (g_gnn_trace_epi < 0 || g_gnn_trace_epi == a.epilogue)) g_gnn_trace[((size_t)blockIdx.x * WPB + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();
 #else
 #define GT(i)
 #endif
@@ -122,116 +244,8 @@ __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer
     const int e0 = a.rowptr ? a.rowptr[node] : node * a.fixed_k;
     const int e1 = a.rowptr ? a.rowptr[node + 1] : (node + 1) * a.fixed_k;
     const int deg = e1 - e0;
-    float p[R], s[R];
-    if (a.pq) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) { const int h = r * 64 + lane; p[r] = h < H ? a.pq[(size_t)node * a.ldpq + h] : 0.f; }
-    } else {
-      float xi[FM];
-#pragma unroll
-      for (int f = 0; f < FM; ++f) xi[f] = f < a.f ? a.x[(size_t)node * a.ldx + f] : 0.f;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        float acc = bp[r];
-#pragma unroll
-        for (int f = 0; f < FM; ++f) acc = __builtin_fmaf(wp[r][f], xi[f], acc);
-        p[r] = acc;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) s[r] = 0.f;
-    // With tables: tanh(P_i + Q_j) = 1 - 2 / (EP_i EQ_j + 1), summed as deg - 2 sum 1 / (EP_i EQ_j + 1). Per edge and channel
-    // ONE quarter-rate instruction (v_rcp_f32) and 1.5 packed ones (two edges per v_pk_mul / v_pk_add) where the form below
-    // spends two quarter-rate and five full-rate ones -- 22 issue cycles per edge against 52; the rows gathered are EQ_j.
-    bool exact = true;
-    if constexpr (R == 1) {
-      if (a.epq) {
-        const int hl = min(lane, H - 1);                // lanes past H redo channel H-1 (never stored)
-        const float ep = a.epq[(size_t)node * a.ldepq + hl];
-        const int eqo = H + hl;                         // row base uniform (SGPR), lane offset in a VGPR: saddr loads
-        const f2 ep2 = {ep, ep}, one2 = {1.f, 1.f};
-        f2 acc = {0.f, 0.f};
-        for (int eb = e0; eb < e1; eb += 64) {
-          const int cnt = min(64, e1 - eb);
-          const int jv = lane < cnt ? (int)a.src[eb + lane] : 0;
-          int t = 0;
-          for (; t + kEF <= cnt; t += kEF) {            // whole groups: kEF rows in flight, no masks
-            float q[kEF];
-#pragma unroll
-            for (int u = 0; u < kEF; ++u) q[u] = (a.epq + (size_t)__builtin_amdgcn_readlane(jv, t + u) * a.ldepq)[eqo];
-#pragma unroll
-            for (int u = 0; u < kEF; u += 2) {
-              const f2 d = ep2 * f2{q[u], q[u + 1]} + one2;
-              acc += f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-            }
-          }
-          for (; t < cnt; t += 4) {                     // the rest, four at a time: a missing edge is EQ = +inf, 1 / inf = 0
-            float q[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const float v = (a.epq + (size_t)__builtin_amdgcn_readlane(jv, min(t + u, cnt - 1)) * a.ldepq)[eqo];
-              q[u] = t + u < cnt ? v : __builtin_inff();
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u += 2) {
-              const f2 d = ep2 * f2{q[u], q[u + 1]} + one2;
-              acc += f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-            }
-          }
-        }
-        s[0] = (float)deg - 2.0f * (acc.x + acc.y);
-        exact = __ballot(s[0] != s[0]) != 0;            // a marked table entry (or inf * 0) somewhere in this node's edges
-        if (exact) s[0] = 0.f;
-      }
-    }
-    // edges in chunks of 64: one coalesced index load, then wave-uniform j's, kEF neighbour rows in flight
-    // (the loop is a chain of L2 round trips at 2 waves/SIMD: depth is what hides them)
-    for (int eb = e0; exact && eb < e1; eb += 64) {
-      const int cnt = min(64, e1 - eb);
-      const int jv = lane < cnt ? (int)a.src[eb + lane] : 0;
-      for (int t = 0; a.pq && t < cnt; t += kEF) {
-        int j[kEF];
-#pragma unroll
-        for (int u = 0; u < kEF; ++u) j[u] = __builtin_amdgcn_readlane(jv, min(t + u, cnt - 1));
-        {
-          float q[kEF][R];
-#pragma unroll
-          for (int u = 0; u < kEF; ++u)
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-              const int h = r * 64 + lane;
-              q[u][r] = h < H ? a.pq[(size_t)j[u] * a.ldpq + H + h] : 0.f;
-            }
-#pragma unroll
-          for (int u = 0; u < kEF; ++u)
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-              const float v = fast_tanh(__fadd_rn(p[r], q[u][r]));
-              s[r] += (t + u < cnt) ? v : 0.f;
-            }
-        }
-      }
-      if (!a.pq) {
-        // first layer: every lane fetches ONE neighbour's features (a single gather latency for the whole
-        // chunk), then neighbour t's row is broadcast out of lane t; Q is formed on the fly
-        float xv[FM];
-#pragma unroll
-        for (int f = 0; f < FM; ++f) xv[f] = (lane < cnt && f < a.f) ? a.x[(size_t)jv * a.ldx + f] : 0.f;
-        for (int t = 0; t < cnt; ++t) {
-          float xj[FM];
-#pragma unroll
-          for (int f = 0; f < FM; ++f)
-            xj[f] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv[f]), t));
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            float q = 0.f;
-#pragma unroll
-            for (int f = 0; f < FM; ++f) q = __builtin_fmaf(wq[r][f], xj[f], q);
-            s[r] += fast_tanh(__fadd_rn(p[r], q));
-          }
-        }
-      }
-    }
+    float s[R];
+    edge_aggregate<R, FM>(a, node, lane, H, e0, e1, wp, wq, bp, s);
     GT(2)
     if (a.aggr == 1) {
       const float inv = 1.0f / (float)max(deg, 1);
@@ -355,6 +369,157 @@ __global__ __launch_bounds__(64 * WPB) void gnn_layer_kernel(const nbd_gnn_layer
   }
 }
 
+// ---- H = 64: the layer with its dense tail on the matrix pipe.
+// In-kernel stamps of the kernel above at N = 4096, k = 50 (tools/gnn_layer_trace.py): of 13.9 us, 1.3-1.9 go to staging
+// W^T into LDS in front of the first edge, 2.5-3.4 to the mat-vec (LDS-bandwidth bound: each of a workgroup's 16 waves
+// reads the whole 16-32 KB matrix for ITS node), 4.3 to LayerNorm + head on the last layer (cold global loads of their
+// constants and of the velocity, LDS-routed wave reductions). Here the 16 nodes of a workgroup are ONE 16-row operand:
+//   - nothing is staged: every wave asks for its registers' worth of what the tail needs -- its 16 x 64 x 16 block's B
+//     fragments (v_mfma_f32_16x16x4_f32: lane (k = l >> 4, n = l & 15)), biases, LayerNorm / head rows, its velocity --
+//     together with its first edge indices, so one cold round trip covers them all;
+//   - the edge loop (edge_aggregate) leaves S_i in lane = channel; the 16 rows meet in LDS, waves 0 .. n_ep/16 - 1
+//     multiply (16 MFMAs each, fp32 in, fp32 accumulate) and hand the 16 x n_ep result back through LDS;
+//   - wave = node again: bias, stores (+ the next layer's exponential table), or LayerNorm + head with DPP reductions.
+typedef float f4m __attribute__((ext_vector_type(4)));
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_add(float x) {      // x + (x moved by one DPP step; lanes the move does not reach add 0)
+  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROWS, 0xf, false));
+}
+// the sum over the wave, in every lane: row_shr 1/2/4/8 inside the rows of 16, row_bcast 15 and 31 across them, all VALU
+// (__shfl_xor is a ds_bpermute -- an LDS round trip -- per step)
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+  x = dpp_add<0x111, 0xf>(x); x = dpp_add<0x112, 0xf>(x); x = dpp_add<0x114, 0xf>(x); x = dpp_add<0x118, 0xf>(x);
+  x = dpp_add<0x142, 0xa>(x); x = dpp_add<0x143, 0xc>(x);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
+constexpr int kT = 16;               // nodes (= waves) per workgroup = rows of the MFMA operand
+constexpr int kSS = 66;              // row stride of S in LDS: A-fragment reads (m, 4 ks + q) fall on banks 2 m + q
+constexpr int kOS = 132;             // row stride of the product
+
+template <int FM>
+__global__ __launch_bounds__(64 * kT) void gnn_layer64_kernel(const nbd_gnn_layer_args a) {
+  __shared__ float S[kT * kSS];
+  __shared__ float O[kT * kOS];
+  constexpr int H = 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  [[maybe_unused]] constexpr int WPB = kT;
+  GT(0)
+  const bool folded = a.epilogue == NBD_GNN_NEXT_PQ_FOLDED;
+  const int n_out = folded ? a.ep_out : H;              // columns of the product: 128 or 64
+  const int node = blockIdx.x * kT + wave;
+  const bool live = node < a.n;
+  const int nc = live ? node : a.n - 1;                 // waves past the end shadow the last node (they only keep the barriers)
+  const int e0 = a.rowptr ? a.rowptr[nc] : nc * a.fixed_k;
+  const int e1 = a.rowptr ? a.rowptr[nc + 1] : (nc + 1) * a.fixed_k;
+  const int deg = e1 - e0;
+
+  // ---- requests for everything the tail needs
+  float bfrag[16];
+  const float* wmat = folded ? a.w_ep : a.w2t;          // [64][n_out], k-major
+  const bool mult = wave * 16 < n_out;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) bfrag[ks] = mult ? wmat[(size_t)(4 * ks + (lane >> 4)) * n_out + 16 * wave + (lane & 15)] : 0.f;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;          // folded: b2', b_ep of columns lane and 64 + lane; head: b2
+  float lg_e = 0.f, lb_e = 0.f, lg_y = 0.f, lb_y = 0.f, encv = 0.f, velv = 0.f, bh = 0.f;
+  float wh_e[kMaxOut], wh_y[kMaxOut];
+  const int E = a.e;
+  if (folded) {
+    c0 = a.b2[lane]; c1 = a.b_ep[lane];
+    if (64 + lane < n_out) { c2 = a.b2[64 + lane]; c3 = a.b_ep[64 + lane]; }
+  } else {
+    c0 = a.b2[lane];
+    lg_y = a.ln_g[E + lane]; lb_y = a.ln_b[E + lane];
+    if (lane < E) { lg_e = a.ln_g[lane]; lb_e = a.ln_b[lane]; encv = a.enc[(size_t)nc * a.ldenc + lane]; }
+#pragma unroll
+    for (int d = 0; d < kMaxOut; ++d) {
+      wh_e[d] = 0.f; wh_y[d] = 0.f;
+      if (d < a.ep_out) {                               // wave-uniform
+        wh_y[d] = a.w_ep[(size_t)d * (E + H) + E + lane];
+        if (lane < E) wh_e[d] = a.w_ep[(size_t)d * (E + H) + lane];
+      }
+    }
+    if (lane < a.ep_out) { bh = a.b_ep[lane]; if (a.kick_vel) velv = a.kick_vel[(size_t)nc * a.ep_out + lane]; }
+  }
+  float wp[1][FM], wq[1][FM], bp[1];
+  if (a.pq == nullptr) {
+    bp[0] = a.bpq[lane];
+#pragma unroll
+    for (int f = 0; f < FM; ++f) {
+      const bool ok = f < a.f;
+      wp[0][f] = ok ? a.wpq[(size_t)lane * a.f + f] : 0.f;
+      wq[0][f] = ok ? a.wpq[(size_t)(H + lane) * a.f + f] : 0.f;
+    }
+  }
+  GT(1)
+
+  // ---- edges
+  float s[1];
+  edge_aggregate<1, FM>(a, nc, lane, H, e0, e1, wp, wq, bp, s);
+  GT(2)
+  if (a.aggr == 1) s[0] *= 1.0f / (float)max(deg, 1);
+  const float beta = a.aggr == 1 ? (deg > 0 ? 1.f : 0.f) : (float)deg;
+
+  // ---- the 16 rows times W^T
+  S[wave * kSS + lane] = s[0];
+  __syncthreads();
+  if (mult) {
+    f4m acc = {0.f, 0.f, 0.f, 0.f};
+    const float* arow = S + (lane & 15) * kSS + (lane >> 4);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * ks], bfrag[ks], acc, 0, 0, 0);
+    float* ocol = O + (4 * (lane >> 4)) * kOS + 16 * wave + (lane & 15);     // D: rows 4 (l >> 4) + v, column l & 15
+#pragma unroll
+    for (int v = 0; v < 4; ++v) ocol[v * kOS] = acc[v];
+  }
+  __syncthreads();
+  GT(4)
+  if (!live) return;
+
+  if (folded) {
+    // next [P|Q] = (Wpq W2) S + beta (Wpq b2) + bpq
+    const float o0 = O[wave * kOS + lane] + __builtin_fmaf(beta, c0, c1);
+    a.out[(size_t)node * a.ldout + lane] = o0;
+    if (a.out_epq) a.out_epq[(size_t)node * a.ldout_epq + lane] = exp_entry(o0);
+    if (64 + lane < n_out) {
+      const float o1 = O[wave * kOS + 64 + lane] + __builtin_fmaf(beta, c2, c3);
+      a.out[(size_t)node * a.ldout + 64 + lane] = o1;
+      if (a.out_epq) a.out_epq[(size_t)node * a.ldout_epq + 64 + lane] = exp_entry(o1);
+    }
+    GT(3)
+    return;
+  }
+  // y = W2 S + beta b2, then LayerNorm over [enc (E <= 64) || y (64)] and the head
+  const float y = O[wave * kOS + lane] + beta * c0;
+  const float C = (float)(E + H);
+  const float mean = wave_sum_dpp(y + (lane < E ? encv : 0.f)) / C;
+  const float dy = y - mean, de = lane < E ? encv - mean : 0.f;
+  const float rstd = 1.0f / sqrtf(wave_sum_dpp(dy * dy + de * de) / C + a.ln_eps);
+  const float zy = dy * rstd * lg_y + lb_y;
+  const float ze = lane < E ? de * rstd * lg_e + lb_e : 0.f;
+  GT(5)
+  if (a.epilogue == NBD_GNN_FINAL_LN) {
+    if (lane < E) a.out[(size_t)node * a.ldout + lane] = ze;
+    a.out[(size_t)node * a.ldout + E + lane] = zy;
+    return;
+  }
+  float mine = 0.f;                                      // lane d keeps output d
+#pragma unroll
+  for (int d = 0; d < kMaxOut; ++d) {
+    if (d < a.ep_out) {
+      const float t = wave_sum_dpp(__builtin_fmaf(zy, wh_y[d], ze * wh_e[d]));
+      mine = lane == d ? t : mine;
+    }
+  }
+  if (lane < a.ep_out) {
+    const float o_d = mine + bh;
+    a.out[(size_t)node * a.ldout + lane] = o_d;
+    if (a.kick_vel) a.kick_vel[(size_t)node * a.ep_out + lane] = __fadd_rn(velv, __fmul_rn(a.kick_c, o_d));
+  }
+  GT(6)
+}
+
 inline int status() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : (int)e; }
 
 }  // namespace
@@ -363,6 +528,7 @@ extern "C" {
 
 #ifdef NBD_GNN_TRACE
 int nbd_debug_gnn_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gnn_trace), &buf, sizeof(buf)); }
+int nbd_debug_gnn_trace_epilogue(int epi) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gnn_trace_epi), &epi, sizeof(epi)); }
 #endif
 
 int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
@@ -406,6 +572,17 @@ int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
   // 76.1 / 72.7 / 71.5 us (round 1's shape: 4 waves, 512 workgroups looping over two nodes each).
   hipStream_t st = (hipStream_t)stream;
   const bool f4 = a.pq != nullptr || a.f <= 4;
+  // H = 64 with a 64 x 128 folded next-[P|Q] or a LayerNorm (+ head) over at most 64 encoder columns: the MFMA-tail kernel
+  // (NBD_GNN_MFMA_TAIL=0: the kernel below, for comparison)
+  static const bool mfma_tail = [] { const char* e = getenv("NBD_GNN_MFMA_TAIL"); return !(e && e[0] == '0'); }();
+  if (mfma_tail && a.h == 64 &&
+      ((a.epilogue == NBD_GNN_NEXT_PQ_FOLDED && a.ep_out % 16 == 0 && a.ep_out <= 128) ||
+       ((a.epilogue == NBD_GNN_FINAL_HEAD || a.epilogue == NBD_GNN_FINAL_LN) && a.e <= 64))) {
+    const int blocks64 = (a.n + kT - 1) / kT;
+    if (f4) gnn_layer64_kernel<4><<<blocks64, 64 * kT, 0, st>>>(a);
+    else gnn_layer64_kernel<kFMax><<<blocks64, 64 * kT, 0, st>>>(a);
+    return status();
+  }
   constexpr int W = 16;
   int blocks = (a.n + W - 1) / W;
   if (blocks > 512) blocks = 512;                        // two resident workgroups per CU at most (LDS, 32 waves); more nodes loop

@@ -20,19 +20,24 @@ m1 = torch.tensor(m * n, dtype=torch.float32, device="cuda")[:, None]
 feat = torch.cat([vel, m1], 1)
 for _ in range(3): model.predict(pos, feat)
 L = _lib.lib(); L.nbd_debug_gnn_trace.argtypes = [ctypes.c_void_p]; L.nbd_debug_gnn_trace.restype = ctypes.c_int
-tr = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
-assert L.nbd_debug_gnn_trace(tr.data_ptr()) == 0
-model.predict(pos, feat); torch.cuda.synchronize()        # both layers write; the last writer (layer 2) wins
-assert L.nbd_debug_gnn_trace(None) == 0
-t = tr.view(-1, 8).cpu().numpy(); t = t[t[:, 0] != 0]
-t0 = t[:, 0].min()
-out = {"waves": int(len(t)), "start_us_p50_max": [float(np.percentile((t[:,0]-t0)/100,50)), float(((t[:,0]-t0)/100).max())],
-       "staging_us_mean": float(((t[:,1]-t[:,0])/100).mean()), "edges_us_mean": float(((t[:,2]-t[:,1])/100).mean()),
-       "edges_done_at_us_p50_max": [float(np.percentile((t[:,2]-t0)/100,50)), float(((t[:,2]-t0)/100).max())]}
-if (t[:, 6] != 0).any():
-    out["matvec_us_mean"] = float(((t[:,4]-t[:,2])/100).mean()); out["layernorm_us_mean"] = float(((t[:,5]-t[:,4])/100).mean())
-    out["head_us_mean"] = float(((t[:,6]-t[:,5])/100).mean()); out["end_at_us_p50_max"] = [float(np.percentile((t[:,6]-t0)/100,50)), float(((t[:,6]-t0)/100).max())]
-fin = np.zeros(len(t), dtype=bool)
-if fin.any():
-    out["matvec_us_mean_folded_layers"] = float(((t[fin,3]-t[fin,2])/100).mean())
-print(json.dumps(out))
+res = {}
+for name, epi in (("first_layer_next_pq_folded", 4), ("last_layer_final_head", 2)):
+    tr = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
+    assert L.nbd_debug_gnn_trace_epilogue(epi) == 0
+    assert L.nbd_debug_gnn_trace(tr.data_ptr()) == 0
+    model.predict(pos, feat); torch.cuda.synchronize()
+    assert L.nbd_debug_gnn_trace(None) == 0
+    t = tr.view(-1, 8).cpu().numpy(); t = t[t[:, 0] != 0]
+    if len(t) == 0:
+        continue
+    t0 = t[:, 0].min()
+    out = {"waves": int(len(t)), "start_us_p50_max": [float(np.percentile((t[:,0]-t0)/100,50)), float(((t[:,0]-t0)/100).max())],
+           "staging_us_mean": float(((t[:,1]-t[:,0])/100).mean()), "edges_us_mean": float(((t[:,2]-t[:,1])/100).mean()),
+           "edges_done_at_us_p50_max": [float(np.percentile((t[:,2]-t0)/100,50)), float(((t[:,2]-t0)/100).max())]}
+    if (t[:, 6] != 0).any():
+        out["matvec_us_mean"] = float(((t[:,4]-t[:,2])/100).mean()); out["layernorm_us_mean"] = float(((t[:,5]-t[:,4])/100).mean())
+        out["head_us_mean"] = float(((t[:,6]-t[:,5])/100).mean()); out["end_at_us_p50_max"] = [float(np.percentile((t[:,6]-t0)/100,50)), float(((t[:,6]-t0)/100).max())]
+    if (t[:, 3] != 0).any():
+        out["matvec_folded_us_mean"] = float(((t[:,3]-t[:,2])/100).mean()); out["end_at_us_p50_max"] = [float(np.percentile((t[:,3]-t0)/100,50)), float(((t[:,3]-t0)/100).max())]
+    res[name] = out
+print(json.dumps(res))
