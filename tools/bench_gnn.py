@@ -44,6 +44,8 @@ def main():
     m1 = torch.tensor(m * n, dtype=torch.float32, device="cuda")[:, None]
     acc = model.predict(pos, torch.cat([vel, m1], 1))
     out = {"n": n, "k": 50}
+    feat = torch.cat([vel, m1], 1)
+    out["eager_predict_ms_gpu"], out["eager_predict_ms_wall"] = timeit(lambda: model.predict(pos, feat), iters)   # one C-ABI call
     out["eager_step_ms_gpu"], out["eager_step_ms_wall"] = timeit(lambda: tr.step(pos, vel, m1, acc, 1e-4), iters)
     adv = tr._capture_step(pos, vel, m1, acc, 1e-4)
     out["captured_step_ms_gpu"], out["captured_step_ms_wall"] = timeit(lambda: adv(clone=False), iters)
