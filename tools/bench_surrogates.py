@@ -187,11 +187,12 @@ def run(iters=20):
     alg = sum(2.0 * e_ * (2 * f * h_ + h_ * h_) for f in (4, 64))            # 2 E (2 F H + H H) per layer
     exe = sum(2.0 * n_ * (2 * f * h_ + h_ * h_) for f in (4, 64)) + 2 * 5.0 * e_ * h_   # per-node Linears + ~5 flop per edge-channel tanh
     out["gnn_n4096_k50"]["roofline"] = roofline_block(
-        "gnn_layer_kernel x2 (one fused launch per EdgeConv layer, graph given)", f_ms, alg, exe,
+        "gnn_layer64_kernel x2 (one fused launch per EdgeConv layer, graph given: per-kernel path, first layer forms Q on the fly, no exponential tables)", f_ms, alg, exe,
         4.0 * (n_ * 7 + n_ * 3) + 8.0 * e_,
         "algorithmic = the reference's per-edge formulation 2 E (2 F H + H H) (gnn.py:75-93); executed = first Linear "
         "factored per node (P_i + Q_j), second Linear once per node after the aggregation, E H tanh evaluations "
-        "(fp32 VALU, no MFMA in this kernel): latency-bound at 4096 waves of work, far below any throughput roofline")
+        "(fp32 VALU; the per-node 64-wide products run as 16-row fp32 MFMA operands): latency-bound at 4096 waves of work, far "
+        "below any throughput roofline. Inside the rollout's one-call pass the layers also use exponential tables (DESIGN.md)")
 
     _trace("gnn graph timed")
     torch.manual_seed(0)
