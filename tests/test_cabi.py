@@ -92,6 +92,21 @@ def test_host_only_queries():
     ca.cdim = 66                                                                        # out_channels % 4: the adjoint direction
     ca.head_dim[0] = 70
     assert L.nbd_cc_train_workspace_bytes(ctypes.byref(ca)) == 0
+    # the exponential tables of a one-call GNN forward: one [n][2h] block per layer, only for h <= 64 with the first
+    # layer formed from x and every layer feeding the next one's [P|Q]
+    fa = _lib.GnnForwardArgs()
+    assert L.nbd_gnn_forward_workspace_bytes(None) == 0 and L.nbd_gnn_forward_workspace_bytes(ctypes.byref(fa)) == 0
+    fa.n, fa.k, fa.n_layers = 4096, 50, 2
+    for l in range(2):
+        fa.layers[l].h = 64
+    fa.layers[0].x, fa.layers[0].f, fa.layers[0].epilogue, fa.layers[0].ep_out = 0x1000, 4, 4, 128
+    fa.layers[0].out, fa.layers[0].ldout = 0x2000, 128
+    fa.layers[1].pq, fa.layers[1].ldpq = 0x2000, 128
+    assert L.nbd_gnn_forward_workspace_bytes(ctypes.byref(fa)) == 2 * 4096 * 128 * 4
+    fa.layers[1].pq = 0x3000                                                            # not the first layer's output
+    assert L.nbd_gnn_forward_workspace_bytes(ctypes.byref(fa)) == 0
+    fa.layers[1].pq, fa.n = 0x2000, 10000                                               # beyond the staged search
+    assert L.nbd_gnn_forward_workspace_bytes(ctypes.byref(fa)) == 0
 
 
 def test_bad_arguments_are_rejected_without_touching_the_gpu():
@@ -110,6 +125,9 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert L.nbd_linear_wgrad_bias_f32(None, 4, None, 4, None, 10, 4, 4, None, 4, None, None, 0, None) == -1
     assert L.nbd_rowptr_sorted_i64(None, 5, 3, None, None) == -1
     assert L.nbd_gnn_train_forward_f32(None, None) == -1 and L.nbd_cc_train_forward_f32(None, None) == -1
+    assert L.nbd_knn_graph_hint_pq_f32(None, 5, 3, 0, 15, None, None, None, None) == -1
+    pq = _lib.KnnPqArgs()
+    assert L.nbd_knn_graph_hint_pq_f32(None, 5, 3, 0, 15, None, None, ctypes.byref(pq), None) == -1      # no tables to write
     dims = (ctypes.c_int * 2)(300, 3)
     assert L.nbd_ln_mlp_head_f32(None, 300, 300, None, None, 1e-5, 1, None, None, dims, None, 3, None, 0.0, 4, None) == -1
     # n == 0 is a no-op, not an error
