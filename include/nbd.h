@@ -303,7 +303,8 @@ int nbd_edgeconv_aggregate_f32(const float* pq, int ldpq, int h, const int* rowp
 /* EdgeConv with aggr = "max" (PyG's own default; gnn.py:79-93 passes the user's aggr through): the
  * second Linear cannot be hoisted out of a max, so messages are materialised per edge,
  * m[e] = tanh(P_tgt[e] + Q_src[e]) (edges grouped by target), nbd_linear_f32 runs over the E rows and
- * nbd_segment_reduce_f32 reduces each target's rows (mode 0 = sum, 1 = mean, 2 = max; empty -> 0). */
+ * nbd_segment_reduce_f32 reduces each target's rows (mode 0 = sum, 1 = mean, 2 = max; empty -> 0; 3 = product in row
+ * order, empty -> 1: torch_scatter's scatter(reduce="mul"), which contconv.py:95-97 reaches with agg="mul"). */
 int nbd_edge_messages_f32(const float* pq, int ldpq, int h, const int64_t* src, const int64_t* tgt, int64_t n_edges,
                           float* m, int ldm, nbd_stream_t stream);
 int nbd_segment_reduce_f32(const float* m, int ldm, int h, const int* rowptr, int n, int mode, float* out, int ldo,
@@ -490,6 +491,11 @@ int nbd_contconv_bin_bwd_f32(const float* pos, const float* da, int in_channels,
  * m[e][c] == x[i][c] (x = the forward output), 0 elsewhere. m may have zero rows for a target. */
 int nbd_segment_max_bwd_f32(const float* m, int ldm, int h, const float* x, int ldx, const int* rowptr, int n,
                             const float* dx, int lddx, float* dm, int lddm, nbd_stream_t stream);
+
+/* Backward of nbd_segment_reduce_f32 mode 3 (product): dm[e][c] = dx[i][c] * prod over the OTHER rows e' of target i of
+ * m[e'][c] (prefix times suffix: exact when a row holds zeros). */
+int nbd_segment_mul_bwd_f32(const float* m, int ldm, int h, const int* rowptr, int n, const float* dx, int lddx,
+                            float* dm, int lddm, nbd_stream_t stream);
 
 /* Backward of nbd_layernorm_f32: dx[n][c], dgamma[c], dbeta[c] from x, gamma (NULL = 1) and dy. */
 size_t nbd_layernorm_bwd_workspace_bytes(int n, int c);

@@ -39,8 +39,8 @@ class ContinuousConv(nn.Module):
         self.in_channels, self.out_channels = in_channels, out_channels
         self.radius, self.agg = radius, agg
         self.filter_resolution = filter_resolution
-        if agg not in ("mean", "sum", "add", "max", "min"):
-            raise NotImplementedError(f"agg={agg!r}: scatter reductions provided: sum/add, mean, max, min")
+        if agg not in ("mean", "sum", "add", "max", "min", "mul"):
+            raise NotImplementedError(f"agg={agg!r}: torch_scatter's reductions are sum/add, mean, max, min, mul")
         self.filters = nn.Parameter(torch.randn(filter_resolution, filter_resolution, filter_resolution,
                                                 in_channels, out_channels))            # contconv.py:20-28
 
@@ -107,7 +107,7 @@ class ContinuousConv(nn.Module):
             if centres.numel() == 0:
                 centres = torch.zeros(1, dtype=torch.int32, device=positions.device)
         r2 = float(np.float32(self.radius ** 2))                       # contconv.py:86: python double -> fp32
-        if self.agg in ("max", "min"):
+        if self.agg in ("max", "min", "mul"):
             return self._forward_extreme(positions, features, rowptr, centres, act, out)
         if self.agg != "mean":
             scale = None
@@ -168,7 +168,8 @@ class ContinuousConv(nn.Module):
 
 
     def _forward_extreme(self, positions, features, rowptr, centres, act, out):
-        """agg = "max" / "min" (scatter's other reductions, contconv.py:95-97): the feature-side binning needs a
+        """agg = "max" / "min" / "mul" (scatter's other reductions, contconv.py:95-97; "mul" = the product of a row's
+        messages, 1 for a row without any, as torch_scatter's scatter_mul): the feature-side binning needs a
         LINEAR aggregation, so the per-edge messages are materialised -- every edge becomes a row of its own in
         a virtual graph (row N + e at the position of the edge's aggregation target, one edge, sum aggregation)
         through the same kernels -- and reduced per target by nbd_segment_reduce_f32. Under autograd the same construction
@@ -181,7 +182,8 @@ class ContinuousConv(nn.Module):
             # backward sends a row's gradient to the first message attaining it (ag.SegmentMaxFn, as EdgeConv's max).
             e = int(rowptr[-1])
             if e == 0:
-                red = torch.zeros((n, self.out_channels), dtype=torch.float32, device=dev) + 0.0 * self.filters.sum()
+                red = torch.full((n, self.out_channels), 1.0 if self.agg == "mul" else 0.0, dtype=torch.float32,
+                                 device=dev) + 0.0 * self.filters.sum()
             else:
                 tgt = torch.repeat_interleave(torch.arange(n, device=dev), (rowptr[1:] - rowptr[:-1]).to(torch.int64), output_size=e)
                 pos_v = torch.cat([positions, positions[tgt]]).contiguous()
@@ -192,8 +194,11 @@ class ContinuousConv(nn.Module):
                     msgs = self.forward(pos_v, feat_v, edge_index=ei_v)[n:]
                 finally:
                     self.agg = agg
-                red = ag.SegmentMaxFn.apply((-msgs if agg == "min" else msgs).contiguous(), rowptr, n)
-                red = -red if agg == "min" else red
+                if agg == "mul":
+                    red = ag.SegmentMulFn.apply(msgs.contiguous(), rowptr, n)
+                else:
+                    red = ag.SegmentMaxFn.apply((-msgs if agg == "min" else msgs).contiguous(), rowptr, n)
+                    red = -red if agg == "min" else red
             if out is not None:
                 raise NbdError("ContinuousConv.forward: out= is an inference-only option")
             return torch.tanh(red) if act == "tanh" else red
@@ -213,7 +218,7 @@ class ContinuousConv(nn.Module):
             self.agg = agg
         if agg == "min":
             msgs = -msgs
-        red = nnops.segment_reduce(msgs.contiguous(), rowptr, n, "max")
+        red = nnops.segment_reduce(msgs.contiguous(), rowptr, n, "mul" if agg == "mul" else "max")
         if agg == "min":
             red = -red
         if act == "tanh":
@@ -517,11 +522,11 @@ class ContinuousConvModel(nn.Module):
         # one graph object for all layers: forward lists of every resolution and the adjoint lists of the layers whose
         # input carries a gradient, four jobs per launch
         graph = None
-        if x7.shape[0] > 0 and any(l.trains_fused() and l.agg not in ("max", "min") for l in self.contconv):
+        if x7.shape[0] > 0 and any(l.trains_fused() and l.agg not in ("max", "min", "mul") for l in self.contconv):
             graph = ag.ConvGraph.from_lists(pos, float(np.float32(self.radius ** 2)), lists)
             wants, needs_grad = [], enc.requires_grad
             for layer in self.contconv:
-                if layer.trains_fused() and layer.agg not in ("max", "min"):
+                if layer.trains_fused() and layer.agg not in ("max", "min", "mul"):
                     _, cmap, n_cells = layer.cells()
                     wants.append((layer.filter_resolution, cmap, n_cells, False))
                     if needs_grad:
@@ -529,7 +534,7 @@ class ContinuousConvModel(nn.Module):
                 needs_grad = True
             graph.prebuild(wants)
         for layer in self.contconv:
-            h = layer(pos, h, lists=lists, act="tanh", graph=graph if layer.agg not in ("max", "min") else None)
+            h = layer(pos, h, lists=lists, act="tanh", graph=graph if layer.agg not in ("max", "min", "mul") else None)
             if self.training and self.continuous_conv_dropout > 0:
                 h = torch.nn.functional.dropout(h, p=self.continuous_conv_dropout, training=True)
         z = ag.LayerNormFn.apply(torch.cat((enc, h), dim=-1), self.layer_norm.weight, self.layer_norm.bias,

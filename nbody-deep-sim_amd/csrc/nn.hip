@@ -319,7 +319,8 @@ __global__ __launch_bounds__(256) void edge_messages_kernel(const float* __restr
     M[(size_t)e * ldm + h] = tanhf(__fadd_rn(PQ[(size_t)i * ldpq + h], PQ[(size_t)j * ldpq + H + h]));
 }
 
-// out[i] = reduce over rows rowptr[i] .. rowptr[i+1] of M (0 = sum, 1 = mean, 2 = max; empty -> 0)
+// out[i] = reduce over rows rowptr[i] .. rowptr[i+1] of M (0 = sum, 1 = mean, 2 = max; empty -> 0; 3 = product in row
+// order, empty -> 1: torch_scatter's scatter_mul starts from ones)
 __global__ __launch_bounds__(256) void segment_reduce_kernel(const float* __restrict__ M, int ldm, int H,
                                                              const int* __restrict__ rowptr, int n, int mode,
                                                              float* __restrict__ out, int ldo) {
@@ -328,13 +329,13 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const float* __rest
   const int lane = threadIdx.x & 63;
   const int e0 = rowptr[i], e1 = rowptr[i + 1];
   for (int h = lane; h < H; h += 64) {
-    float acc = mode == 2 ? -__builtin_inff() : 0.f;
+    float acc = mode == 2 ? -__builtin_inff() : mode == 3 ? 1.f : 0.f;
     for (int e = e0; e < e1; ++e) {
       const float v = M[(size_t)e * ldm + h];
-      acc = mode == 2 ? fmaxf(acc, v) : acc + v;
+      acc = mode == 2 ? fmaxf(acc, v) : mode == 3 ? __fmul_rn(acc, v) : acc + v;
     }
     if (mode == 1) acc = acc / (float)max(e1 - e0, 1);
-    if (e1 == e0) acc = 0.f;
+    if (e1 == e0) acc = mode == 3 ? 1.f : 0.f;
     out[(size_t)i * ldo + h] = acc;
   }
 }
@@ -946,7 +947,7 @@ int nbd_edge_messages_f32(const float* pq, int ldpq, int h, const int64_t* src, 
 
 int nbd_segment_reduce_f32(const float* m, int ldm, int h, const int* rowptr, int n, int mode, float* out, int ldo,
                            nbd_stream_t stream) {
-  if (n < 0 || h <= 0 || mode < 0 || mode > 2) return NBD_E_BADARG;
+  if (n < 0 || h <= 0 || mode < 0 || mode > 3) return NBD_E_BADARG;
   if (n == 0) return 0;
   if (!rowptr || !out || ldo < h || (!m && ldm != 0) || ldm < h) return NBD_E_BADARG;
   segment_reduce_kernel<<<ceil_div(n, 4), 256, 0, (hipStream_t)stream>>>(m, ldm, h, rowptr, n, mode, out, ldo);

@@ -330,6 +330,28 @@ __global__ __launch_bounds__(256) void segment_max_bwd_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------ segment product backward (agg = "mul")
+// dm[e][c] = dx[i][c] * prod_{e' != e} m[e'][c]: exclusive prefix times exclusive suffix, no division (exact with zeros).
+// The suffix products are parked in dm itself on a first pass from the back, then the forward pass multiplies in the prefix.
+__global__ __launch_bounds__(256) void segment_mul_bwd_kernel(const float* __restrict__ m, int ldm, int H,
+                                                              const int* __restrict__ rowptr, int n,
+                                                              const float* __restrict__ dx, int lddx,
+                                                              float* __restrict__ dm, int lddm) {
+  const int i = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int e0 = rowptr[i], e1 = rowptr[i + 1];
+  for (int h = lane; h < H; h += 64) {
+    float suf = dx[(size_t)i * lddx + h];
+    for (int e = e1 - 1; e >= e0; --e) { dm[(size_t)e * lddm + h] = suf; suf = __fmul_rn(suf, m[(size_t)e * ldm + h]); }
+    float pre = 1.f;
+    for (int e = e0; e < e1; ++e) {
+      dm[(size_t)e * lddm + h] = __fmul_rn(dm[(size_t)e * lddm + h], pre);
+      pre = __fmul_rn(pre, m[(size_t)e * ldm + h]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ BatchNorm1d, training mode
 // (the PyG MLP of contconv.py:136-141 carries BatchNorm; a module that was never put in eval() normalises
 // with the batch statistics.) Column statistics in two fixed-order stages like nbd_colsum_f32.
@@ -647,6 +669,15 @@ int nbd_contconv_bin_bwd_f32(const float* pos, const float* da, int in_channels,
   contconv_bin_bwd_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(pos, da, in_channels, rowptr_s, tgt_s, deg, cap,
                                                                filter_resolution, radius_sq, cell_map, cells_out, dfeat,
                                                                lddf);
+  return status();
+}
+
+int nbd_segment_mul_bwd_f32(const float* m, int ldm, int h, const int* rowptr, int n, const float* dx, int lddx,
+                            float* dm, int lddm, nbd_stream_t stream) {
+  if (n < 0 || h < 0) return NBD_E_BADARG;
+  if (n == 0 || h == 0) return 0;
+  if (!m || !rowptr || !dx || !dm || ldm < h || lddx < h || lddm < h) return NBD_E_BADARG;
+  segment_mul_bwd_kernel<<<ceil_div(n, 4), 256, 0, (hipStream_t)stream>>>(m, ldm, h, rowptr, n, dx, lddx, dm, lddm);
   return status();
 }
 

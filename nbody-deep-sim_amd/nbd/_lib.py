@@ -273,6 +273,7 @@ SIGNATURES = {
                                                c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "nbd_segment_max_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                         c_void_p, c_int, c_void_p]),
+    "nbd_segment_mul_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "nbd_layernorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "nbd_layernorm_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p, c_int,
                                       c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

@@ -144,6 +144,24 @@ class SegmentMaxFn(Function):
         return nnops.segment_max_bwd(m, x, rowptr, dx if dx.stride(1) == 1 else dx.contiguous()), None, None
 
 
+class SegmentMulFn(Function):
+    """x_i = product over the rows of target i (empty -> 1: torch_scatter's scatter_mul); each row's gradient is the
+    product of the others times the target's."""
+
+    @staticmethod
+    def forward(ctx, m, rowptr, n):
+        x = nnops.segment_reduce(m, rowptr, n, "mul")
+        ctx.save_for_backward(m, rowptr)
+        ctx.n = n
+        return x
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dx):
+        m, rowptr = ctx.saved_tensors
+        return nnops.segment_mul_bwd(m, rowptr, ctx.n, dx if dx.stride(1) == 1 else dx.contiguous()), None, None
+
+
 class LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):

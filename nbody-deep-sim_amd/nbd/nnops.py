@@ -9,7 +9,7 @@ import torch
 from . import _lib
 
 ACT = {None: 0, "none": 0, "tanh": 1}
-AGGR = {"sum": 0, "add": 0, "mean": 1, "max": 2}
+AGGR = {"sum": 0, "add": 0, "mean": 1, "max": 2, "mul": 3}
 
 
 def _mat(t: torch.Tensor, name: str):
@@ -572,6 +572,17 @@ def segment_max_bwd(m, x, rowptr, dx):
                                                       _mat(x, "x"), rowptr.data_ptr(), n, dx.data_ptr(), _mat(dx, "dx"),
                                                       dm.data_ptr(), h, _lib.current_stream(m.device)),
                    "nbd_segment_max_bwd_f32")
+    return dm
+
+
+def segment_mul_bwd(m, rowptr, n, dx):
+    """Gradient of the per-target product (segment_reduce mode "mul") with respect to its rows."""
+    e, h = m.shape
+    dm = torch.empty((e, h), dtype=torch.float32, device=m.device)
+    with _lib.on_device(m.device):
+        _lib.check(_lib.lib().nbd_segment_mul_bwd_f32(m.data_ptr(), _mat(m, "m") if e else h, h, rowptr.data_ptr(), n,
+                                                      dx.data_ptr(), _mat(dx, "dx"), dm.data_ptr(), h,
+                                                      _lib.current_stream(m.device)), "nbd_segment_mul_bwd_f32")
     return dm
 
 

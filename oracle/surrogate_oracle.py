@@ -48,7 +48,9 @@ the HIP path is tested against:
       contconv.py:136-141), the GNN encoder does not (norm=None, gnn.py:62). Inference uses the
       running statistics (predict/eval_graph_batch call eval()).
   scatter(src, index, dim_size, reduce)   [contconv.py:95-97]   sum, or sum / max(count, 1) for mean;
-      "max" / "min": per-channel extreme of the messages of a row, 0 for a row without messages.
+      "max" / "min": per-channel extreme of the messages of a row, 0 for a row without messages;
+      "mul": per-channel product of the messages of a row, 1 for a row without messages (torch_scatter 2.1
+      scatter(): reduce == "mul" -> scatter_mul, whose output starts as torch.ones).
 """
 from __future__ import annotations
 
@@ -249,7 +251,7 @@ class ContinuousConvOracle(torch.nn.Module):
     def forward(self, positions, features, edge_index, edge_block=4096):
         row, col = edge_index[0], edge_index[1]
         out = torch.zeros((positions.shape[0], self.out_channels), dtype=features.dtype)
-        extreme = self.agg in ("max", "min")           # scatter(reduce="max"/"min"): per-edge messages, rows without
+        extreme = self.agg in ("max", "min", "mul")    # scatter(reduce="max"/"min"/"mul"): per-edge messages, rows without
         messages = []                                  # edges stay 0 (torch_scatter fills empty segments with 0)
         for e0 in range(0, row.numel(), edge_block):       # blocked only to bound the (E,I,O) temporary
             rw, cl = row[e0:e0 + edge_block], col[e0:e0 + edge_block]
@@ -265,6 +267,12 @@ class ContinuousConvOracle(torch.nn.Module):
                 messages.append(conv)
             else:
                 out.index_add_(0, rw, conv)
+        if extreme and self.agg == "mul":              # scatter_mul: ones, multiplied by every message of the row
+            out = torch.ones_like(out)
+            if messages:
+                out.scatter_reduce_(0, row.unsqueeze(1).expand(-1, self.out_channels), torch.cat(messages),
+                                    reduce="prod", include_self=True)
+            return out
         if extreme:
             if messages:
                 out.scatter_reduce_(0, row.unsqueeze(1).expand(-1, self.out_channels), torch.cat(messages),

@@ -393,8 +393,50 @@ def test_contconv_extreme_aggregations_match_oracle(agg, D, I, O, gpu_device):
     assert global_rel(got, ref) < TOL and row_rel(got, ref) < 10 * TOL
     assert float(got[torch.bincount(ei[0], minlength=300) == 0].abs().max()) == 0.0
     with pytest.raises(NotImplementedError):
-        contconv.ContinuousConv(I, O, D, agg="mul")
-    # (training through max / min: tests/test_train_gpu.py::test_contconv_extreme_aggregations_train)
+        contconv.ContinuousConv(I, O, D, agg="median")              # not one of torch_scatter's reductions
+    # (training through max / min: tests/test_train_gpu.py::test_contconv_extreme_aggregations_train; "mul": below)
+
+
+@pytest.mark.parametrize("D,I,O", [(4, 8, 16), (3, 70, 40)])
+def test_contconv_product_aggregation_matches_oracle_and_trains(D, I, O, gpu_device):
+    """scatter(reduce="mul") (contconv.py:95-97 passes `agg` straight through; torch_scatter's scatter_mul starts from
+    ones): the product of a row's messages, 1 for a row without any, forward and backward (each message's gradient is the
+    product of the others -- prefix times suffix, exact with zero messages) against autograd on the oracle. The bar is
+    TOL per factor: a product of up to `cap` messages carries the sum of their relative errors, so cap = 4 here."""
+    import contconv
+    from oracle import surrogate_oracle as so
+    cap = 4
+    torch.manual_seed(D + 40)
+    n = 200
+    pos, _, _ = _plummer_pos(n, 9)
+    feat = torch.randn(n, I)
+    dout = torch.randn(n, O)
+    ora = so.ContinuousConvOracle(I, O, D, radius=1.0, agg="mul")
+    layer = contconv.ContinuousConv(I, O, D, radius=1.0, agg="mul").cuda()
+    _copy_state(layer, ora)
+    ei = so.radius_graph(pos, 1.0, loop=False, max_num_neighbors=cap)
+    lonely = torch.bincount(ei[0], minlength=n) == 0
+    assert lonely.any()
+    with torch.no_grad():
+        ref = ora(pos, feat, ei)
+        got = layer(pos.cuda(), feat.cuda(), edge_index=ei.cuda()).cpu()
+    assert global_rel(got, ref) < cap * TOL
+    assert torch.equal(got[lonely], torch.ones_like(got[lonely]))
+    fr = feat.clone().requires_grad_()
+    torch.tanh(ora(pos, fr, ei)).backward(dout)
+    fg = feat.clone().cuda().requires_grad_()
+    out = layer(pos.cuda(), fg, edge_index=ei.cuda(), act="tanh")
+    out.backward(dout.cuda())
+    assert global_rel(fg.grad.cpu(), fr.grad) < cap * TOL
+    assert global_rel(layer.filters.grad.cpu(), ora.filters.grad) < cap * TOL
+    # a zero message: the other rows' gradients vanish, its own is the product of the others (no division anywhere)
+    from nbd import nnops
+    m = torch.tensor([[2.0, 0.0], [3.0, 5.0], [4.0, 0.0], [7.0, 7.0]], device="cuda")
+    rowptr = torch.tensor([0, 3, 3, 4], dtype=torch.int32, device="cuda")
+    x = nnops.segment_reduce(m, rowptr, 3, "mul")
+    assert torch.equal(x.cpu(), torch.tensor([[24.0, 0.0], [1.0, 1.0], [7.0, 7.0]]))
+    dm = nnops.segment_mul_bwd(m, rowptr, 3, torch.ones((3, 2), device="cuda"))
+    assert torch.equal(dm.cpu(), torch.tensor([[12.0, 0.0], [8.0, 0.0], [6.0, 0.0], [1.0, 1.0]]))
 
 
 def test_gnn_predict_through_one_cabi_call_equals_the_per_kernel_path(gpu_device):

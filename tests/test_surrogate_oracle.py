@@ -225,3 +225,24 @@ def test_trainer_step_restatement_is_leapfrog():
     p2, v2, a2 = so.trainer_step(lambda p, f: -p, pos, vel, m, acc, 0.1)
     v_half = vel + 0.05 * acc
     assert torch.allclose(p2, pos + 0.1 * v_half) and torch.allclose(a2, -p2) and torch.allclose(v2, v_half + 0.05 * a2)
+
+
+def test_contconv_oracle_product_aggregation_known_answer():
+    """scatter(reduce="mul") in the oracle: a row's output is the product of its messages, 1 without any -- checked
+    against the sum-aggregation oracle's single-edge messages multiplied by hand."""
+    import torch
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(3)
+    pos = torch.tensor([[0.0, 0, 0], [0.3, 0, 0], [0, 0.4, 0], [5.0, 5, 5]])
+    feat = torch.randn(4, 3)
+    mul = so.ContinuousConvOracle(3, 2, 3, radius=1.0, agg="mul")
+    add = so.ContinuousConvOracle(3, 2, 3, radius=1.0, agg="sum")
+    add.load_state_dict(mul.state_dict())
+    ei = torch.tensor([[0, 0, 1], [1, 2, 0]])
+    with torch.no_grad():
+        out = mul(pos, feat, ei)
+        m01 = add(pos, feat, ei[:, 0:1])[0]
+        m02 = add(pos, feat, ei[:, 1:2])[0]
+        m10 = add(pos, feat, ei[:, 2:3])[1]
+    assert torch.allclose(out[0], m01 * m02, rtol=1e-6, atol=0) and torch.allclose(out[1], m10, rtol=1e-6, atol=0)
+    assert torch.equal(out[2], torch.ones(2)) and torch.equal(out[3], torch.ones(2))
