@@ -391,6 +391,21 @@ typedef struct nbd_gnn_layer_args {
   int ldepq;
   float* out_epq;
   int ldout_epq;
+  /* Pre-advance (optional; FINAL_HEAD with ep_out == 3, kick_vel set, h == 64 -- NBD_E_UNSUPPORTED otherwise): the
+   * leapfrog bookkeeping of a rollout step (trainer.py:217-227) in the epilogue, so that a captured step is the search
+   * and the layers only. With vh = adv_vel_half[i] (the half-kicked velocity this step's positions were drifted with),
+   * x = adv_pos[i] (those positions: what the search saw) and a = out[i]:
+   *   kick_vel[i] = vh + kick_c a        this step's velocity (written, not accumulated)
+   *   adv_pos_out[i] = x                 this step's position
+   *   adv_vel_half[i] = kick_vel[i] + kick_c a ;  adv_pos[i] = x + adv_dt adv_vel_half[i]    the next step's first half,
+   * the new position also into the first three columns of adv_posm[i] (rows of 4: the packed model input). Every product
+   * and sum is rounded separately, as nbd_kick_f32 / nbd_kick_drift_f32 round them: the trajectory is bit for bit the one
+   * of the separate launches. Only node i's own rows are touched. */
+  float* adv_vel_half;
+  float* adv_pos;
+  float* adv_posm;
+  float* adv_pos_out;
+  float adv_dt;
 } nbd_gnn_layer_args;
 int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream);
 

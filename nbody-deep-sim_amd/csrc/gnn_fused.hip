@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64 * kT) void gnn_layer64_kernel(const nbd_gnn_laye
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) bfrag[ks] = mult ? wmat[(size_t)(4 * ks + (lane >> 4)) * n_out + 16 * wave + (lane & 15)] : 0.f;
   float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;          // folded: b2', b_ep of columns lane and 64 + lane; head: b2
-  float lg_e = 0.f, lb_e = 0.f, lg_y = 0.f, lb_y = 0.f, encv = 0.f, velv = 0.f, bh = 0.f;
+  float lg_e = 0.f, lb_e = 0.f, lg_y = 0.f, lb_y = 0.f, encv = 0.f, velv = 0.f, posv = 0.f, bh = 0.f;
   float wh_e[kMaxOut], wh_y[kMaxOut];
   const int E = a.e;
   if (folded) {
@@ -440,7 +440,11 @@ __global__ __launch_bounds__(64 * kT) void gnn_layer64_kernel(const nbd_gnn_laye
         if (lane < E) wh_e[d] = a.w_ep[(size_t)d * (E + H) + lane];
       }
     }
-    if (lane < a.ep_out) { bh = a.b_ep[lane]; if (a.kick_vel) velv = a.kick_vel[(size_t)nc * a.ep_out + lane]; }
+    if (lane < a.ep_out) {
+      bh = a.b_ep[lane];
+      if (a.adv_pos) { velv = a.adv_vel_half[(size_t)nc * 3 + lane]; posv = a.adv_pos[(size_t)nc * 3 + lane]; }
+      else if (a.kick_vel) velv = a.kick_vel[(size_t)nc * a.ep_out + lane];
+    }
   }
   float wp[1][FM], wq[1][FM], bp[1];
   if (a.pq == nullptr) {
@@ -515,7 +519,18 @@ __global__ __launch_bounds__(64 * kT) void gnn_layer64_kernel(const nbd_gnn_laye
   if (lane < a.ep_out) {
     const float o_d = mine + bh;
     a.out[(size_t)node * a.ldout + lane] = o_d;
-    if (a.kick_vel) a.kick_vel[(size_t)node * a.ep_out + lane] = __fadd_rn(velv, __fmul_rn(a.kick_c, o_d));
+    if (a.adv_pos) {                                     // nbd.h: this step's (x, v), then the next step's half-kick + drift
+      const float vfull = __fadd_rn(velv, __fmul_rn(a.kick_c, o_d));
+      a.kick_vel[(size_t)node * 3 + lane] = vfull;
+      a.adv_pos_out[(size_t)node * 3 + lane] = posv;
+      const float vnext = __fadd_rn(vfull, __fmul_rn(a.kick_c, o_d));
+      a.adv_vel_half[(size_t)node * 3 + lane] = vnext;
+      const float xn = __fadd_rn(posv, __fmul_rn(a.adv_dt, vnext));
+      a.adv_pos[(size_t)node * 3 + lane] = xn;
+      a.adv_posm[(size_t)node * 4 + lane] = xn;
+    } else if (a.kick_vel) {
+      a.kick_vel[(size_t)node * a.ep_out + lane] = __fadd_rn(velv, __fmul_rn(a.kick_c, o_d));
+    }
   }
   GT(6)
 }
@@ -543,6 +558,9 @@ int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
   else { if (!a.x || !a.wpq || !a.bpq || a.f <= 0 || a.ldx < a.f) return NBD_E_BADARG; if (a.f > kFMax) return NBD_E_UNSUPPORTED; }
   if (a.kick_vel && a.epilogue != NBD_GNN_FINAL_HEAD) return NBD_E_BADARG;
   if (a.epq && (a.h > 64 || a.ldepq < 2 * a.h)) return NBD_E_BADARG;
+  const bool adv = a.adv_vel_half || a.adv_pos || a.adv_posm || a.adv_pos_out;
+  if (adv && (!a.adv_vel_half || !a.adv_pos || !a.adv_posm || !a.adv_pos_out || !a.kick_vel)) return NBD_E_BADARG;
+  if (adv && (a.epilogue != NBD_GNN_FINAL_HEAD || a.ep_out != 3 || a.h != 64 || a.e > 64)) return NBD_E_UNSUPPORTED;
   if (a.out_epq && ((a.epilogue != NBD_GNN_NEXT_PQ && a.epilogue != NBD_GNN_NEXT_PQ_FOLDED) || a.ldout_epq < a.ep_out)) return NBD_E_BADARG;
   int n_ep = 0;
   switch (a.epilogue) {
@@ -583,6 +601,7 @@ int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
     else gnn_layer64_kernel<kFMax><<<blocks64, 64 * kT, 0, st>>>(a);
     return status();
   }
+  if (adv) return NBD_E_UNSUPPORTED;                     // the pre-advance epilogue lives in the kernel above only
   constexpr int W = 16;
   int blocks = (a.n + W - 1) / W;
   if (blocks > 512) blocks = 512;                        // two resident workgroups per CU at most (LDS, 32 waves); more nodes loop

@@ -396,7 +396,7 @@ class GraphModel(torch.nn.Module):
             fa.workspace, fa.workspace_bytes = ws.data_ptr(), need
         return {"fa": fa, "keep": keep, "out_dim": head[0][0].shape[0]}
 
-    def _predict_one_call(self, x_in, pos, k, out=None, kick=None):
+    def _predict_one_call(self, x_in, pos, k, out=None, kick=None, advance=None):
         """kNN graph + all fused layers through nbd_gnn_forward_f32, or None when this call cannot go that way (first
         call of a sequence: no previous graph to reuse as buffer and hint; configuration not all-fused)."""
         from nbd import _lib
@@ -429,9 +429,23 @@ class GraphModel(torch.nn.Module):
             last.kick_vel, last.kick_c = kick[0].data_ptr(), float(kick[1])
         else:
             last.kick_vel, last.kick_c = None, 0.0
+        if advance is not None:
+            # (vel_half, pos_out, posm, dt): the leapfrog bookkeeping in the last layer's epilogue (include/nbd.h,
+            # nbd_gnn_layer_args.adv_*); `pos` is then the pre-advanced position array the epilogue advances again
+            vh, pos_out, posm, dt = advance
+            ok = (kick is not None and od == 3 and self.gnn_dim == 64 and self.input_dim <= 64
+                  and all(t.shape == (n, 3) and t.dtype == torch.float32 and t.is_contiguous() and t.device == dev for t in (vh, pos_out))
+                  and posm.dtype == torch.float32 and posm.is_contiguous() and posm.shape[1] == 4 and posm.shape[0] >= n)
+            if not ok:
+                return None
+            last.adv_vel_half, last.adv_pos, last.adv_posm = vh.data_ptr(), pos.data_ptr(), posm.data_ptr()
+            last.adv_pos_out, last.adv_dt = pos_out.data_ptr(), float(dt)
+        else:
+            last.adv_vel_half = last.adv_pos = last.adv_posm = last.adv_pos_out = None
         with _lib.on_device(dev):
             _lib.check(_lib.lib().nbd_gnn_forward_f32(ctypes.byref(fa), _lib.current_stream(dev)), "nbd_gnn_forward_f32")
         self._kick_done = kick is not None
+        self._advance_done = advance is not None
         graphops.mark(buf, "_nbd_grouped")
         return out
 
@@ -461,7 +475,9 @@ class GraphModel(torch.nn.Module):
             pred = self._forward_inference(x_in, ei, max(min(k, pos.shape[0] - 1), 0))
         return pred
 
-    def _predict_posm(self, posm, pos, k=50, out=None, kick=None):
+    supports_pre_advance = True          # _predict_posm(advance=...): see Trainer._capture_step
+
+    def _predict_posm(self, posm, pos, k=50, out=None, kick=None, advance=None):
         """predict() for callers that already hold the packed rows {x, y, z, mass} the kick-drift kernel writes
         (Trainer's captured rollout step): with input_dim == 4 that IS the model input [pos | mass]
         (gnn.py:131-132), so nothing is concatenated. Same graph, same kernels, same values as predict().
@@ -469,19 +485,26 @@ class GraphModel(torch.nn.Module):
         single-Linear head; `self._kick_done` tells the caller whether it did (otherwise the caller kicks)."""
         self.eval()
         self._kick_done = False
+        self._advance_done = False
         self._kick_hint = kick
         try:
-            return self._predict_posm_impl(posm, pos, k, out)
+            return self._predict_posm_impl(posm, pos, k, out, advance)
         finally:
             self._kick_hint = None
 
-    def _predict_posm_impl(self, posm, pos, k, out):
+    def _predict_posm_impl(self, posm, pos, k, out, advance=None):
+        """advance = (vel_half, pos_out, dt): also do the step's leapfrog bookkeeping in the last layer's epilogue
+        (see _predict_one_call); `self._advance_done` tells the caller whether it happened -- it never does on the
+        general path below, and the caller must then not have relied on it (Trainer checks before capturing)."""
         with torch.no_grad():
             n = pos.shape[0]
             kk = max(min(k, n - 1), 0)
-            pred = self._predict_one_call(posm[:n], pos, k, out=out, kick=self._kick_hint)
+            adv = None if advance is None else (advance[0], advance[1], posm, advance[2])
+            pred = self._predict_one_call(posm[:n], pos, k, out=out, kick=self._kick_hint, advance=adv)
             if pred is not None:
                 return pred
+            if advance is not None:
+                raise NbdError("GraphModel._predict_posm: the pre-advancing step needs the one-call fused path")
             buf = self._knn_buf
             if buf is not None and (buf.shape != (2, n * kk) or buf.device != pos.device):
                 buf = None

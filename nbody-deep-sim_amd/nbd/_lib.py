@@ -48,7 +48,9 @@ class GnnLayerArgs(ctypes.Structure):
                 ("epilogue", c_int), ("w_ep", c_void_p), ("b_ep", c_void_p), ("ep_out", c_int),
                 ("enc", c_void_p), ("ldenc", c_int), ("e", c_int), ("ln_g", c_void_p), ("ln_b", c_void_p),
                 ("ln_eps", c_float), ("out", c_void_p), ("ldout", c_int), ("kick_vel", c_void_p), ("kick_c", c_float),
-                ("epq", c_void_p), ("ldepq", c_int), ("out_epq", c_void_p), ("ldout_epq", c_int)]
+                ("epq", c_void_p), ("ldepq", c_int), ("out_epq", c_void_p), ("ldout_epq", c_int),
+                ("adv_vel_half", c_void_p), ("adv_pos", c_void_p), ("adv_posm", c_void_p), ("adv_pos_out", c_void_p),
+                ("adv_dt", c_float)]
 
 
 GNN_MAX_LAYERS = 8

@@ -38,6 +38,7 @@ class Trainer:
         # rollouts replay ONE captured hipGraph per step (the step is ~17 short launches: launch-bound)
         self.use_hip_graph = True
         self.hip_graph_min_steps = 5       # shorter rollouts do not amortise the capture
+        self.pre_advance = True            # captured GNN step: leapfrog bookkeeping in the last layer's epilogue (_capture_step)
 
     def train_from_dir(self, data_path, epochs, batch_size, save_every, save_path=None, create_save_path=False):
         """trainer.py:20-92. Returns (epoch_losses, epoch_mse_losses). Checkpoints are `model_{epoch}.pt`
@@ -122,10 +123,29 @@ class Trainer:
                 posm = torch.zeros((direct.padded_len(s_pos.shape[0]), 4), dtype=torch.float32, device=s_pos.device)
                 m_flat = m.reshape(-1).contiguous()
                 keep += [posm, m_flat]
+            # Pre-advancing form (GraphModel, H = 64: include/nbd.h nbd_gnn_layer_args.adv_*): the last layer's epilogue does
+            # the leapfrog bookkeeping -- this step's velocity and position out, the next step's half-kick and drift in --
+            # so a replay is the search and the layers only. The first half-step is taken here, once, by the usual kernel.
+            pre = None
+            if packed and self.pre_advance and getattr(self.model, "supports_pre_advance", False):
+                vel_half, pos_pre = s_vel.clone(), s_pos.clone()
+                direct.kick_drift(pos_pre, vel_half, s_acc, m_flat, half, full, posm=posm)
+                try:        # one un-captured step: does this model / shape take the one-call path with the epilogue?
+                    t_pos, t_vel, t_acc, t_vh, t_pp, t_pm = (t.clone() for t in (s_pos, s_vel, s_acc, vel_half, pos_pre, posm))
+                    self.model._predict_posm(t_pm, t_pp, out=t_acc, kick=(t_vel, half), advance=(t_vh, t_pos, full))
+                    if self.model._advance_done:
+                        pre = (vel_half, pos_pre)
+                        keep += [vel_half, pos_pre]
+                except Exception:
+                    pre = None
             with torch.cuda.graph(graph):
                 # step() on the static state IN PLACE (same kernels and arithmetic; the functional clones and
                 # copy-backs of step() would be five more launches per replay)
-                if packed:
+                if pre is not None:
+                    o_acc = self.model._predict_posm(posm, pre[1], out=s_acc, kick=(s_vel, half), advance=(pre[0], s_pos, full))
+                    if not self.model._advance_done:
+                        raise RuntimeError("pre-advancing step fell off the one-call path during capture")
+                elif packed:
                     direct.kick_drift(s_pos, s_vel, s_acc, m_flat, half, full, posm=posm)
                     # the second half-kick rides in the last layer's epilogue when the model's fused path allows it
                     o_acc = self.model._predict_posm(posm, s_pos, out=s_acc, kick=(s_vel, half))   # s_acc is consumed by kick_drift above

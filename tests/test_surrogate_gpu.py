@@ -629,27 +629,33 @@ def test_test_from_dir_on_a_generated_csv(tmp_path, gpu_device):
     assert np.isfinite(df_roll.values).all() and (df_roll.loc[("output_file_1.csv", 0, 0)][["pos_rmse", "vel_rmse"]] == 0).all()
 
 
-@pytest.mark.parametrize("kind", ["gnn", "contconv"])
+@pytest.mark.parametrize("kind", ["gnn", "gnn64", "gnn64_separate_kick_drift", "contconv"])
 def test_hipgraph_rollout_step_equals_eager(kind, gpu_device):
     """Trainer._capture_step replays the captured step several times (state advances inside the graph);
     every replay must equal the eager Trainer.step bit for bit -- in particular counters that are
-    zeroed inside the captured region have to be re-zeroed on every replay."""
+    zeroed inside the captured region have to be re-zeroed on every replay. gnn64: the published width, whose
+    captured step has no kick-drift launch (the last layer's epilogue does the leapfrog bookkeeping, rounding as the
+    separate kernels do); gnn64_separate_kick_drift: the same model with that form switched off."""
     import contconv
     import gnn
     import trainer
     torch.manual_seed(5)
-    if kind == "gnn":
-        model = gnn.GraphModel(input_dim=4, gnn_dim=32, message_passing_steps=2, aggr="mean", neighbors=10, device="cuda")
+    if kind.startswith("gnn"):
+        model = gnn.GraphModel(input_dim=4, gnn_dim=32 if kind == "gnn" else 64, message_passing_steps=2, aggr="mean",
+                               neighbors=10, device="cuda")
     else:
         model = contconv.ContinuousConvModel(in_channels=4, out_channels=3, filter_resolution=[4, 3], radius=1.0, agg="mean",
                                              continuous_conv_layers=2, continuous_conv_dim=16, encoder_hiddens=[8],
                                              decoder_hiddens=[8], device="cuda").eval()
     tr = trainer.Trainer(model, None, device="cuda", dt=0.01)
+    tr.pre_advance = kind != "gnn64_separate_kick_drift"
     pos, vel, m = _plummer_pos(900, 21)
     pos, vel, m1 = pos.cuda(), vel.cuda(), (m * 900)[:, None].cuda()
     acc = model.predict(pos, torch.cat([vel, m1], 1))
     adv = tr._capture_step(pos, vel, m1, acc, 0.01)
     assert adv is not None
+    if kind.startswith("gnn"):
+        assert model._advance_done == (kind == "gnn64")
     p, v, a = pos, vel, acc
     for i in range(4):
         p, v, a = tr.step(p, v, m1, a, 0.01)
