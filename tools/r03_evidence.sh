@@ -22,6 +22,9 @@ python tools/summarize_pmc_kernels.py "gpurun_out/r03f_pmc_bench" gpurun_out/r03
 tools/pmc_run.sh r03f_pmc_cc -- python3 $R/tools/bench_contconv.py 4
 tools/pmc_lds.sh r03f_pmclds_cc -- python3 $R/tools/bench_contconv.py 4
 python tools/summarize_pmc_kernels.py "gpurun_out/r03f_pmc_cc" gpurun_out/r03f_pmc_cc_summary.json contconv_stream_kernel contconv_pairs contconv_stream_finish > /dev/null
+tools/pmc_run.sh r03f_pmc_gnn -- python3 $R/tools/bench_gnn.py 20
+python tools/summarize_pmc_kernels.py "gpurun_out/r03f_pmc_gnn" gpurun_out/r03f_pmc_gnn_summary.json gnn_layer64_kernel knn_select_staged_kernel > /dev/null
+python tools/bench_gnn.py 300 > gpurun_out/r03f_gnn_bench.json 2>/dev/null
 for t in bench cc gnn train; do
   f=$(find gpurun_out/r03f_prof_$t -name "*kernel_trace.csv" | head -1)
   python tools/summarize_trace.py $f gpurun_out/r03f_${t}_trace_summary.json > /dev/null
