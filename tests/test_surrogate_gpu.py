@@ -255,6 +255,11 @@ def _copy_state(dst, src):
     dict(input_dim=7, gnn_dim=128, message_passing_steps=2, aggr="sum", neighbors=6),       # H = 128: general path only
     dict(input_dim=4, gnn_dim=100, message_passing_steps=1, aggr="mean", neighbors=70, output_dim=5),
     dict(input_dim=4, gnn_dim=40, message_passing_steps=2, aggr="max", neighbors=9),          # PyG EdgeConv's own default
+    # H = 64 beyond the published shape (the MFMA-tail kernel's other epilogues and inputs): 7 features formed on the fly,
+    # three layers (a folded next-[P|Q] fed from [P|Q]), sum aggregation, LayerNorm handed to an MLP head ...
+    dict(input_dim=7, gnn_dim=64, message_passing_steps=3, aggr="sum", neighbors=6, output_hiddens=[16]),
+    # ... and behind an encoder: 64 encoder columns, the first [P|Q] from a Linear, LayerNorm over 128
+    dict(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", neighbors=7, node_encoder_dims=[24]),
 ])
 def test_gnn_forward_matches_oracle(cfg, gpu_device):
     import gnn
