@@ -27,7 +27,8 @@ def _batch(n, sizes):
 
 # ------------------------------------------------------------------ graph build: index-exact
 @pytest.mark.parametrize("n,k", [(1, 5), (2, 1), (10, 3), (10, 50), (65, 10), (200, 64), (500, 32), (500, 50),
-                                 (300, 100), (400, 200), (4096, 32)])
+                                 (300, 100), (400, 200), (4096, 32),
+                                 (5000, 20), (8192, 8), (8193, 5)])      # staged form: second half of its lane words, its limit, past it
 def test_knn_graph_bit_exact(n, k, gpu_device):
     from nbd import graphops
     from oracle import surrogate_oracle as so
@@ -886,7 +887,7 @@ def test_evaluate_rollout_rejects_ragged_steps(gpu_device):
         tr.evaluate_rollout("f.csv", data, 0, 3, 0.01, pd.DataFrame())
 
 
-@pytest.mark.parametrize("n,k", [(500, 10), (4096, 50), (700, 70), (65, 64)])
+@pytest.mark.parametrize("n,k", [(500, 10), (4096, 50), (700, 70), (65, 64), (6000, 30)])
 def test_knn_graph_result_does_not_depend_on_the_hint(n, k, gpu_device):
     """nbd_knn_graph_hint_f32: a previous graph bounds the search; a perfect, stale, duplicated or garbage hint
     must all give exactly the un-hinted (= oracle) result, also when the hint buffer is the output buffer."""
