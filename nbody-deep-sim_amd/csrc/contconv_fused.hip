@@ -1107,23 +1107,55 @@ __global__ __launch_bounds__(256) void contconv_stream_finish_kernel(
   }
   const int rb = TN / gridDim.y;                                   // rows of the tile this block finishes
   const int r0 = tile * TN + blockIdx.y * rb;
-  for (int e = tid; e < rb * OP / 4; e += 256) {
-    const int rl = e / (OP / 4), c = (e - rl * (OP / 4)) * 4;
-    const int row = r0 + rl;
-    if (row >= n || c >= O) continue;
-    f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (cnt < 0) v = f4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};   // refused tile
-    for (int w = w_first; w <= w_last; ++w) {
-      if (s_cut[w] >= s_cut[w + 1]) continue;                                  // empty range: wrote nothing
-      const f4 x = *reinterpret_cast<const f4*>(partial + ((size_t)(w + tile) * TN + (row - tile * TN)) * OP + c);
-      v = f4{v[0] + x[0], v[1] + x[1], v[2] + x[2], v[3] + x[3]};
-    }
-    const float sc = rowscale ? rowscale[row] : 1.0f;
+  // four output quads per thread and trip, three slots per round trip: the loads go out together (the slots were written by
+  // other XCDs a moment ago, every load is a cold round trip; one quad and one slot at a time made the kernel a chain of
+  // them: 13.9 -> 11.7 us), summed in slot order per element as before. (fast tanh instead of libm's here: no change.)
+  constexpr int U = 4;
+  const int total = rb * OP / 4;
+  for (int e0 = tid; e0 < total; e0 += 256 * U) {
+    f4 v[U];
+    int row[U], c[U];
+    bool ok[U];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (c + j < O) {
-        float y = rowscale ? __fmul_rn(v[j], sc) : v[j];
-        out[(size_t)row * ldo + c + j] = act == 1 ? tanhf(y) : y;
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + 256 * u;
+      const int rl = e / (OP / 4);
+      c[u] = (e - rl * (OP / 4)) * 4;
+      row[u] = r0 + rl;
+      ok[u] = e < total && row[u] < n && c[u] < O;
+      v[u] = cnt < 0 ? f4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")}      // refused tile
+                     : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr int WB = 3;                                                      // slots per round trip (a tile rarely has more)
+    for (int w0 = w_first; w0 <= w_last; w0 += WB) {
+      f4 x[WB][U];
+      bool live[WB];
+#pragma unroll
+      for (int q = 0; q < WB; ++q) {
+        const int w = w0 + q;
+        live[q] = w <= w_last && s_cut[min(w, G - 1)] < s_cut[min(w, G - 1) + 1];     // an empty range wrote nothing
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          x[q][u] = ok[u] && live[q] ? *reinterpret_cast<const f4*>(partial + ((size_t)(w + tile) * TN + (row[u] - tile * TN)) * OP + c[u])
+                                     : f4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int q = 0; q < WB; ++q) {
+        if (!live[q]) continue;                                                // wave-uniform; a skipped slot adds nothing, not + 0
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = f4{v[u][0] + x[q][u][0], v[u][1] + x[q][u][1], v[u][2] + x[q][u][2], v[u][3] + x[q][u][3]};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      const float sc = rowscale ? rowscale[row[u]] : 1.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (c[u] + j < O) {
+          float y = rowscale ? __fmul_rn(v[u][j], sc) : v[u][j];
+          out[(size_t)row[u] * ldo + c[u] + j] = act == 1 ? tanhf(y) : y;
+        }
       }
     }
   }
