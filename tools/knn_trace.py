@@ -16,8 +16,16 @@ ei = graphops.knn_graph(pos, k, loop=True)
 buf = ei.clone()
 L = _lib.lib(); L.nbd_debug_knn_trace.argtypes = [ctypes.c_void_p]; L.nbd_debug_knn_trace.restype = ctypes.c_int
 pos2 = pos + 1e-4 * torch.randn_like(pos)
+WITH_PQ = "--pq" in sys.argv          # the rollout's form: the search kernel also writes the first layer's table rows
+x = torch.randn(n, 4, device="cuda"); wpq = torch.randn(128, 4, device="cuda") * 0.3; bpq = torch.randn(64, device="cuda") * 0.1
+epq = torch.empty(n, 128, device="cuda")
+pq = _lib.KnnPqArgs(); pq.x, pq.ldx, pq.f, pq.h = x.data_ptr(), 4, 4, 64
+pq.wpq, pq.bpq, pq.epq, pq.ldepq = wpq.data_ptr(), bpq.data_ptr(), epq.data_ptr(), 128
 def hinted():
-    _lib.check(L.nbd_knn_graph_hint_f32(pos2.data_ptr(), n, k, 1, None, None, None, n * k, buf.data_ptr(), buf.data_ptr(), None), "knn")
+    if WITH_PQ:
+        _lib.check(L.nbd_knn_graph_hint_pq_f32(pos2.data_ptr(), n, k, 1, n * k, buf.data_ptr(), buf.data_ptr(), ctypes.byref(pq), None), "knn")
+    else:
+        _lib.check(L.nbd_knn_graph_hint_f32(pos2.data_ptr(), n, k, 1, None, None, None, n * k, buf.data_ptr(), buf.data_ptr(), None), "knn")
 for _ in range(5): hinted()
 torch.cuda.synchronize()
 tr = torch.zeros(n * 8, dtype=torch.int64, device="cuda")
