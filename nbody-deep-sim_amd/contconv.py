@@ -69,13 +69,15 @@ class ContinuousConv(nn.Module):
         return nnops.contconv_shuffle_filters(self.filters, idx)
 
     def fused_ok(self) -> bool:
-        ok = self.use_fused and nnops.contconv_fused_supported(self.in_channels, self.out_channels, self.cells()[2])
+        # the kernel wants in_channels % 4 == 0; other widths run it on zero-padded feature columns (forward(): one pad
+        # kernel; the shuffled filters are zero-padded to % 16 rows anyway, so the product is the same sum)
+        ok = self.use_fused and nnops.contconv_fused_supported((self.in_channels + 3) // 4 * 4, self.out_channels, self.cells()[2])
         if self.use_fused and not ok and not getattr(self, "_warned_fallback", False):
             import warnings
             self._warned_fallback = True          # once per layer: the other path is ~2.5x slower and forms A in HBM
             warnings.warn(f"ContinuousConv({self.in_channels} -> {self.out_channels}, D = {self.filter_resolution}, "
                           f"{self.cells()[2]} reachable cells): outside the fused block-sparse kernel's shapes "
-                          f"(in_channels % 4 == 0, <= 128; <= 160 cells) -- using the binned-matrix + GEMM path, which "
+                          f"(in_channels <= 128; <= 160 cells) -- using the binned-matrix + GEMM path, which "
                           f"materialises A (nodes x cells x in_channels fp32) in HBM")
         return ok
 
@@ -86,6 +88,7 @@ class ContinuousConv(nn.Module):
         the last is the forward kernel with in / out channels swapped, hence the second shape check)."""
         k = self.cells()[2]
         return (self.fused_ok() and self.in_channels <= 128 and self.out_channels <= 128 and
+                nnops.contconv_fused_supported(self.in_channels, self.out_channels, k) and
                 nnops.contconv_fused_supported(self.out_channels, self.in_channels, k))
 
     def forward(self, positions, features, edge_index=None, lists=None, act=None, out=None, wt=None, pairs=None,
@@ -142,6 +145,8 @@ class ContinuousConv(nn.Module):
             _, cmap, n_cells = self.cells()
             feats = features if (features.stride(-1) == 1 and features.stride(0) % 2 == 0 and
                                  features.data_ptr() % 8 == 0) else features.contiguous()
+            if self.in_channels % 4:
+                feats = torch.nn.functional.pad(feats, (0, 4 - self.in_channels % 4))
             if pairs is None:
                 pairs = nnops.contconv_pairs(positions.contiguous(), rowptr, centres, centres.numel(),
                                              self.filter_resolution, r2, cmap, n_cells)

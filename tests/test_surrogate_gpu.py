@@ -341,7 +341,8 @@ def test_contconv_layer_matches_oracle(agg, D, I, O, gpu_device):
 @pytest.mark.parametrize("n,D,I,O,agg,r,cap", [
     (400, 4, 8, 16, "mean", 1.0, 32), (1000, 6, 128, 128, "mean", 1.0, 32), (129, 3, 4, 20, "sum", 1.0, 32),
     (513, 5, 96, 130, "mean", 0.8, 32), (300, 4, 32, 64, "sum", 3.0, 300), (64, 2, 12, 33, "mean", 1.0, 32),
-    (2000, 6, 64, 96, "mean", 0.6, 32), (1, 4, 8, 8, "mean", 1.0, 32)])
+    (2000, 6, 64, 96, "mean", 0.6, 32), (1, 4, 8, 8, "mean", 1.0, 32),
+    (300, 5, 7, 33, "mean", 1.0, 32), (350, 3, 70, 40, "sum", 1.0, 32), (200, 4, 1, 5, "mean", 1.0, 32)])   # in_channels % 4 != 0: padded columns
 def test_contconv_fused_kernels_match_oracle_and_binned_path(n, D, I, O, agg, r, cap, gpu_device):
     """csrc/contconv_fused.hip (pair lists + gather/MFMA/accumulate in one kernel) against the oracle and against
     the round-1 formulation (dense binned matrix + GEMM) on the same edges: ragged tile counts, nodes without
@@ -382,7 +383,7 @@ def test_contconv_fused_kernels_match_oracle_and_binned_path(n, D, I, O, agg, r,
 def test_contconv_extreme_aggregations_match_oracle(agg, D, I, O, gpu_device):
     """scatter(reduce="max"/"min") (contconv.py:95-97 passes `agg` straight through): per-edge messages
     materialised through the virtual one-edge-per-row graph, then the segment reduction; rows without edges 0.
-    (I = 70 is off the fused kernel's grid: the binned + GEMM path carries the messages there.)"""
+    (I = 70: not a multiple of 4 -- the fused kernel runs on zero-padded feature columns.)"""
     import contconv
     from oracle import surrogate_oracle as so
     torch.manual_seed(D)
