@@ -681,15 +681,17 @@ def test_tiny_systems_match_oracle(n, gpu_device):
     pos, vel, m = _plummer_pos(max(n, 2), 30 + n)
     pos, vel, m = pos[:n].contiguous(), vel[:n].contiguous(), m[:n].contiguous()
     feat = torch.cat([vel, m[:, None]], 1)
-    ora = so.GraphModelOracle(input_dim=4, gnn_dim=16, message_passing_steps=2, aggr="mean", neighbors=3).eval()
-    model = gnn.GraphModel(input_dim=4, gnn_dim=16, message_passing_steps=2, aggr="mean", neighbors=3, device="cuda")
-    _copy_state(model, ora)
-    for fused in (True, False):
-        model.use_fused = fused
-        got = model.predict(pos.cuda(), feat.cuda()).cpu()
-        ref = ora.predict(pos, feat, k=50)
-        assert got.shape == (n, 3) and torch.isfinite(got).all()
-        assert (got - ref).abs().max() < 2e-5 * max(ref.abs().max().item(), 1.0), fused
+    for width in (16, 64):                      # 64: the workgroup-of-16-nodes layer kernel with fewer nodes than that
+        ora = so.GraphModelOracle(input_dim=4, gnn_dim=width, message_passing_steps=2, aggr="mean", neighbors=3).eval()
+        model = gnn.GraphModel(input_dim=4, gnn_dim=width, message_passing_steps=2, aggr="mean", neighbors=3, device="cuda")
+        _copy_state(model, ora)
+        for fused in (True, False):
+            model.use_fused = fused
+            ref = ora.predict(pos, feat, k=50)
+            for call in range(3 if fused else 1):   # later calls: the hinted one-call pass (staged search, tables)
+                got = model.predict(pos.cuda(), feat.cuda()).cpu()
+                assert got.shape == (n, 3) and torch.isfinite(got).all()
+                assert (got - ref).abs().max() < 2e-5 * max(ref.abs().max().item(), 1.0), (width, fused, call)
     cfg = dict(in_channels=4, out_channels=3, filter_resolution=[3], radius=1.0, agg="mean", self_loops=True,
                continuous_conv_layers=1, continuous_conv_dim=8, encoder_hiddens=[6], decoder_hiddens=[5])
     ora_c = so.ContinuousConvModelOracle(**cfg).eval()
