@@ -22,7 +22,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from gnn import MLP, _WeightCache, head_chain, run_chain, transform_to_graph  # noqa: F401  (same import as contconv.py:6)
+from gnn import MLP, _WeightCache, ensure_eval, head_chain, run_chain, transform_to_graph  # noqa: F401  (same import as contconv.py:6)
 from nbd import autograd as ag
 from nbd import graphops, nnops
 from nbd._lib import NbdError
@@ -389,7 +389,7 @@ class ContinuousConvModel(nn.Module):
         kick = (vel, c): vel += c * prediction in the decoder kernel's epilogue when the fused head runs; `_kick_done`
         tells the caller whether it did (otherwise the caller kicks)."""
         from nbd.data import Data
-        self.eval()
+        ensure_eval(self)
         self._kick_done = False
         with torch.no_grad():
             if getattr(self, "_radius_cache", None) is None:
@@ -406,7 +406,7 @@ class ContinuousConvModel(nn.Module):
         """contconv.py:261-271. (The reference also builds a k=50 kNN graph here that forward() then
         ignores; that dead work is not reproduced.)"""
         from nbd.data import Data
-        self.eval()
+        ensure_eval(self)
         with torch.no_grad():
             # predict() is the rollout entry point (Trainer.step): consecutive calls see almost the same configuration,
             # so the radius search re-tests cached candidate lists and runs its O(n^2) scan only when a body has moved

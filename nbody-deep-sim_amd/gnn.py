@@ -102,13 +102,33 @@ class _WeightCache:
         self.module, self.key, self.value = module, None, None
 
     def get(self, builder):
-        tensors = list(self.module.parameters()) + list(self.module.buffers())
-        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors)
+        # every parameter and buffer of the module tree, by a plain walk over the modules' own dicts: parameters() /
+        # buffers() build names and de-duplicate through generators -- 40 % of an eager predict()'s host time, measured
+        # (tools/profile_predict_host.py) -- and the key only needs the tensors
+        tensors, stack = [], [self.module]
+        while stack:
+            mod = stack.pop()
+            tensors.extend(t for t in mod._parameters.values() if t is not None)
+            tensors.extend(t for t in mod._buffers.values() if t is not None)
+            stack.extend(c for c in mod._modules.values() if c is not None)
+        key = tuple((t.data_ptr(), t._version, t.device) for t in tensors)
         if key != self.key:
             with torch.no_grad():
                 self.value = builder()
             self.key = key
         return self.value
+
+
+def ensure_eval(module):
+    """module.eval() only if some module of the tree is in training mode: Module.eval() re-assigns `training` on every
+    submodule through __setattr__ on every call (a third of an eager predict()'s host time)."""
+    stack = [module]
+    while stack:
+        mod = stack.pop()
+        if mod.training:
+            module.eval()
+            return
+        stack.extend(c for c in mod._modules.values() if c is not None)
 
 
 class GraphModel(torch.nn.Module):
@@ -452,7 +472,7 @@ class GraphModel(torch.nn.Module):
     def predict(self, pos, feat, neighbors=None):
         """gnn.py:205-215. The reference never forwards `self.neighbors` here, so the graph uses
         transform_to_graph's default k = 50; `neighbors=` is this build's optional override."""
-        self.eval()
+        ensure_eval(self)
         with torch.no_grad():
             k = 50 if neighbors is None else neighbors
             if not pos.is_cuda:
@@ -483,7 +503,7 @@ class GraphModel(torch.nn.Module):
         (gnn.py:131-132), so nothing is concatenated. Same graph, same kernels, same values as predict().
         kick = (vel, c): apply vel += c * prediction in the last layer's epilogue when the fused path runs with a
         single-Linear head; `self._kick_done` tells the caller whether it did (otherwise the caller kicks)."""
-        self.eval()
+        ensure_eval(self)
         self._kick_done = False
         self._advance_done = False
         self._kick_hint = kick
