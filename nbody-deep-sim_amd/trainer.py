@@ -165,7 +165,8 @@ class Trainer:
 
         def advance(clone=True):
             """One captured step. clone=False hands back the graph's own state buffers: valid only until
-            the next call (evaluate_rollout copies them into its table right away)."""
+            the next call (evaluate_rollout copies them into its table right away). The buffers are outputs: in the
+            pre-advancing form the next step starts from the graph's own pre-advanced copy, not from what they hold."""
             graph.replay()
             return (s_pos.clone(), s_vel.clone(), s_acc.clone()) if clone else (s_pos, s_vel, s_acc)
         cache = getattr(self.model, "_cache", None)
