@@ -36,6 +36,10 @@ extern "C" {
 typedef void* nbd_stream_t;
 
 int nbd_abi_version(void);
+/* sizeof() of the argument structs below as this library was compiled, by name ("nbd_gnn_layer_args", ...; 0 for an
+ * unknown name): a binding that mirrors a struct field for field checks its own size against this before the first call
+ * (nbd/_lib.py does; tests/test_cabi.py holds every mirror to it). */
+size_t nbd_struct_size(const char* name);
 /* Human-readable text for a return code (static storage). */
 const char* nbd_strerror(int code);
 

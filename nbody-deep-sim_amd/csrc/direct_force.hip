@@ -21,6 +21,7 @@
 //     256 CUs when there are few targets; slabs are summed in fixed order by the finishing
 //     kernel, so results are bit-reproducible (no float atomics).
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdint.h>
 
 #include "../../include/nbd.h"
@@ -514,6 +515,15 @@ bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 extern "C" {
 
 int nbd_abi_version(void) { return NBD_ABI_VERSION; }
+
+size_t nbd_struct_size(const char* name) {
+  if (!name) return 0;
+#define NBD_SZ(T) if (!strcmp(name, #T)) return sizeof(T);
+  NBD_SZ(nbd_gnn_layer_args) NBD_SZ(nbd_gnn_forward_args) NBD_SZ(nbd_knn_pq_args) NBD_SZ(nbd_gnn_train_args)
+  NBD_SZ(nbd_gnn_train_grads) NBD_SZ(nbd_cc_train_args) NBD_SZ(nbd_cc_train_grads) NBD_SZ(nbd_cc_pairs_job)
+#undef NBD_SZ
+  return 0;
+}
 
 const char* nbd_strerror(int code) {
   if (code == 0) return "ok";

@@ -246,6 +246,7 @@ SIGNATURES = {
     "nbd_gnn_train_workspace_bytes": (c_size_t, [POINTER(GnnTrainArgs)]),
     "nbd_gnn_train_forward_f32": (c_int, [POINTER(GnnTrainArgs), c_void_p]),
     "nbd_gnn_train_backward_f32": (c_int, [POINTER(GnnTrainArgs), c_void_p, c_int, POINTER(GnnTrainGrads), c_void_p]),
+    "nbd_struct_size": (c_size_t, [ctypes.c_char_p]),
     "nbd_gnn_layer_f32": (c_int, [POINTER(GnnLayerArgs), c_void_p]),
     "nbd_gnn_forward_workspace_bytes": (c_size_t, [POINTER(GnnForwardArgs)]),
     "nbd_knn_graph_hint_pq_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, POINTER(KnnPqArgs),
@@ -284,6 +285,12 @@ SIGNATURES = {
 _lib = None
 
 
+# C struct name -> its ctypes mirror (include/nbd.h; sizes checked against nbd_struct_size() when the library is loaded)
+STRUCT_MIRRORS = {"nbd_gnn_layer_args": GnnLayerArgs, "nbd_gnn_forward_args": GnnForwardArgs, "nbd_knn_pq_args": KnnPqArgs,
+                  "nbd_gnn_train_args": GnnTrainArgs, "nbd_gnn_train_grads": GnnTrainGrads, "nbd_cc_train_args": CcTrainArgs,
+                  "nbd_cc_train_grads": CcTrainGrads, "nbd_cc_pairs_job": CcPairsJob}
+
+
 def lib() -> ctypes.CDLL:
     """The loaded library; raises NbdError (never falls back) if it is not built."""
     global _lib
@@ -306,6 +313,10 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = argtypes
         if handle.nbd_abi_version() != 1:
             raise NbdError("libnbd_hip.so ABI version mismatch; rebuild")
+        for cname, mirror in STRUCT_MIRRORS.items():       # a stale .so beside newer Python (or the reverse) must not run
+            if handle.nbd_struct_size(cname.encode()) != ctypes.sizeof(mirror):
+                raise NbdError(f"libnbd_hip.so: sizeof({cname}) = {handle.nbd_struct_size(cname.encode())}, the ctypes mirror "
+                               f"has {ctypes.sizeof(mirror)} bytes; rebuild the library (python -c 'import __graft_entry__ as g; g.build()')")
         _lib = handle
     return _lib
 

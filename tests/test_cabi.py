@@ -41,6 +41,18 @@ def test_ctypes_table_matches_header():
     assert sorted(_lib.SIGNATURES) == declared_symbols()
 
 
+def test_ctypes_struct_mirrors_have_the_c_sizes():
+    """Every argument struct of include/nbd.h has a ctypes mirror (nbd/_lib.py) of exactly the compiled size -- a field
+    added on one side only would shift every later field silently."""
+    L = _lib.lib()
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "nbd.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"typedef struct (nbd_[a-z0-9_]+)", text)))
+    assert declared == sorted(_lib.STRUCT_MIRRORS)
+    for name, mirror in _lib.STRUCT_MIRRORS.items():
+        assert L.nbd_struct_size(name.encode()) == ctypes.sizeof(mirror) > 0, name
+    assert L.nbd_struct_size(b"no_such_struct") == 0 and L.nbd_struct_size(None) == 0
+
+
 def test_host_only_queries():
     L = _lib.lib()
     assert L.nbd_posm_padded_len(0) == 0
