@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NBD_ABI_VERSION 1
+#define NBD_ABI_VERSION 2
 #define NBD_E_BADARG (-1)   /* null pointer / negative size / misaligned buffer              */
 #define NBD_E_WORKSPACE (-2) /* workspace smaller than nbd_*_workspace_bytes() reported        */
 #define NBD_E_UNSUPPORTED (-3)
@@ -605,10 +605,15 @@ int nbd_cc_train_backward_f32(const nbd_cc_train_args* args, const float* dout, 
  *   edge_index[1]. cell_map (int32 [D^3], -1 = cell dropped) or NULL; n_cells = cells kept. edge_capacity >=
  *   rowptr[n] sizes the lists (host-known bound, e.g. n * max_num_neighbors: no device read-back).
  * nbd_contconv_fused_f32: out[n][:] = act(rowscale[n] * sum_cells A[n][cell] . F[cell]) with
- *   filters_shuffled = the (cell, in, out) filters in MFMA fragment order (v_mfma_f32_16x16x4_f32): float index
- *   ((((cell * ceil(O/16) + cb) * ceil(I/16) + g) * 64 + lane) * 4 + j) holds F[cell][16 g + 4 (lane >> 4) + j][16 cb +
- *   (lane & 15)], zero beyond I / O (nbd_contconv_filter_floats floats in all). act: 0 none, 1 tanh.
- *   rowscale may be NULL. Deterministic.
+ *   filters_shuffled = the (cell, in, out) filters as nbd_contconv_shuffle_filters_f32 writes them: every element split
+ *   into three bf16 terms (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round to nearest even: together
+ *   the 24 significant bits of x), in the fragment order of v_mfma_f32_16x16x32_bf16 -- 16-byte quad index
+ *   (((cell * ceil(O/16) + cb) * 4 + s) * 3 + u) * 64 + lane holds term u (0 lo, 1 mid, 2 hi) of
+ *   F[cell][32 s + 8 (lane >> 4) + e][16 cb + (lane & 15)], e = 0 .. 7; zero beyond I / O (nbd_contconv_filter_floats
+ *   counts it in floats: 4 per quad). act: 0 none, 1 tanh. rowscale may be NULL. Deterministic.
+ *   Arithmetic: fp32-equivalent. The features are split the same way on chip and the six term products of order <= 2^-16
+ *   (all but mid.lo, lo.mid, lo.lo) are accumulated in fp32 on the bf16 matrix pipe; the row error against an fp64
+ *   product is no larger than that of the fp32 matrix instruction (tests/test_surrogate_gpu.py holds it to that).
  * Limit: a node with more than 65 535 edges (the pair kernel counts pairs per (node, cell) in 16 bits) is not
  *   processed -- its whole tile of NBD_CC_TILE nodes comes out as NaN, loudly, instead of being summed wrongly. */
 int nbd_contconv_fused_supported(int in_channels, int out_channels, int n_cells);
@@ -657,9 +662,10 @@ int nbd_contconv_filter_grad_full_f32(const float* feat, int ldf, int in_channel
                                       const int* rowptr, int n, int64_t edge_capacity, const void* pair_lists, int n_cells,
                                       const int* cell_map, int cells_total, float* dfilters_full, void* workspace,
                                       size_t workspace_bytes, nbd_stream_t stream);
-/* filters (cells_total, in, out) row-major -> filters_shuffled, the fragment order nbd_contconv_fused_f32 reads, over the
- * kept cells kept_cells[0 .. n_cells) (int64 indices into the full grid, ascending). transposed = 1 re-lays every cell's
- * filter TRANSPOSED (the operand of the feature gradient: in / out swapped). nbd_contconv_filter_floats floats out. */
+/* filters (cells_total, in, out) row-major -> filters_shuffled, the bf16 x 3 fragment order nbd_contconv_fused_f32 reads
+ * (above), over the kept cells kept_cells[0 .. n_cells) (int64 indices into the full grid, ascending). transposed = 1
+ * re-lays every cell's filter TRANSPOSED (the operand of the feature gradient: in / out swapped).
+ * nbd_contconv_filter_floats floats out (16-byte aligned). Once per weight update. */
 int nbd_contconv_shuffle_filters_f32(const float* filters, const int64_t* kept_cells, int n_cells, int in_channels,
                                      int out_channels, int transposed, float* filters_shuffled, nbd_stream_t stream);
 /* Byte offsets of the sections of a pair-list buffer (for reports and tests; the layout is otherwise opaque):

@@ -47,8 +47,6 @@
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-typedef int i8v __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -56,7 +54,6 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int status() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : (int)e; }
 
 constexpr int TN = NBD_CC_TILE;      // nodes per tile (128)
-constexpr int LDA = 132;             // A row stride in floats: 16-B aligned, conflict-free ds_read_b128 fragments
 constexpr int MAXC = 160;            // filter cells kept (reachable) supported: D = 6 at R = 1 has exactly 160; the pair
                                      // kernel's LDS tables (7 bytes per (node, cell) + scan scratch) fill the 160 KiB at that
 constexpr int SUBR = 16;             // packed rows per step of the fused kernel (one 16 x 16 MFMA tile of rows)
@@ -64,16 +61,9 @@ constexpr int SUBR = 16;             // packed rows per step of the fused kernel
 // consumers ~1.1-1.45 us whatever it holds and the producers ~14.5 ns per pair (in-kernel stamps at the published shape,
 // round 3: the gathers are served from the Infinity Cache at ~3.5 TB/s), so below ~80-100 pairs the matrix side sets
 // the pace and above it the gather. (The additive model cost = a + pairs, a = 32 .. 96, measured 2-12 % slower.)
-#ifndef NBD_CC_COST_MIN
-#define NBD_CC_COST_MIN 80         // swept again once the cuts moved into the plan kernel (profiles/r03_contconv_ablations.json):
-#endif                             // 56 / 64 / 72 / 80 / 88 / 96 -> D = 6 + D = 4 layers 0.657 / 0.636 / 0.633 / 0.626 / 0.634 / 0.633 ms
-constexpr int CC_COST_MIN = NBD_CC_COST_MIN;
-#ifndef NBD_CC_COST_ADD
-#define NBD_CC_COST_ADD 0          // experiment switch: > 0 = the additive model cost = NBD_CC_COST_ADD + pairs
-#endif
-__host__ __device__ inline int step_cost(int pairs) {
-  return NBD_CC_COST_ADD > 0 ? NBD_CC_COST_ADD + pairs : (pairs > CC_COST_MIN ? pairs : CC_COST_MIN);
-}
+constexpr int CC_COST_MIN = 80;    // swept once the cuts moved into the plan kernel (profiles/r03_contconv_ablations.json):
+                                   // 56 / 64 / 72 / 80 / 88 / 96 -> D = 6 + D = 4 layers 0.657 / 0.636 / 0.633 / 0.626 / 0.634 / 0.633 ms
+__host__ __device__ inline int step_cost(int pairs) { return pairs > CC_COST_MIN ? pairs : CC_COST_MIN; }
 
 // first step record of a tile: a (tile, cell) with r rows has ceil(r / 16) <= r / 16 + 1 steps and a tile's rows
 // are <= 8 x its edges, so e_t / 2 + tile * (cells + 2) needs no scan across tiles (one terminal record per tile)
@@ -429,66 +419,66 @@ __global__ __launch_bounds__(1024) void contconv_plan_kernel(const PlanJobs jobs
 
 // ---------------------------------------------------------------------------------------------- fused conv
 // grid = (persistent workgroups, 1, column groups of 128); block = 1024 threads: waves 0-7 consume (MFMA, 16 output
-// columns each), waves 8-15 produce (gather + sum of the packed A rows; producer p owns ring buffer p).
+// columns each), waves 8-15 produce (gather + sum of the packed A rows).
 //
 // A "step" is 16 packed rows (distinct nodes) of one (tile, cell). The global step sequence (tile-major, then
-// cell, then 16-row slice; the pair kernel's per-tile step lists laid end to end) is cut into gridDim.x equal
-// contiguous ranges; a workgroup copies its range's step records into LDS (<= CC_CAP at a time) and walks it.
-// Producer p builds the steps p, p + 8, p + 16, ... of the range into buffer p; consumer waves walk all steps in
-// order. The two sides meet only through LDS flags -- full[b] = number of steps buffer b has held, done[b] =
-// consumer waves that have finished with them -- so a producer has eight step-times for the latency of its step
+// cell, then 16-row slice; the pair kernel's per-tile step lists laid end to end) is cut into gridDim.x contiguous
+// ranges of equal cost; a workgroup copies its range's step records into LDS (<= CC_CAP at a time) and walks it.
+// Producer p builds the steps p, p + 8, p + 16, ... of the range, step q into ring buffer q mod NBUF; consumer waves walk
+// all steps in order. The two sides meet only through LDS flags -- full[b] = number of steps buffer b has held, done[b][w]
+// = steps of buffer b consumer wave w has finished with -- so a producer has eight step-times for the latency of its step
 // (row records and pair records prefetched one own-step ahead; the feature rows of <= 32 pairs in flight), and the
 // consumers never wait for each other: every wave owns its 16 output columns of the LDS accumulator.
-#if defined(NBD_CC_ABL) && NBD_CC_ABL == 5           /* timing only: the consumers just hand the buffers back */
-#define CC_ABL_NO_CONSUME 1
-#else
-#define CC_ABL_NO_CONSUME 0
-#endif
-#if defined(NBD_CC_ABL) && NBD_CC_ABL == 6           /* timing only: one cell's filter fragment for all cells */
-#define CC_ABL_ONE_FRAGMENT 1
-#else
-#define CC_ABL_ONE_FRAGMENT 0
-#endif
-#if defined(NBD_CC_ABL) && NBD_CC_ABL == 3
-#define CC_MFMA(acc, a, b) acc[0] += a * b;
-#else
-#define CC_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-#endif
-#ifndef NBD_CC_SLEEP
-#define NBD_CC_SLEEP 2             // s_sleep between two polls of a flag (x64 cycles)
-#endif
-#ifndef NBD_CC_PRODUCER_PRIO
-#define NBD_CC_PRODUCER_PRIO 3
-#endif
+//
+// ARITHMETIC (round 4): fp32-equivalent on the bf16 matrix pipe. The fp32 matrix instruction (v_mfma_f32_16x16x4_f32)
+// runs at the fp32 vector rate, 1/16 of the bf16 rate, and was the kernel's pace-setter (0.93 us of matrix-pipe time per
+// step and SIMD). Both operands are now split into three bf16 terms,
+//     x = x_hi + x_mid + x_lo,   x_hi = bf16(x), x_mid = bf16(x - x_hi), x_lo = bf16(x - x_hi - x_mid)
+// (round to nearest even; both differences are exact in fp32, and the last rounding is too but for a measure-zero set:
+// the three terms carry all 24 bits of x), and the product is the six terms of order <= 2^-16,
+//     a.b ~= a_hi b_lo + a_mid b_mid + a_hi b_mid + a_mid b_hi + a_lo b_hi + a_hi b_hi,
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (24 instructions of 16 cycles per step and wave instead of 32 of 32
+// cycles). What is dropped (a_mid b_lo, a_lo b_mid, a_lo b_lo) is <= 2^-24 |a| |b| per product -- the size of the rounding
+// the fp32 instruction commits on every product anyway; tests/test_surrogate_gpu.py holds the row error against an fp64
+// product to no more than the fp32-MFMA kernel's on the same inputs (tools/cc_bf16x3.hip: 9e-8 vs 1.2e-7 on N(0,1) data).
+// The filters are split once per weight update (contconv_shuffle_kernel); the A rows by the producers as they write them.
+constexpr int CC_SLEEP = 2;                      // s_sleep between two polls of a flag (x64 cycles)
+constexpr int CC_PRODUCER_PRIO = 3;
 // The two consumer waves of a SIMD (w and w + 4) run at DIFFERENT priorities: at equal priority their MFMAs
 // interleave issue by issue, both bursts end together and both waves then sit in their LDS round trips (flag poll,
-// first fragment read, scatter) at the same time with the matrix pipe idle -- a convoy (in-kernel stamps, round 3:
-// 1.80 us per 16-row step against 0.98 us of matrix work, producers idle 53 % of the time). With one wave preferred
-// its burst runs uncontended while the other is in its latency phase, and vice versa.
-#ifndef NBD_CC_PRIO_HI
-#define NBD_CC_PRIO_HI 2
-#endif
-#ifndef NBD_CC_PRIO_LO
-#define NBD_CC_PRIO_LO 1
-#endif
-// ... and (NBD_CC_TOKEN = 1, off: it bought nothing) they can take turns on the matrix pipe explicitly: turn[simd] counts the bursts started on that SIMD -- wave w's
-// burst of step q is number 2 q, wave w + 4's 2 q + 1 -- and a wave starts its burst when the one before it is three
-// quarters issued (the handover then lands about when that burst ends). Without it both waves' MFMAs interleave, both
-// bursts take twice their length and both waves do their bookkeeping together with the pipe idle.
-#ifndef NBD_CC_TOKEN
-#define NBD_CC_TOKEN 0    // measured (round 3, N = 16 384): consumers alone 0.336 ms with, 0.324 without; whole layer 0.413 / 0.420
-#endif
-#ifndef NBD_CC_NBF
-#define NBD_CC_NBF 4               // batches of PB gathered rows in flight per producer wave
-#endif
-constexpr int NBUF = 8;                          // ring depth = producer waves
+// fragment reads, scatter) at the same time with the matrix pipe idle -- a convoy (in-kernel stamps, round 3). With one
+// wave preferred its burst runs uncontended while the other is in its latency phase, and vice versa.
+constexpr int CC_PRIO_HI = 2, CC_PRIO_LO = 1;
+constexpr int NBUF = 6;                          // ring depth: what the LDS holds beside the accumulator (12 KiB per step)
+constexpr int NPROD = 8;                         // producer waves
 constexpr int CC_CONSUMERS = 8;                  // consumer waves (16 output columns each)
-constexpr int CC_THREADS = (CC_CONSUMERS + NBUF) * 64;
+constexpr int CC_THREADS = (CC_CONSUMERS + NPROD) * 64;
 constexpr int LDO = 132;                         // accumulator row stride (floats): spreads the rows of a 128-bit scatter over the banks
-constexpr int CC_CAP = 256;                      // step records held in LDS at a time (a multiple of NBUF)
+constexpr int CC_CAP = 256;                      // step records held in LDS at a time (a multiple of NPROD)
 constexpr int CC_GRID = 256;                     // persistent workgroups (one per CU of an MI355X)
 constexpr int PB = 8;                            // gathered rows per batch
+constexpr int NBF = 4;                           // batches of PB gathered rows in flight per producer wave
+// A step in LDS: three planes (hi, mid, lo) of 16 rows x 128 bf16 = 256 B per row, no padding: the 16-byte chunk c of row
+// m sits at chunk c ^ m (XOR swizzle). A consumer lane reads chunk (lane >> 4) + 4 s of row lane & 15: whatever lanes the
+// LDS groups together (MI355X_MICROARCH.md, ds_read_b128: {0-3, 12-15, 20-27}, ...), equal lane >> 4 means distinct rows
+// -> distinct chunks, and the two lane >> 4 values of a group land on complementary halves: conflict-free. A producer lane
+// writes the dword (2 bf16) of columns 2 lane, 2 lane + 1: 64 distinct banks.
+constexpr int A_ROW_BYTES = 256, A_PLANE_BYTES = SUBR * A_ROW_BYTES, A_STEP_BYTES = 3 * A_PLANE_BYTES;
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+typedef int q4 __attribute__((ext_vector_type(4)));       // a quad of 8 bf16 as the registers see it
+
+// x (two floats) -> the three bf16 terms, packed two to a dword (low half = x[0])
+__device__ __forceinline__ unsigned pk_bf16(f2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2)); }
+__device__ __forceinline__ f2 unpk_bf16(unsigned h) { return f2{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)}; }
+__device__ __forceinline__ void split_bf16x3(f2 v, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = pk_bf16(v);
+  const f2 r1 = v - unpk_bf16(hi);               // exact
+  mid = pk_bf16(r1);
+  const f2 r2 = r1 - unpk_bf16(mid);             // exact
+  lo = pk_bf16(r2);
+}
 
 // Flags live in LDS and guard LDS data only: relaxed workgroup-scope atomics + fences restricted to the local
 // address space, so that signalling never drains the global loads a wave keeps in flight (filter-fragment and
@@ -496,7 +486,7 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 #define CC_WAIT(flag, cond)                                                                                  \
   do {                                                                                                       \
     while (!(__hip_atomic_load(&(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) cond))               \
-      __builtin_amdgcn_s_sleep(NBD_CC_SLEEP);                                                                \
+      __builtin_amdgcn_s_sleep(CC_SLEEP);                                                                    \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");                                          \
   } while (0)
 #define CC_RELEASE_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
@@ -506,13 +496,12 @@ typedef float f4v __attribute__((ext_vector_type(4)));
   do {                                                                                                       \
     while (__builtin_amdgcn_ballot_w64(__hip_atomic_load((ptr) + (lane & (CC_CONSUMERS - 1)), __ATOMIC_RELAXED, \
                                                          __HIP_MEMORY_SCOPE_WORKGROUP) < (want)) != 0ull)      \
-      __builtin_amdgcn_s_sleep(NBD_CC_SLEEP);                                                                \
+      __builtin_amdgcn_s_sleep(CC_SLEEP);                                                                    \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");                                          \
   } while (0)
 
-// Build-time probes (tools/build_contconv_trace.sh, tools/contconv_trace.py): -DNBD_CC_TRACE stamps every workgroup
-// (s_memrealtime) and accumulates the time consumer wave 0 / producer wave 0 spend on the LDS flags; -DNBD_CC_ABL = 3
-// is a timing-only ablation (no MFMA). Neither is in the product build.
+// Build-time probe (tools/build_contconv_trace.sh, tools/contconv_trace.py): -DNBD_CC_TRACE stamps every workgroup
+// (s_memrealtime) and accumulates the time consumer wave 0 / producer wave 0 spend on the LDS flags. Not in the product build.
 #ifdef NBD_CC_TRACE
 __device__ long long* g_cc_trace = nullptr;
 #define DBG_T(x) const long long x = __builtin_amdgcn_s_memrealtime();
@@ -522,35 +511,26 @@ __device__ long long* g_cc_trace = nullptr;
 #define DBG_ACC(cond, v, x)
 #endif
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
-
 // LDS / memory loads are "divergent" to the compiler even at wave-uniform addresses: values that steer control flow
 // are moved to SGPRs explicitly, or every `if` on them becomes v_cmp + s_and_saveexec and the counters VGPRs
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 __device__ __forceinline__ int4 uni4(int4 v) { return make_int4(UNI(v.x), UNI(v.y), UNI(v.z), UNI(v.w)); }
 __device__ __forceinline__ int2 uni2(int2 v) { return make_int2(UNI(v.x), UNI(v.y)); }
 
-// range of workgroup w of G over T steps: [T w / G, T (w + 1) / G)
-__host__ __device__ inline int range_begin(long long T, int w, int G) { return (int)(T * w / G); }
-
 struct CCArgs {
   const float* feat; int ldf, I; const int* rowptr; int n, n_tiles;
   const int2* rows; const int2* pair; const int4* steps; const int* tile_nsteps; const int* tile_cost;
   const int* cuts;     // [CC_GRID + 1] first step of every workgroup's range ...
   const int* tile_base;   // ... and [tiles + 1] first step of every tile: the plan, computed once per pair list (contconv_plan_kernel)
-  const f4* filt; int n_cells, kq_count, colblocks, OP; float* partial;
+  const uint4* filt; int n_cells, colblocks, OP; float* partial;
 };
 
 // LDS carve-up of the fused kernel (dynamic region, 16-byte aligned)
 struct CCLds {
   float* out_acc;      // [TN][LDO]
-  float* a_buf;        // [NBUF][SUBR][LDA]
+  char* a_buf;         // [NBUF][3 planes][SUBR][256 B]
   int* rowmap;         // [NBUF][SUBR]
-  int2* scratch;       // [NBUF producers][2][64] {row byte offset, weight}: two groups of 64 pair records per wave
+  int2* scratch;       // [NPROD producers][2][64] {row byte offset, weight}: two groups of 64 pair records per wave
   int4* st4;           // [CC_CAP] {cell | rows << 8 | steps left in the cell << 16, tile, first row, e_t}
   int2* st2;           // [CC_CAP] {first pair, end pair}
   int* seg;            // [3][CC_CAP], borrows the ring's first buffer while the ring is idle
@@ -559,17 +539,20 @@ struct CCLds {
 __device__ __forceinline__ CCLds cc_lds(float* lds, int* statics) {
   CCLds L;
   L.out_acc = lds;
-  L.a_buf = L.out_acc + TN * LDO;
-  L.rowmap = reinterpret_cast<int*>(L.a_buf + NBUF * SUBR * LDA);
+  L.a_buf = reinterpret_cast<char*>(L.out_acc + TN * LDO);
+  L.rowmap = reinterpret_cast<int*>(L.a_buf + NBUF * A_STEP_BYTES);
   L.scratch = reinterpret_cast<int2*>(L.rowmap + NBUF * SUBR);
-  L.st4 = reinterpret_cast<int4*>(L.scratch + NBUF * 128);
+  L.st4 = reinterpret_cast<int4*>(L.scratch + NPROD * 128);
   L.st2 = reinterpret_cast<int2*>(L.st4 + CC_CAP);
   L.seg = reinterpret_cast<int*>(L.a_buf);
-  L.s_red = statics; L.s_nseg = statics + 16; L.full = statics + 24; L.done = statics + 32;   // done[NBUF][CC_CONSUMERS]
+  L.s_red = statics; L.s_nseg = statics + 16; L.full = statics + 24; L.done = statics + 32;   // full[NBUF], done[NBUF][CC_CONSUMERS]
   return L;
 }
-constexpr size_t CC_LDS_BYTES = (size_t)(TN * LDO + NBUF * SUBR * LDA) * sizeof(float) + NBUF * SUBR * sizeof(int) +
-                                NBUF * 128 * sizeof(int2) + CC_CAP * (sizeof(int4) + sizeof(int2));
+constexpr size_t CC_LDS_BYTES = (size_t)TN * LDO * sizeof(float) + (size_t)NBUF * A_STEP_BYTES + NBUF * SUBR * sizeof(int) +
+                                NPROD * 128 * sizeof(int2) + CC_CAP * (sizeof(int4) + sizeof(int2));
+static_assert(CC_LDS_BYTES + 1024 <= 160 * 1024, "the fused kernel's LDS carve-up");
+static_assert(3 * CC_CAP * sizeof(int) <= (size_t)A_STEP_BYTES, "the segment list borrows one ring buffer");
+static_assert(NBUF <= 8, "full[] has eight words");
 
 // The step records of [p0, p1) of the global sequence -> LDS (all 1024 threads; both roles call it at the same
 // points, so the barriers match). The ring is idle here (first pass: untouched; later passes: every wave has left
@@ -602,15 +585,15 @@ __device__ __forceinline__ void cc_load_table(const CCArgs& A, const CCLds& L, i
   __syncthreads();
 }
 
-// ---------------- producer p: steps p, p + 8, ... of every pass into ring buffer p
+// ---------------- producer p: steps p, p + 8, ... of every pass, step q into ring buffer q mod NBUF
 // Per gathered row: one broadcast ds_read of its record {byte offset of the row, weight}, one v_add (lane offset),
 // one buffer_load_dwordx2, one v_pk_fma_f32. No scalar loads and no round trip to memory between the batches of a
 // step: the records of 64 pairs are fetched by ONE coalesced vector load (the first 64 of a step already while the
-// wave's previous step was summed) and parked in wave-private LDS.
+// wave's previous step was summed) and parked in wave-private LDS. A finished row (fp32 sums of columns 2 lane, 2 lane + 1
+// in the lane) is split into its three bf16 terms and stored as three dwords.
 __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int g0, int g1, int tid, long long* dbg) {
   const int lane = tid & 63, p = UNI(tid >> 6) - CC_CONSUMERS;     // the wave index in an SGPR: `p`-dependent branches are scalar
-  __builtin_amdgcn_s_setprio(NBD_CC_PRODUCER_PRIO);
-  float* a_dst = L.a_buf + p * SUBR * LDA;
+  __builtin_amdgcn_s_setprio(CC_PRODUCER_PRIO);
   int2* my_scr = L.scratch + p * 128;
   const int I = A.I;
   const bool live = 2 * lane < I;
@@ -633,6 +616,8 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
     f.s0 = r0.x; f.w0 = __int_as_float(r0.y);
     f.s1 = r1.x; f.w1 = __int_as_float(r1.y);
   };
+  // this lane's dword of row `row` in a plane: chunk (lane >> 2) ^ row, dword lane & 3 of it
+  const int lane_chunk = lane >> 2, lane_dw = (lane & 3) * 4;
   int qbase = 0;
   for (int p0 = g0; p0 < g1; p0 += CC_CAP) {
     const int p1 = min(g1, p0 + CC_CAP), npass = p1 - p0;
@@ -641,16 +626,10 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
     DBG_ACC(true, dbg[2], t0_)
     Pre nx = {make_int2(0, 0), 0, 0, 0.f, 0.f};
     if (p < npass) fetch(p, nx);
-    for (int i = p; i < npass; i += NBUF) {
-      const int use = (qbase + i) / NBUF;
+    for (int i = p; i < npass; i += NPROD) {
+      const int q = qbase + i, b = q % NBUF, use = q / NBUF;
+      char* a_dst = L.a_buf + b * A_STEP_BYTES;
       DBG_T(s0_)
-#if defined(NBD_CC_ABL) && NBD_CC_ABL == 4          /* timing only: no gather at all, the consumers' own speed */
-      if (use > 0) CC_WAIT_ALL_DONE(L.done + p * CC_CONSUMERS, use);
-      if (lane < SUBR) L.rowmap[p * SUBR + lane] = lane;
-      CC_RELEASE_FENCE();
-      if (lane == 0) __hip_atomic_store(&L.full[p], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      continue;
-#endif
       const int4 r = uni4(L.st4[i]);
       const int2 pr = uni2(L.st2[i]);
       const int cnt = (r.x >> 8) & 31, pb = pr.x, np = pr.y - pr.x;
@@ -658,23 +637,31 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
       const size_t e8 = (size_t)8 * r.w;
       const Pre cu = nx;
       const int2 rinfo = cu.rinfo;
-      fetch(min(i + NBUF, npass - 1), nx);                         // unconditional (the last steps re-fetch themselves)
+      fetch(min(i + NPROD, npass - 1), nx);                        // unconditional (the last steps re-fetch themselves)
       // the ring buffer is claimed only when the first feature rows are already on their way
       bool claimed = false;
       auto claim = [&]() {
         if (!claimed) {
           DBG_T(c0_)
-          if (use > 0) CC_WAIT_ALL_DONE(L.done + p * CC_CONSUMERS, use);   // the consumers are done with this buffer
+          if (use > 0) CC_WAIT_ALL_DONE(L.done + b * CC_CONSUMERS, use);   // the consumers are done with this buffer
           DBG_ACC(true, dbg[0], c0_)
-          if (lane < SUBR) L.rowmap[p * SUBR + lane] = lane < cnt ? rinfo.x : -1;   // padding rows: no node
+          if (lane < SUBR) L.rowmap[b * SUBR + lane] = lane < cnt ? rinfo.x : -1;   // padding rows: no node
           claimed = true;
         }
       };
       int cur = 0;
       int next_begin = __builtin_amdgcn_readlane(rinfo.y, 1);
       f2 acc = {0.f, 0.f};
-      auto flush = [&]() {                                         // row `cur` is complete
-        *reinterpret_cast<f2*>(a_dst + cur * LDA + 2 * lane) = live ? acc : f2{0.f, 0.f};
+      auto store_row = [&]() {                                     // row `cur` is complete: split, three dwords
+        unsigned hi, mid, lo;
+        split_bf16x3(live ? acc : f2{0.f, 0.f}, hi, mid, lo);
+        char* d = a_dst + cur * A_ROW_BYTES + (((lane_chunk ^ cur) & 15) << 4) + lane_dw;
+        *reinterpret_cast<unsigned*>(d) = hi;
+        *reinterpret_cast<unsigned*>(d + A_PLANE_BYTES) = mid;
+        *reinterpret_cast<unsigned*>(d + 2 * A_PLANE_BYTES) = lo;
+      };
+      auto flush = [&]() {
+        store_row();
         acc = f2{0.f, 0.f};
         ++cur;
         next_begin = __builtin_amdgcn_readlane(rinfo.y, cur + 1);
@@ -693,7 +680,7 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
       // NBF batches of PB rows in flight. EVERY stage issues exactly PB row loads (past the end: re-reads of the
       // last pair's row, L1 hits): only then can hipcc count its s_waitcnt vmcnt() and let batch j be summed while
       // the younger batches are in flight.
-      f2 fbuf[NBD_CC_NBF][PB];
+      f2 fbuf[NBF][PB];
 #define CC_ISSUE(SLOT, OFF)                                                                                  \
       {                                                                                                      \
         _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                                     \
@@ -728,7 +715,7 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
       CC_SUM(J, 32 * HQ + PB * (J), b0 + 4 * HQ + (J))                                                       \
       if (b0 + 4 * HQ + (J) + 1 >= nb) { done = true; break; }                                               \
       if (ISSUE_NEXT) CC_ISSUE(J, 32 * HQ + 32 + PB * (J))
-      static_assert(PB == 8 && NBD_CC_NBF == 4, "the slot rotation below is written out for four batches of 8 in flight");
+      static_assert(PB == 8 && NBF == 4, "the slot rotation below is written out for four batches of 8 in flight");
       bool done = false;
       for (int b0 = 0; !done; b0 += 16) {                            // one segment = 16 batches = 128 pairs
         if (b0 > 0) {
@@ -738,9 +725,6 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
           rs1 = r1.x; rw1 = __int_as_float(r1.y);
         }
         __builtin_amdgcn_wave_barrier();
-#if defined(NBD_CC_ABL) && NBD_CC_ABL == 2          /* timing only: every row from a 64 KiB table (L1 / L2 hits) */
-        rs0 &= 127; rs1 &= 127;
-#endif
         my_scr[lane] = make_int2((int)((unsigned)rs0 * ldb), PB * b0 + lane < np ? __float_as_int(rw0) : 0);
         my_scr[64 + lane] = make_int2((int)((unsigned)rs1 * ldb), PB * b0 + 64 + lane < np ? __float_as_int(rw1) : 0);
         __builtin_amdgcn_wave_barrier();
@@ -771,12 +755,12 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
       // are "used" here so that hipcc retires them now: left pending, their registers -- reused as temporaries at the
       // loop head -- made every wait there a vmcnt(0) that drained the row loads in flight (seen in the ISA).
 #pragma unroll
-      for (int sl = 0; sl < NBD_CC_NBF; ++sl)
+      for (int sl = 0; sl < NBF; ++sl)
 #pragma unroll
         for (int u = 0; u < PB; ++u) asm volatile("" ::"v"(fbuf[sl][u]));
-      *reinterpret_cast<f2*>(a_dst + cur * LDA + 2 * lane) = live ? acc : f2{0.f, 0.f};
+      store_row();
       CC_RELEASE_FENCE();
-      if (lane == 0) __hip_atomic_store(&L.full[p], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) __hip_atomic_store(&L.full[b], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       DBG_ACC(true, dbg[1], s0_)
     }
     qbase += npass;
@@ -784,36 +768,50 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
 }
 
 // ---------------- consumer: 16 output columns, all steps in order
-// Two consumer waves share a SIMD (waves w and w + 4). A step is ONE 16 x 16 tile per wave, the K = I contraction in
-// two independent accumulator chains; the MFMA takes the filter fragment as its first operand and the packed A rows
-// as its second, so the result comes out transposed -- lane l holds output columns 4 (l >> 4) .. + 3 of packed row
-// l & 15 -- and the scatter into the node's accumulator row is one ds_read_b128 + ds_write_b128 per lane (with the
-// operands the other way round a lane held one column of four rows: eight 32-bit read-modify-writes per step).
-// The fragment (I / 16 dwordx4 per lane) sits in registers, the next cell's is fetched into a second set while
-// this one multiplies (the two sets alternate: no copies). When the range crosses into the next tile (and at its
-// end) the wave writes its 16 columns of the accumulator to partial slot (workgroup + tile) and zeroes them.
+// Two consumer waves share a SIMD (waves w and w + 4). A step is ONE 16 x 16 tile per wave, the K = I contraction in NS
+// slabs of 32, six bf16 term products per slab; the MFMA takes the filter fragment as its first operand and the packed A
+// rows as its second, so the result comes out transposed -- lane l holds output columns 4 (l >> 4) .. + 3 of packed row
+// l & 15 -- and the scatter into the node's accumulator row is one ds_read_b128 + ds_write_b128 per lane. When the range
+// crosses into the next tile (and at its end) the wave writes its 16 columns of the accumulator to partial slot
+// (workgroup + tile) and zeroes them.
 //
-// SOFTWARE PIPELINE (round 3). In-kernel stamps of the first persistent version: a consumer wave spent 0.49 us of a
-// 1.83 us step issuing MFMAs and the rest in LDS round trips that nothing overlapped -- step record (tile), flag poll,
-// first fragment read, cell bookkeeping (2 dependent reads per cell), each 150-400 cycles with 16 waves on the LDS --
-// and with two waves per SIMD the pipe sat idle 47 % of the time. Now every control read is issued one step (or one
-// cell) before its value is used: while step i multiplies, the wave reads step i + 1's record and flag, and -- if that
-// step is already full, the normal case with the producers running ahead -- its row map and first two fragment
-// quads; the next cell's {cell, steps} come from a read issued a whole cell earlier.
-template <int KG>
+// Per slab s, in this order (S0 / S1 / BIG = three accumulators):
+//     S0 += b_lo[s] a_hi[s]    S1 += b_mid[s] a_mid[s]    S0 += b_mid[s] a_hi[s]
+//     S1 += b_hi[s] a_mid[s]   S0 += b_hi[s] a_lo[s]      BIG += b_hi[s] a_hi[s]
+// and the step's result is (S0 + S1) + BIG: the five products of order 2^-8 and 2^-16 never meet the leading one before
+// the end, whatever the slab order.
+//
+// THE FILTER FRAGMENT (NS slabs x 3 terms, one quad of 8 bf16 each: 48 VGPRs at I = 128) is single-buffered and reloaded
+// IN PLACE, quad by quad, inside the last step of a cell: the moment a quad's last MFMA of the step is issued, the next
+// cell's quad is requested into the same registers. The next step uses the quads in the same order, so every quad has 21
+// to 23 MFMAs of 24 to arrive -- with the sibling wave's burst in between about twice that in time: more than an L2 hit's
+// latency. (Two register sets with the next cell's fetched a whole cell ahead, round 3's scheme, would need 96 VGPRs for
+// the fragments alone; a 16-wave workgroup has 128 per lane.) hipcc cannot express either the in-flight registers or
+// the counted waits, so the loads are issued from inline asm ("+v": same register in and out) and the waits are written
+// by hand: the consumers issue no other vector loads (flush_acc drains its stores on the spot), loads retire in order,
+// and quads are always requested in the cyclic order j = 3 s + {lo, mid, hi} in which they are used. With Q = 3 NS quads:
+// before quad j's first use, a step that reloads waits vmcnt(Q - 1) (outstanding, oldest first: j .. Q - 1 of the previous
+// reload, then this step's 0 .. j - 1); a step that does not, vmcnt(Q - 1 - j) (outstanding: j .. Q - 1, or nothing).
+// tools/check_contconv_isa.py (run by the CPU tests) walks the disassembly's control-flow graph and verifies that nothing
+// reads or writes a fragment register between its load and the wait that covers it. K slabs beyond I hold zeros on both
+// sides (the producers write zeros beyond I, the shuffle kernel pads the filters).
+//
+// THE A FRAGMENTS (3 quads per slab) are streamed: slabs 0 .. 2 are requested at the step's start (the first two quads of
+// slab 0 already in the middle of the previous step, when that step's flag showed the buffer full), slab 3 when slab 0's
+// products are issued -- 36 VGPRs instead of 48.
+template <int NS>
 __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int g0, int g1, int tid, long long* dbg) {
   const int lane = tid & 63, cw = UNI(tid >> 6);
-  if (cw < CC_CONSUMERS / 2) __builtin_amdgcn_s_setprio(NBD_CC_PRIO_HI);
-  else __builtin_amdgcn_s_setprio(NBD_CC_PRIO_LO);
+  if (cw < CC_CONSUMERS / 2) __builtin_amdgcn_s_setprio(CC_PRIO_HI);
+  else __builtin_amdgcn_s_setprio(CC_PRIO_LO);
   const int cb = blockIdx.z * CC_CONSUMERS + cw;                   // 16-column block of the output
-  const int colblocks = A.colblocks, kq_count = A.kq_count;
+  const int colblocks = A.colblocks;
   const bool has_cols = cb < colblocks;
   int cur_tile = -1;
   auto flush_acc = [&](int tile) {
     int ln = lane;
     asm volatile("" : "+v"(ln));     // opaque: keeps hipcc from hoisting this rare path's per-lane addresses out of the step
-                                     // loops, where they cost five VGPRs that then spilled (and every spill slot's
-                                     // s_waitcnt vmcnt(0) drained the fragment prefetch)
+                                     // loops, where they cost VGPRs the step body needs
     float* dst = A.partial + ((size_t)(blockIdx.x + tile) * TN) * A.OP + (size_t)blockIdx.z * 128 + cw * 16 + (ln & 3) * 4;
     float* src = L.out_acc + cw * 16 + (ln & 3) * 4;
 #pragma unroll 4
@@ -824,83 +822,88 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
       *a = f4{0.f, 0.f, 0.f, 0.f};
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores and loads retire out of order with each other: keep the
-  };                                                   // hand-counted vmcnt of the fragment prefetch among loads only
-  static_assert(KG == 8 || KG == 2, "CC_FRAGMENT_LANDED counts KG loads");
-  f4 bf0[KG], bf1[KG];
-  // The next cell's fragment is requested a whole cell ahead and must stay IN FLIGHT until that cell starts. hipcc
-  // cannot express that: with builtin loads its s_waitcnt insertion put vmcnt(7) .. vmcnt(0) in front of the first
-  // MFMAs of a cell -- counting the loads just issued for the NEXT cell as if they were the current one's -- so every
-  // cell change waited out the L2 / Infinity Cache latency of the prefetch it had just started (in-kernel stamps:
-  // 0.73 us per step outside the steps, 40 % of a consumer wave's time; round 2's kernel had the same vmcnt(5) ..
-  // vmcnt(0) ladder behind its `g < kq_count ? v : 0` select). So the loads are issued from inline asm, which the
-  // compiler's wait insertion does not track, and the wait is written here: vmcnt(KG) in front of a cell's first
-  // step = "everything but the KG loads just issued for the next cell has landed". The "+v" operands of the wait
-  // make every use of the fragment depend on it. tools/check_contconv_isa.py (run by the CPU tests) verifies in the
-  // disassembly that nothing touches a fragment register between its load and that wait. K-groups beyond I
-  // (g >= kq_count) re-read the last group: finite numbers that meet all-zero A columns (the producers write zeros
-  // beyond I). The consumers issue no other vector-memory loads; the stores of flush_acc are drained on the spot.
-  // Addressing: the wave's column block of cell 0 as a scalar base, the cell's byte offset + 16 * lane in one VGPR
-  // (the filter matrix is checked < 2 GiB on the host), the k-groups as immediate offsets of two loads bases.
-  const char* fbase = reinterpret_cast<const char*>(A.filt) + (size_t)min(cb, colblocks - 1) * kq_count * 1024;
-  const unsigned cell_stride = (unsigned)colblocks * (unsigned)kq_count * 1024u;      // bytes between cells
-  auto load_b = [&](f4* dstv, int cell) {
-    const unsigned off0 = (unsigned)cell * cell_stride + (unsigned)lane * 16u;
-    if (KG == 8) {
-      const unsigned g4 = (unsigned)min(4, kq_count - 1) * 1024u;                       // I <= 64: groups 4-7 re-read group kq-1
-      const unsigned off1 = off0 + g4;
-      const unsigned d1 = kq_count > 1 ? 1024u : 0u, d2 = kq_count > 2 ? 2048u : d1, d3 = kq_count > 3 ? 3072u : d2;
-      const unsigned e1 = kq_count > 5 ? 1024u : 0u, e2 = kq_count > 6 ? 2048u : e1, e3 = kq_count > 7 ? 3072u : e2;
-      if (kq_count == 8) {            // the published shape: immediates
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dstv[0]) : "v"(off0), "s"(fbase) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(dstv[1]) : "v"(off0), "s"(fbase) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=&v"(dstv[2]) : "v"(off0), "s"(fbase) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=&v"(dstv[3]) : "v"(off0), "s"(fbase) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dstv[4]) : "v"(off1), "s"(fbase) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(dstv[5]) : "v"(off1), "s"(fbase) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=&v"(dstv[6]) : "v"(off1), "s"(fbase) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=&v"(dstv[7]) : "v"(off1), "s"(fbase) : "memory");
-      } else {
-        const unsigned o[8] = {off0, off0 + d1, off0 + d2, off0 + d3, off1, off1 + e1, off1 + e2, off1 + e3};
+  };                                                   // hand-counted vmcnt of the fragment loads among loads only
+  static_assert(NS == 1 || NS == 2 || NS == 4, "K slabs of 32");
+  constexpr int NQ = 3 * NS;                         // fragment quads per lane
+  // (quads are held as 4 x i32, a type hipcc never takes apart: as 8 x bf16 it unpacked and re-packed them by halves around
+  // every block boundary -- v_perm / v_lshrrev on registers with loads in flight)
+  q4 B[NQ];                                          // [3 s + u], u = 0 lo, 1 mid, 2 hi: the order of use
 #pragma unroll
-        for (int g = 0; g < 8; ++g)
-          asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dstv[g]) : "v"(o[g]), "s"(fbase) : "memory");
-      }
-    } else {
-      const unsigned off1 = off0 + (kq_count > 1 ? 1024u : 0u);
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dstv[0]) : "v"(off0), "s"(fbase) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dstv[KG - 1]) : "v"(off1), "s"(fbase) : "memory");
-    }
-  };
-  int* turn = L.done + NBUF * CC_CONSUMERS + (cw & 3);               // this SIMD's burst counter (waves w and w + 4)
-  const int a_lane = (lane & 15) * LDA + (lane >> 4) * 4;            // this lane's corner of a step's A tile
+  for (int j = 0; j < NQ; ++j) B[j] = q4{0, 0, 0, 0};
+  // Addressing: the wave's column block of cell 0 as a scalar base; the cell's byte offset + 16 lane (+ 4096 per four
+  // quads) in a VGPR (the filter matrix is checked < 2 GiB on the host), the quad inside its four as an immediate offset.
+  const char* fbase = reinterpret_cast<const char*>(A.filt) + (size_t)min(cb, colblocks - 1) * (NQ * 1024);
+  const unsigned cell_stride = (unsigned)colblocks * (NQ * 1024u);                    // bytes between cells
+  const unsigned lane16 = (unsigned)lane * 16u;
+#define CC_LOAD_QUAD(J, OFFS)                                                                                \
+  {                                                                                                          \
+    if constexpr (((J) & 3) == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(B[J]) : "v"(OFFS[(J) >> 2]), "s"(fbase) : "memory"); \
+    if constexpr (((J) & 3) == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "+v"(B[J]) : "v"(OFFS[(J) >> 2]), "s"(fbase) : "memory"); \
+    if constexpr (((J) & 3) == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "+v"(B[J]) : "v"(OFFS[(J) >> 2]), "s"(fbase) : "memory"); \
+    if constexpr (((J) & 3) == 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "+v"(B[J]) : "v"(OFFS[(J) >> 2]), "s"(fbase) : "memory"); \
+  }
+#define CC_QUAD_OFFSETS(NAME, CELL)                                                                          \
+  unsigned NAME[3];                                                                                          \
+  NAME[0] = (unsigned)(CELL) * cell_stride + lane16; NAME[1] = NAME[0] + 4096u; NAME[2] = NAME[0] + 8192u;
+  // "all but the N youngest loads have landed", tied to quad J's registers: every later use of them depends on it
+#define CC_QUAD_LANDED(J, N) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(B[J]) : "n"(N));
+#define CC_DRAIN()                                                                                           \
+  {                                                                                                          \
+    if constexpr (NS == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]));         \
+    if constexpr (NS == 2)                                                                                   \
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[NS > 1 ? 3 : 0]), "+v"(B[NS > 1 ? 4 : 0]), "+v"(B[NS > 1 ? 5 : 0])); \
+    if constexpr (NS == 4)                                                                                   \
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[NS > 1 ? 3 : 0]), "+v"(B[NS > 1 ? 4 : 0]), "+v"(B[NS > 1 ? 5 : 0]), \
+                   "+v"(B[NS > 2 ? 6 : 0]), "+v"(B[NS > 2 ? 7 : 0]), "+v"(B[NS > 2 ? 8 : 0]), "+v"(B[NS > 2 ? 9 : 0]), "+v"(B[NS > 2 ? 10 : 0]), \
+                   "+v"(B[NS > 2 ? 11 : 0]));                                                                 \
+  }
+  const int a_row = (lane & 15) * A_ROW_BYTES;                       // this lane's row of a step's A planes ...
+  const int sw0 = (((lane >> 4) ^ (lane & 15)) & 15) << 4;           // ... and its chunk of K slab 0 (slab s: ^ (s << 6))
   const int o_lane = cw * 16 + 4 * (lane >> 4);
   int qbase = 0;
   for (int p0 = g0; p0 < g1; p0 += CC_CAP) {
     const int p1 = min(g1, p0 + CC_CAP), npass = p1 - p0;
-    DBG_T(t0_)
     cc_load_table(A, L, p0, p1, tid);
-    (void)0;   /* (table loads: ~2 us per workgroup, see the producers' [2]) */
     // pipeline registers: the first reads of the step about to run (when `have`), that step's tile
-    f4 a0n = {0.f, 0.f, 0.f, 0.f};
+    q4 ah0n = q4{0, 0, 0, 0}, am0n = ah0n, al0n = ah0n;
     int node_n = -1;
     bool have = false;
     int tile_n = UNI(L.st4[0].y);
-#define CC_FRAGMENT_LANDED(BC)                                                                               \
-    if (has_cols) {                                                                                          \
-      if (KG == 8)                                                                                           \
-        asm volatile("s_waitcnt vmcnt(8)" : "+v"(BC[0]), "+v"(BC[1]), "+v"(BC[2]), "+v"(BC[3]), "+v"(BC[4]), \
-                     "+v"(BC[5]), "+v"(BC[6]), "+v"(BC[7]));                                                 \
-      else                                                                                                   \
-        asm volatile("s_waitcnt vmcnt(2)" : "+v"(BC[0]), "+v"(BC[1]));                                       \
-    }
-#define CC_FIRST_READS(B)                                                                                    \
+#define CC_A(BASE, PLANE, S) (*reinterpret_cast<const q4*>((BASE) + (PLANE) * A_PLANE_BYTES + (sw0 ^ ((S) << 6))))
+#define CC_FIRST_READS(BUF)                                                                                  \
     {                                                                                                        \
-      node_n = L.rowmap[(B) * SUBR + (lane & 15)];                                                           \
-      a0n = *reinterpret_cast<const f4*>(L.a_buf + (B) * SUBR * LDA + a_lane);                               \
+      node_n = L.rowmap[(BUF) * SUBR + (lane & 15)];                                                         \
+      ah0n = CC_A(L.a_buf + (BUF) * A_STEP_BYTES + a_row, 0, 0);                                             \
+      am0n = CC_A(L.a_buf + (BUF) * A_STEP_BYTES + a_row, 1, 0);                                             \
+      al0n = CC_A(L.a_buf + (BUF) * A_STEP_BYTES + a_row, 2, 0);                                             \
     }
-#define CC_STEP(BC, IDX)                                                                                     \
+#define CC_MFMA(ACC, BQ, AV) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, BQ), __builtin_bit_cast(b8, AV), ACC, 0, 0, 0);
+    // slab S: its six products, every fragment quad re-requested behind its last use when the step reloads
+#define CC_SLAB(S, RELOAD)                                                                                   \
+    if constexpr ((S) < NS) {                                                                                \
+      constexpr int S_ = (S) < NS ? (S) : 0;                                                                 \
+      CC_QUAD_LANDED(3 * S_, (RELOAD) ? NQ - 1 : NQ - 1 - 3 * S_)                                            \
+      CC_MFMA(accs0, B[3 * S_], ah[S_ & 1])                                                                  \
+      if (RELOAD) CC_LOAD_QUAD(3 * S_, offs_)                                                                \
+      CC_QUAD_LANDED(3 * S_ + 1, (RELOAD) ? NQ - 1 : NQ - 2 - 3 * S_)                                        \
+      CC_MFMA(accs1, B[3 * S_ + 1], am[S_ & 1])                                                              \
+      CC_MFMA(accs0, B[3 * S_ + 1], ah[S_ & 1])                                                              \
+      if (RELOAD) CC_LOAD_QUAD(3 * S_ + 1, offs_)                                                            \
+      CC_QUAD_LANDED(3 * S_ + 2, (RELOAD) ? NQ - 1 : NQ - 3 - 3 * S_)                                        \
+      CC_MFMA(accs1, B[3 * S_ + 2], am[S_ & 1])                                                              \
+      CC_MFMA(accs0, B[3 * S_ + 2], al[S_ & 1])                                                              \
+      CC_MFMA(accb, B[3 * S_ + 2], ah[S_ & 1])                                                               \
+      if (RELOAD) CC_LOAD_QUAD(3 * S_ + 2, offs_)                                                            \
+    }
+    // the three quads of slab S into register set S & 1 (slab S - 2's products are issued)
+#define CC_READ_SLAB(S)                                                                                      \
+    if constexpr ((S) < NS) {                                                                                \
+      constexpr int S_ = (S) < NS ? (S) : 0;                                                                 \
+      ah[S_ & 1] = CC_A(a_base, 0, S_); am[S_ & 1] = CC_A(a_base, 1, S_); al[S_ & 1] = CC_A(a_base, 2, S_);  \
+    }
+#define CC_STEP(IDX, RELOAD, NEXT_CELL)                                                                      \
     {                                                                                                        \
-      const int q_ = qbase + (IDX), b = q_ & (NBUF - 1), use = q_ / NBUF;                                    \
+      const int q_ = qbase + (IDX), b = q_ % NBUF, use = q_ / NBUF;                                          \
       if (tile_n != cur_tile) {                        /* the range crosses into the next tile */          \
         if (cur_tile >= 0 && has_cols) flush_acc(cur_tile);                                                  \
         cur_tile = tile_n;                                                                                   \
@@ -912,137 +915,103 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
       }                                                                                                      \
       DBG_T(w0_)                                                                                             \
       /* control reads for step IDX + 1, issued now, used half a burst later */                             \
-      const int nidx_ = min((IDX) + 1, npass - 1), bn_ = (q_ + 1) & (NBUF - 1);                              \
+      const int nidx_ = min((IDX) + 1, npass - 1), qn_ = q_ + 1, bn_ = qn_ % NBUF;                           \
       const int tile_v_ = L.st4[nidx_].y;                                                                    \
       const int flag_v_ = __hip_atomic_load(&L.full[bn_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
-      if (has_cols && !CC_ABL_NO_CONSUME) {                                                                  \
-        f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};                                        \
-        const float* a_base = L.a_buf + b * SUBR * LDA + a_lane;                                             \
+      if (has_cols) {                                                                                        \
+        f4v accs0 = {0.f, 0.f, 0.f, 0.f}, accs1 = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};         \
+        const char* a_base = L.a_buf + b * A_STEP_BYTES + a_row;                                             \
         const int node = node_n;                                                                             \
-        f4 av[KG];                                                                                           \
-        av[0] = a0n;                                                                                         \
+        q4 ah[2], am[2], al[2];                        /* two slabs: one multiplying, one arriving */       \
+        ah[0] = ah0n; am[0] = am0n; al[0] = al0n;                                                            \
+        CC_QUAD_OFFSETS(offs_, NEXT_CELL)                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        /* Four fragment quads at once, the last three one behind each of the first groups of MFMAs -- every   \
-           read four groups (512 cycles) ahead of its use: an LDS read takes 300-400 cycles with 16 waves on the \
-           array, and issued one group (128 cycles) ahead, as hipcc and the first persistent version did, every  \
-           group waited out the difference. (All seven at once cost 12 more VGPRs: spills.) */                \
-        _Pragma("unroll") for (int g = 1; g < KG && g < 5; ++g) av[g] = *reinterpret_cast<const f4*>(a_base + g * 16); \
-        if (NBD_CC_TOKEN) {                          /* my turn on this SIMD's matrix pipe? */               \
-          __builtin_amdgcn_sched_barrier(0);                                                                 \
-          const int my_turn_ = 2 * q_ + (cw >= CC_CONSUMERS / 2 ? 1 : 0);                                    \
-          while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < my_turn_)          \
-            __builtin_amdgcn_s_sleep(1);                                                                     \
-          __builtin_amdgcn_sched_barrier(0);                                                                 \
-        }                                                                                                    \
-        _Pragma("unroll") for (int g = 5; g < KG; ++g) av[g] = *reinterpret_cast<const f4*>(a_base + g * 16); \
-        _Pragma("unroll") for (int g = 0; g < KG && g < 4; ++g) {                                            \
-          CC_MFMA(acc0, BC[g][0], av[g][0]) CC_MFMA(acc1, BC[g][1], av[g][1])                                \
-          CC_MFMA(acc0, BC[g][2], av[g][2]) CC_MFMA(acc1, BC[g][3], av[g][3])                                \
-        }                                                                                                    \
-        if (KG == 8) {                                                                                       \
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                 \
-          _Pragma("unroll") for (int g = 0; g < 3; ++g) {                                                    \
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                               \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
-          }                                                                                                  \
-        }                                                                                                    \
+        CC_READ_SLAB(1)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        /* mid-burst: is step IDX + 1 already full? then its row map and first fragment quads come now */   \
+        CC_SLAB(0, RELOAD)                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        CC_READ_SLAB(2)                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        CC_SLAB(1, RELOAD)                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        CC_READ_SLAB(3)                                                                                      \
+        /* mid-burst: is step IDX + 1 already full? then its row map and the quads of its first slab come now */ \
         tile_n = UNI(tile_v_);                                                                               \
-        have = (IDX) + 1 < npass && UNI(flag_v_) >= (q_ + 1) / NBUF + 1;                                     \
+        have = (IDX) + 1 < npass && UNI(flag_v_) >= qn_ / NBUF + 1;                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        CC_SLAB(2, RELOAD)                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
         if (have) {                                                                                          \
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");                                    \
           CC_FIRST_READS(bn_)                                                                                \
         }                                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        /* second half, the node's accumulator quad requested in front of it (padding rows: row 0, discarded;  \
-           in program order behind the previous step's write of this wave) */                                \
+        /* the node's accumulator quad (padding rows: row 0, discarded; in program order behind the previous   \
+           step's write of this wave) */                                                                     \
         f4* o = reinterpret_cast<f4*>(L.out_acc + max(node, 0) * LDO + o_lane);                              \
         const f4 old = *o;                                                                                   \
-        _Pragma("unroll") for (int g = 4; g < KG && g < 6; ++g) {                                            \
-          CC_MFMA(acc0, BC[g][0], av[g][0]) CC_MFMA(acc1, BC[g][1], av[g][1])                                \
-          CC_MFMA(acc0, BC[g][2], av[g][2]) CC_MFMA(acc1, BC[g][3], av[g][3])                                \
-        }                                                                                                    \
-        if (KG == 8) {                                                                                       \
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
-          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                 \
-        }                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        if (NBD_CC_TOKEN && lane == 0)               /* three quarters issued: the sibling may start */      \
-          __hip_atomic_store(turn, 2 * q_ + (cw >= CC_CONSUMERS / 2 ? 2 : 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        _Pragma("unroll") for (int g = 6; g < KG; ++g) {                                                     \
-          CC_MFMA(acc0, BC[g][0], av[g][0]) CC_MFMA(acc1, BC[g][1], av[g][1])                                \
-          CC_MFMA(acc0, BC[g][2], av[g][2]) CC_MFMA(acc1, BC[g][3], av[g][3])                                \
-        }                                                                                                    \
+        CC_SLAB(3, RELOAD)                                                                                   \
         /* the buffer can go back to its producer: A and the row map are in registers */                    \
         CC_RELEASE_FENCE();                                                                                  \
         if (lane == 0) __hip_atomic_store(&L.done[b * CC_CONSUMERS + cw], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
         if (node >= 0)                                                                                       \
-          *o = f4{old[0] + (acc0[0] + acc1[0]), old[1] + (acc0[1] + acc1[1]), old[2] + (acc0[2] + acc1[2]),  \
-                  old[3] + (acc0[3] + acc1[3])};                                                             \
+          *o = f4{old[0] + ((accs0[0] + accs1[0]) + accb[0]), old[1] + ((accs0[1] + accs1[1]) + accb[1]),    \
+                  old[2] + ((accs0[2] + accs1[2]) + accb[2]), old[3] + ((accs0[3] + accs1[3]) + accb[3])};   \
       } else {                                                                                               \
-        if (NBD_CC_TOKEN) {                                                                                  \
-          const int my_turn_ = 2 * q_ + (cw >= CC_CONSUMERS / 2 ? 1 : 0);                                    \
-          while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < my_turn_)          \
-            __builtin_amdgcn_s_sleep(1);                                                                     \
-          if (lane == 0) __hip_atomic_store(turn, my_turn_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-        }                                                                                                    \
         tile_n = UNI(tile_v_);                                                                               \
         have = false;                                                                                        \
         if (lane == 0) __hip_atomic_store(&L.done[b * CC_CONSUMERS + cw], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
       }                                                                                                      \
       DBG_ACC(true, dbg[1], w0_)                                                                             \
     }
-    // Cells two at a time: the even cell multiplies with fragment set 0 while set 1 is fetched for the odd cell
-    // and vice versa. Written out like this (instead of a parity switch inside one loop) the loads of the NEXT
-    // cell are the only ones younger than the current cell's, so the wait before the first MFMA is a counted
-    // vmcnt(KG) and the prefetch really stays in flight. {cell, steps left} of the cell after the next one is read
-    // at the start of a cell and used at the start of the next.
-    auto meta_at = [&](int i) { return L.st4[min(i, npass - 1)].x; };      // cell | rows << 8 | steps left << 16
-    auto steps_of = [&](int meta, int i) { return min((meta >> 16) & 0xff, npass - i); };
-    int i = 0;
+    // meta = cell | rows << 8 | steps left in the cell << 16. A cell's steps but the last run in a loop that requests
+    // nothing; the last one requests the next cell's fragment (a pass's last step: its own cell's again -- the next pass
+    // starts afresh, and loads to one register retire in order).
+    auto meta_at = [&](int i) { return L.st4[min(i, npass - 1)].x; };
     int meta = UNI(meta_at(0));
-    if (has_cols) { load_b(bf0, meta & 0xff); if (CC_ABL_ONE_FRAGMENT) load_b(bf1, meta & 0xff); }
-    int rem = steps_of(meta, 0);
-    int meta_nv = meta_at(rem);                                        // next cell's record, value still on its way
-    while (i < npass) {
-      {
-        const int inext = i + rem;
-        const int meta_n = UNI(meta_nv), rem_n = steps_of(meta_n, inext);
-        if (has_cols && !CC_ABL_ONE_FRAGMENT) load_b(bf1, meta_n & 0xff);   // past the end: the last cell again, never used
-        meta_nv = meta_at(inext + rem_n);
-        DBG_T(f0_) CC_FRAGMENT_LANDED(bf0) DBG_ACC(true, dbg[2], f0_)      /* probe build: [2] = time waiting for fragments */
-        CC_STEP(bf0, i)
-        for (int u = 1; u < rem; ++u) CC_STEP(bf0, i + u)
-        i = inext; rem = rem_n;
+    if (has_cols) {
+      CC_QUAD_OFFSETS(offs0_, meta & 0xff)
+      CC_LOAD_QUAD(0, offs0_) CC_LOAD_QUAD(1, offs0_) CC_LOAD_QUAD(2, offs0_)
+      if constexpr (NS > 1) { CC_LOAD_QUAD(NS > 1 ? 3 : 0, offs0_) CC_LOAD_QUAD(NS > 1 ? 4 : 0, offs0_) CC_LOAD_QUAD(NS > 1 ? 5 : 0, offs0_) }
+      if constexpr (NS > 2) {
+        CC_LOAD_QUAD(NS > 2 ? 6 : 0, offs0_) CC_LOAD_QUAD(NS > 2 ? 7 : 0, offs0_) CC_LOAD_QUAD(NS > 2 ? 8 : 0, offs0_)
+        CC_LOAD_QUAD(NS > 2 ? 9 : 0, offs0_) CC_LOAD_QUAD(NS > 2 ? 10 : 0, offs0_) CC_LOAD_QUAD(NS > 2 ? 11 : 0, offs0_)
       }
-      if (i >= npass) break;
-      {
-        const int inext = i + rem;
-        const int meta_n = UNI(meta_nv), rem_n = steps_of(meta_n, inext);
-        if (has_cols && !CC_ABL_ONE_FRAGMENT) load_b(bf0, meta_n & 0xff);
-        meta_nv = meta_at(inext + rem_n);
-        DBG_T(f1_) CC_FRAGMENT_LANDED(bf1) DBG_ACC(true, dbg[2], f1_)
-        CC_STEP(bf1, i)
-        for (int u = 1; u < rem; ++u) CC_STEP(bf1, i + u)
-        i = inext; rem = rem_n;
-      }
+      // a pass's first request is waited out on the spot (once per CC_CAP steps): hipcc is free to move the quads into the
+      // registers its step loop keeps them in -- it does, for NS < 4 -- and a copy must not see a load in flight
+      CC_DRAIN()
     }
+    for (int i = 0; i < npass;) {
+      const int rem = min((meta >> 16) & 0xff, npass - i);
+      const int meta_nv = meta_at(i + rem);                             // the next cell's record, used by the reloading step
+      for (int u = 0; u + 1 < rem; ++u) CC_STEP(i + u, false, 0)
+      const int meta_n = UNI(meta_nv);
+      CC_STEP(i + rem - 1, true, meta_n & 0xff)
+      i += rem; meta = meta_n;
+    }
+    // the pass's last request (its own cell's fragment again) lands before anything else may use the registers
+    CC_DRAIN()
 #undef CC_STEP
+#undef CC_READ_SLAB
+#undef CC_SLAB
+#undef CC_MFMA
 #undef CC_FIRST_READS
-#undef CC_FRAGMENT_LANDED
+#undef CC_A
     qbase += npass;
   }
+#undef CC_DRAIN
+#undef CC_QUAD_LANDED
+#undef CC_QUAD_OFFSETS
+#undef CC_LOAD_QUAD
   if (has_cols && cur_tile >= 0) flush_acc(cur_tile);
 }
 
-template <int KG>
+template <int NS>
 __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArgs A) {
   // f4-typed so that the dynamic region starts 16-byte aligned behind the static __shared__ variables (declared as
   // float[] it began at an 8-byte offset and every ds_read_b128 / ds_write_b64 took the unaligned path)
   extern __shared__ f4 lds_aligned[];
-  __shared__ int statics[32 + NBUF * CC_CONSUMERS + 4];            // s_red[16], s_nseg, full[8], done[8][8], turn[4]
+  __shared__ int statics[32 + NBUF * CC_CONSUMERS];                // s_red[16], s_nseg, full[8], done[NBUF][8]
   const CCLds L = cc_lds(reinterpret_cast<float*>(lds_aligned), statics);
   const int tid = threadIdx.x, wave = UNI(tid >> 6);
 #ifdef NBD_CC_TRACE
@@ -1054,19 +1023,16 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
 
   // ---- this workgroup's range of the global step sequence: cut where the running COST (per step: max(CC_COST_MIN,
   // pairs)) crosses w / G of its total -- equal matrix work where the tiles are sparse, equal gather work where they
-  // are dense (cut by step COUNT, the first persistent version left the densest workgroups running 1.4x the mean at
-  // D = 4: their producers, not their MFMAs, set the pace). The cuts are part of the pair lists (contconv_plan_kernel,
-  // once per graph and resolution): computing them here cost every launch ~20 us of barriers and dependent loads in
-  // front of its first step (two layers per rollout step share one graph).
-  if (tid < NBUF) L.full[tid] = 0;
-  if (tid < NBUF * CC_CONSUMERS + 4) L.done[tid] = 0;               // and turn[4] behind it
+  // are dense. The cuts are part of the pair lists (contconv_plan_kernel, once per graph and resolution).
+  if (tid < 8) L.full[tid] = 0;
+  if (tid < NBUF * CC_CONSUMERS) L.done[tid] = 0;
   const int g0 = UNI(A.cuts[blockIdx.x]), g1 = UNI(A.cuts[blockIdx.x + 1]);
   if (g0 >= g1) return;                                            // uniform: the whole workgroup leaves
   for (int i = tid; i < TN * LDO / 4; i += CC_THREADS) reinterpret_cast<f4*>(L.out_acc)[i] = f4{0.f, 0.f, 0.f, 0.f};
   // (the first cc_load_table's barriers order the zeroing before any consumer's first scatter)
   DBG_T(r0_)
   if (wave >= CC_CONSUMERS) cc_producer(A, L, g0, g1, tid, dbg_wait);
-  else cc_consumer<KG>(A, L, g0, g1, tid, dbg_wait);
+  else cc_consumer<NS>(A, L, g0, g1, tid, dbg_wait);
   DBG_ACC(true, dbg_wait[3], r0_)
 #ifdef NBD_CC_TRACE
   if (lane == 0) { for (int i = 0; i < 4; ++i) s_dbg[wave][i] = dbg_wait[i]; }
@@ -1471,33 +1437,45 @@ __global__ __launch_bounds__(256) void contconv_wgrad_finish_full_kernel(const f
   out[e] = v;
 }
 
-// filters (cells_total, I, O) -> the fused kernel's MFMA fragment order over the kept cells (include/nbd.h):
-// float index ((((cell * CB + cb) * G + g) * 64 + lane) * 4 + j) = F[kept[cell]][16 g + 4 (lane >> 4) + j][16 cb + (lane & 15)],
-// zero beyond I / O; transposed = 1 re-lays F^T (in / out swapped: the feature gradient's operand). One thread per
-// (cell, cb, g, lane): four strided reads, one 16-byte store. (Five torch launches per call before, four calls per
-// training step.)
+// K slabs of 32 the stream kernel runs for `in` input channels (its template parameter; the fragment is padded to it).
+// Always 4 (K = 128, zeros beyond I): the kernel is written for 1 and 2 as well, but with the smaller fragments hipcc
+// keeps the quads in different registers in the loop of a cell's steps and in the reloading step and copies them in
+// between -- with loads in flight (tools/check_contconv_isa.py refuses those builds). Narrow layers multiply zeros: their
+// matrix work is small either way.
+__host__ __device__ inline int cc_slabs(int in) { (void)in; return 4; }
+
+// filters (cells_total, I, O) -> the fused kernel's MFMA fragment order over the kept cells (include/nbd.h), split into
+// three bf16 terms (split_bf16x3): 16-byte quad index (((cell * CB + cb) * NS + s) * 3 + u) * 64 + lane holds bf16 term
+// u (0 lo, 1 mid, 2 hi: the order the consumers use them in) of F[kept[cell]][32 s + 8 (lane >> 4) + e][16 cb + (lane & 15)], e = 0 .. 7; zero beyond I / O; transposed = 1
+// re-lays F^T (in / out swapped: the feature gradient's operand). One thread per (cell, cb, s, lane): eight strided reads,
+// three 16-byte stores. Once per weight update.
 __global__ __launch_bounds__(256) void contconv_shuffle_kernel(const float* __restrict__ f, const int64_t* __restrict__ kept,
-                                                               int n_cells, int I, int O, int transposed, f4* __restrict__ out) {
+                                                               int n_cells, int I, int O, int transposed, uint4* __restrict__ out) {
   const int Ii = transposed ? O : I, Oo = transposed ? I : O;           // the operand's own in / out
-  const int G = (Ii + 15) >> 4, CB = (Oo + 15) >> 4;
+  const int NS = cc_slabs(Ii), CB = (Oo + 15) >> 4;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)n_cells * CB * G * 64) return;
+  if (idx >= (size_t)n_cells * CB * NS * 64) return;
   const int lane = (int)(idx & 63);
   size_t rest = idx >> 6;
-  const int g = (int)(rest % G); rest /= G;
+  const int sl = (int)(rest % NS); rest /= NS;
   const int cb = (int)(rest % CB);
   const int cell = (int)(rest / CB);
   const float* src = f + (size_t)kept[cell] * I * O;
   const int col = 16 * cb + (lane & 15);
-  f4 v;
+  unsigned t[3][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int kk = 16 * g + 4 * (lane >> 4) + j;
-    float x = 0.f;
-    if (kk < Ii && col < Oo) x = transposed ? src[(size_t)col * O + kk] : src[(size_t)kk * O + col];
-    v[j] = x;
+  for (int e = 0; e < 8; e += 2) {
+    f2 x = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kk = 32 * sl + 8 * (lane >> 4) + e + j;
+      if (kk < Ii && col < Oo) x[j] = transposed ? src[(size_t)col * O + kk] : src[(size_t)kk * O + col];
+    }
+    split_bf16x3(x, t[0][e >> 1], t[1][e >> 1], t[2][e >> 1]);
   }
-  out[idx] = v;
+#pragma unroll
+  for (int term = 0; term < 3; ++term)
+    out[((((size_t)cell * CB + cb) * NS + sl) * 3 + (2 - term)) * 64 + lane] = make_uint4(t[term][0], t[term][1], t[term][2], t[term][3]);
 }
 
 constexpr size_t WG_HEADER_BYTES = 4096;      // ucut[WG_RANGES + 1] in front of the partial slots
@@ -1639,7 +1617,7 @@ size_t nbd_contconv_fused_workspace_bytes(int n, int n_cells, int out_channels) 
 
 size_t nbd_contconv_filter_floats(int in_channels, int out_channels, int n_cells) {
   if (in_channels <= 0 || out_channels <= 0 || n_cells <= 0) return 0;
-  return (size_t)n_cells * ceil_div(out_channels, 16) * ceil_div(in_channels, 16) * 64 * 4;
+  return (size_t)n_cells * ceil_div(out_channels, 16) * 3 * cc_slabs(in_channels) * 64 * 4;    // 16-byte quads of 8 bf16, in floats
 }
 
 int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const int* rowptr, int n, int64_t edge_capacity,
@@ -1669,11 +1647,11 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
   const int* tile_base = reinterpret_cast<const int*>(base + L.tbase);
   float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + CC_CUTS_BYTES);
   const dim3 grid(CC_GRID, 1, colgroups);
-  const int kq_count = ceil_div(in_channels, 16);
+  if (nbd_contconv_filter_floats(in_channels, out_channels, n_cells) * 4 > (size_t)0x7fffffff) return NBD_E_BADARG;   // 32-bit fragment offsets
   CCArgs A;
   A.feat = feat; A.ldf = ldf; A.I = in_channels; A.rowptr = rowptr; A.n = n; A.n_tiles = tiles;
   A.rows = rows; A.pair = pair; A.steps = steps; A.tile_nsteps = tile_nsteps; A.tile_cost = tile_cost; A.cuts = cuts; A.tile_base = tile_base;
-  A.filt = reinterpret_cast<const f4*>(filters_shuffled); A.n_cells = n_cells; A.kq_count = kq_count;
+  A.filt = reinterpret_cast<const uint4*>(filters_shuffled); A.n_cells = n_cells;
   A.colblocks = ceil_div(out_channels, 16); A.OP = OP; A.partial = partial;
 #define CC_LAUNCH(K)                                                                                                \
   do {                                                                                                              \
@@ -1682,7 +1660,7 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
     if (e != hipSuccess) return (int)e;                                                                             \
     contconv_stream_kernel<K><<<grid, CC_THREADS, CC_LDS_BYTES, st>>>(A);                                           \
   } while (0)
-  if (kq_count <= 2) CC_LAUNCH(2); else CC_LAUNCH(8);      // K depth: I <= 32 / I <= 128
+  CC_LAUNCH(4);                                            // cc_slabs(): one K depth, I <= 128
 #undef CC_LAUNCH
   int rc = status();
   if (rc) return rc;
@@ -1739,9 +1717,9 @@ int nbd_contconv_shuffle_filters_f32(const float* filters, const int64_t* kept_c
   if (n_cells <= 0 || in_channels <= 0 || out_channels <= 0 || !filters || !kept_cells || !filters_shuffled) return NBD_E_BADARG;
   if (reinterpret_cast<uintptr_t>(filters_shuffled) & 15) return NBD_E_BADARG;
   const int Ii = transposed ? out_channels : in_channels, Oo = transposed ? in_channels : out_channels;
-  const size_t quads = (size_t)n_cells * ceil_div(Oo, 16) * ceil_div(Ii, 16) * 64;
-  contconv_shuffle_kernel<<<(unsigned)((quads + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-      filters, kept_cells, n_cells, in_channels, out_channels, transposed ? 1 : 0, reinterpret_cast<f4*>(filters_shuffled));
+  const size_t threads = (size_t)n_cells * ceil_div(Oo, 16) * cc_slabs(Ii) * 64;
+  contconv_shuffle_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      filters, kept_cells, n_cells, in_channels, out_channels, transposed ? 1 : 0, reinterpret_cast<uint4*>(filters_shuffled));
   return status();
 }
 

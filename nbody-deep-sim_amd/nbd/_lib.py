@@ -121,6 +121,7 @@ class CcPairsJob(ctypes.Structure):
 
 
 CC_MAX_RES = 4
+ABI_VERSION = 2       # NBD_ABI_VERSION of include/nbd.h (2: the fused ContinuousConv filter operand is bf16 x 3)
 
 # name -> (restype, argtypes); mirrors include/nbd.h one to one (tests check the two agree)
 _F = POINTER(c_float)
@@ -311,7 +312,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.nbd_abi_version() != 1:
+        if handle.nbd_abi_version() != ABI_VERSION:
             raise NbdError("libnbd_hip.so ABI version mismatch; rebuild")
         for cname, mirror in STRUCT_MIRRORS.items():       # a stale .so beside newer Python (or the reverse) must not run
             if handle.nbd_struct_size(cname.encode()) != ctypes.sizeof(mirror):

@@ -218,24 +218,15 @@ def contconv_fused_supported(i_ch: int, o_ch: int, n_cells: int) -> bool:
 
 
 def contconv_shuffle_filters(filters: torch.Tensor, cells: torch.Tensor) -> torch.Tensor:
-    """filters (D,D,D,I,O) -> the MFMA fragment order nbd_contconv_fused_f32 reads (see include/nbd.h):
-    [cell (the kept ones)][16-column block][16-k block][lane][4], lane = 16 * ((k % 16) // 4) + column % 16,
-    element = k % 4, zero padded to I % 16 == 0 and O % 16 == 0. A layout transform of the weights: done once
-    per weight update."""
-    d, i_ch, o_ch = filters.shape[0], filters.shape[3], filters.shape[4]
-    k = int(cells.numel())
-    f = filters.detach().reshape(d * d * d, i_ch, o_ch).index_select(0, cells)
-    ip, op = (i_ch + 15) // 16 * 16, (o_ch + 15) // 16 * 16
-    if ip != i_ch or op != o_ch:
-        f = torch.nn.functional.pad(f, (0, op - o_ch, 0, ip - i_ch))
-    f = f.reshape(k, ip // 16, 4, 4, op // 16, 16)            # [cell][g][kb][j][cb][n]
-    f = f.permute(0, 4, 1, 2, 5, 3).contiguous()              # [cell][cb][g][kb][n][j]
-    return f.reshape(-1)
+    """filters (D,D,D,I,O) -> the operand nbd_contconv_fused_f32 reads (see include/nbd.h): the kept cells' I x O matrices
+    in MFMA fragment order, every element split into three bf16 terms (hi, mid, lo: together its 24 significant bits). A
+    layout transform of the weights: done once per weight update, by one launch (nbd_contconv_shuffle_filters_f32)."""
+    return contconv_shuffle_filters_kernel(filters, cells)
 
 
 def contconv_shuffle_filters_kernel(filters: torch.Tensor, cells: torch.Tensor, transposed: bool = False) -> torch.Tensor:
-    """contconv_shuffle_filters as ONE launch (nbd_contconv_shuffle_filters_f32): what the training step calls four times
-    (two layers, forward and the transposed operand of the feature gradient); `cells` int64 on the device."""
+    """nbd_contconv_shuffle_filters_f32: what the training step calls four times (two layers, forward and the transposed
+    operand of the feature gradient); `cells` int64 on the device."""
     d, i_ch, o_ch = filters.shape[0], filters.shape[3], filters.shape[4]
     f = filters.detach()
     f = f if (f.is_contiguous() and f.dtype == torch.float32) else f.contiguous().float()

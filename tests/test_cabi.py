@@ -28,7 +28,7 @@ def test_header_declares_something():
 def test_library_builds_and_loads():
     _lib.build()
     assert os.path.exists(_lib.LIB_PATH)
-    assert _lib.lib().nbd_abi_version() == 1
+    assert _lib.lib().nbd_abi_version() == _lib.ABI_VERSION == 2
 
 
 @pytest.mark.parametrize("sym", declared_symbols())
