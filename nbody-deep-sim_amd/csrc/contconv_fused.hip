@@ -638,7 +638,9 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
       const Pre cu = nx;
       const int2 rinfo = cu.rinfo;
       fetch(min(i + NPROD, npass - 1), nx);                        // unconditional (the last steps re-fetch themselves)
-      // the ring buffer is claimed only when the first feature rows are already on their way
+      // the ring buffer is claimed only when the step's first row is complete (its pairs have landed and are summed): six
+      // buffers serve eight producers, and a buffer held through the first round trip of a step's gather was a buffer the
+      // others waited for (in-kernel stamps, round 4: producers 47 % of their time on `done`, consumers 31 % on `full`)
       bool claimed = false;
       auto claim = [&]() {
         if (!claimed) {
@@ -653,6 +655,7 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
       int next_begin = __builtin_amdgcn_readlane(rinfo.y, 1);
       f2 acc = {0.f, 0.f};
       auto store_row = [&]() {                                     // row `cur` is complete: split, three dwords
+        claim();
         unsigned hi, mid, lo;
         split_bf16x3(live ? acc : f2{0.f, 0.f}, hi, mid, lo);
         char* d = a_dst + cur * A_ROW_BYTES + (((lane_chunk ^ cur) & 15) << 4) + lane_dw;
@@ -732,7 +735,6 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
         CC_ISSUE(1, PB)
         CC_ISSUE(2, 2 * PB)
         CC_ISSUE(3, 3 * PB)
-        claim();
         do {
 #define HQ 0
           CC_STAGE(0, true) CC_STAGE(1, true) CC_STAGE(2, true) CC_STAGE(3, true)
@@ -775,7 +777,8 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
 // crosses into the next tile (and at its end) the wave writes its 16 columns of the accumulator to partial slot
 // (workgroup + tile) and zeroes them.
 //
-// Per slab s, in this order (S0 / S1 / BIG = three accumulators):
+// Per slab s, in this order (S0 / S1 / BIG = three accumulators; an MFMA never follows one it depends on directly: the
+// consumers-alone build ran 4 % slower with the small products in ONE chain):
 //     S0 += b_lo[s] a_hi[s]    S1 += b_mid[s] a_mid[s]    S0 += b_mid[s] a_hi[s]
 //     S1 += b_hi[s] a_mid[s]   S0 += b_hi[s] a_lo[s]      BIG += b_hi[s] a_hi[s]
 // and the step's result is (S0 + S1) + BIG: the five products of order 2^-8 and 2^-16 never meet the leading one before
@@ -864,18 +867,20 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
   for (int p0 = g0; p0 < g1; p0 += CC_CAP) {
     const int p1 = min(g1, p0 + CC_CAP), npass = p1 - p0;
     cc_load_table(A, L, p0, p1, tid);
-    // pipeline registers: the first reads of the step about to run (when `have`), that step's tile
-    q4 ah0n = q4{0, 0, 0, 0}, am0n = ah0n, al0n = ah0n;
+    // pipeline registers: the A quads and the row map entry of the step about to run (valid when `have`), that step's tile
+    q4 a[NS][3];                                       // [slab][0 hi, 1 mid, 2 lo]
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) a[s_][0] = a[s_][1] = a[s_][2] = q4{0, 0, 0, 0};
     int node_n = -1;
     bool have = false;
     int tile_n = UNI(L.st4[0].y);
 #define CC_A(BASE, PLANE, S) (*reinterpret_cast<const q4*>((BASE) + (PLANE) * A_PLANE_BYTES + (sw0 ^ ((S) << 6))))
-#define CC_FIRST_READS(BUF)                                                                                  \
-    {                                                                                                        \
-      node_n = L.rowmap[(BUF) * SUBR + (lane & 15)];                                                         \
-      ah0n = CC_A(L.a_buf + (BUF) * A_STEP_BYTES + a_row, 0, 0);                                             \
-      am0n = CC_A(L.a_buf + (BUF) * A_STEP_BYTES + a_row, 1, 0);                                             \
-      al0n = CC_A(L.a_buf + (BUF) * A_STEP_BYTES + a_row, 2, 0);                                             \
+    // the three quads of slab S of ring buffer BUF into the slab's registers (whose previous contents are multiplied out)
+#define CC_READ_SLAB(BUF, S)                                                                                 \
+    if constexpr ((S) < NS) {                                                                                \
+      constexpr int S_ = (S) < NS ? (S) : 0;                                                                 \
+      const char* ab_ = L.a_buf + (BUF) * A_STEP_BYTES + a_row;                                              \
+      a[S_][0] = CC_A(ab_, 0, S_); a[S_][1] = CC_A(ab_, 1, S_); a[S_][2] = CC_A(ab_, 2, S_);                 \
     }
 #define CC_MFMA(ACC, BQ, AV) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, BQ), __builtin_bit_cast(b8, AV), ACC, 0, 0, 0);
     // slab S: its six products, every fragment quad re-requested behind its last use when the step reloads
@@ -883,24 +888,25 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
     if constexpr ((S) < NS) {                                                                                \
       constexpr int S_ = (S) < NS ? (S) : 0;                                                                 \
       CC_QUAD_LANDED(3 * S_, (RELOAD) ? NQ - 1 : NQ - 1 - 3 * S_)                                            \
-      CC_MFMA(accs0, B[3 * S_], ah[S_ & 1])                                                                  \
+      CC_MFMA(accs0, B[3 * S_], a[S_][0])                                                                    \
       if (RELOAD) CC_LOAD_QUAD(3 * S_, offs_)                                                                \
       CC_QUAD_LANDED(3 * S_ + 1, (RELOAD) ? NQ - 1 : NQ - 2 - 3 * S_)                                        \
-      CC_MFMA(accs1, B[3 * S_ + 1], am[S_ & 1])                                                              \
-      CC_MFMA(accs0, B[3 * S_ + 1], ah[S_ & 1])                                                              \
+      CC_MFMA(accs1, B[3 * S_ + 1], a[S_][1])                                                                \
+      CC_MFMA(accs0, B[3 * S_ + 1], a[S_][0])                                                                \
       if (RELOAD) CC_LOAD_QUAD(3 * S_ + 1, offs_)                                                            \
       CC_QUAD_LANDED(3 * S_ + 2, (RELOAD) ? NQ - 1 : NQ - 3 - 3 * S_)                                        \
-      CC_MFMA(accs1, B[3 * S_ + 2], am[S_ & 1])                                                              \
-      CC_MFMA(accs0, B[3 * S_ + 2], al[S_ & 1])                                                              \
-      CC_MFMA(accb, B[3 * S_ + 2], ah[S_ & 1])                                                               \
+      CC_MFMA(accs1, B[3 * S_ + 2], a[S_][1])                                                                \
+      CC_MFMA(accs0, B[3 * S_ + 2], a[S_][2])                                                                \
+      CC_MFMA(accb, B[3 * S_ + 2], a[S_][0])                                                                 \
       if (RELOAD) CC_LOAD_QUAD(3 * S_ + 2, offs_)                                                            \
     }
-    // the three quads of slab S into register set S & 1 (slab S - 2's products are issued)
-#define CC_READ_SLAB(S)                                                                                      \
-    if constexpr ((S) < NS) {                                                                                \
-      constexpr int S_ = (S) < NS ? (S) : 0;                                                                 \
-      ah[S_ & 1] = CC_A(a_base, 0, S_); am[S_ & 1] = CC_A(a_base, 1, S_); al[S_ & 1] = CC_A(a_base, 2, S_);  \
-    }
+    // SOFTWARE PIPELINE ACROSS STEPS (round 4). In-kernel stamps and a producers-off build of the first bf16 version: a
+    // consumer wave took ~2100 cycles per step for 384 cycles of its own MFMAs -- an LDS read takes 300-400 cycles with 16
+    // waves on the array, and with each slab's quads requested one slab (96 MFMA cycles) ahead every slab waited out the
+    // difference. Now the quads of the NEXT step are requested from inside this one, into the registers this step has just
+    // multiplied out: slabs 0-1 behind slab 1's products, slabs 2-3 behind slab 3's -- when the next step's buffer is
+    // already full at that point (the normal case with the producers ahead); otherwise at the next step's start, all
+    // twelve at once. One set of 48 registers holds "the step about to run".
 #define CC_STEP(IDX, RELOAD, NEXT_CELL)                                                                      \
     {                                                                                                        \
       const int q_ = qbase + (IDX), b = q_ % NBUF, use = q_ / NBUF;                                          \
@@ -911,7 +917,10 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
       if (!have) {                                     /* not prefetched: the step was not full yet */     \
         DBG_T(c0_) CC_WAIT(L.full[b], >= use + 1);                                                           \
         DBG_ACC(true, dbg[0], c0_)                                                                           \
-        if (has_cols) CC_FIRST_READS(b)                                                                      \
+        if (has_cols) {                                                                                      \
+          node_n = L.rowmap[b * SUBR + (lane & 15)];                                                         \
+          CC_READ_SLAB(b, 0) CC_READ_SLAB(b, 1) CC_READ_SLAB(b, 2) CC_READ_SLAB(b, 3)                        \
+        }                                                                                                    \
       }                                                                                                      \
       DBG_T(w0_)                                                                                             \
       /* control reads for step IDX + 1, issued now, used half a burst later */                             \
@@ -920,40 +929,36 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
       const int flag_v_ = __hip_atomic_load(&L.full[bn_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   \
       if (has_cols) {                                                                                        \
         f4v accs0 = {0.f, 0.f, 0.f, 0.f}, accs1 = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};         \
-        const char* a_base = L.a_buf + b * A_STEP_BYTES + a_row;                                             \
         const int node = node_n;                                                                             \
-        q4 ah[2], am[2], al[2];                        /* two slabs: one multiplying, one arriving */       \
-        ah[0] = ah0n; am[0] = am0n; al[0] = al0n;                                                            \
         CC_QUAD_OFFSETS(offs_, NEXT_CELL)                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        CC_READ_SLAB(1)                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
         CC_SLAB(0, RELOAD)                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        CC_READ_SLAB(2)                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
         CC_SLAB(1, RELOAD)                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        CC_READ_SLAB(3)                                                                                      \
-        /* mid-burst: is step IDX + 1 already full? then its row map and the quads of its first slab come now */ \
+        /* mid-burst: is step IDX + 1 already full? then its row map entry and the quads of its slabs 0-1 come now */ \
         tile_n = UNI(tile_v_);                                                                               \
         have = (IDX) + 1 < npass && UNI(flag_v_) >= qn_ / NBUF + 1;                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        CC_SLAB(2, RELOAD)                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
         if (have) {                                                                                          \
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");                                    \
-          CC_FIRST_READS(bn_)                                                                                \
+          node_n = L.rowmap[bn_ * SUBR + (lane & 15)];                                                       \
+          CC_READ_SLAB(bn_, 0) CC_READ_SLAB(bn_, 1)                                                          \
         }                                                                                                    \
         /* the node's accumulator quad (padding rows: row 0, discarded; in program order behind the previous   \
            step's write of this wave) */                                                                     \
         f4* o = reinterpret_cast<f4*>(L.out_acc + max(node, 0) * LDO + o_lane);                              \
         const f4 old = *o;                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
+        CC_SLAB(2, RELOAD)                                                                                   \
         CC_SLAB(3, RELOAD)                                                                                   \
-        /* the buffer can go back to its producer: A and the row map are in registers */                    \
-        CC_RELEASE_FENCE();                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        /* Buffer b goes back to its producer: its quads and row map entry are in registers (the reads were waited for  \
+           by the MFMAs). No s_waitcnt here: the LDS executes a wave's instructions in order, so the flag store lands      \
+           behind every earlier read of this wave -- the fence is for the compiler only (a release fence proper would     \
+           also wait out the reads just issued for the next step). */                                       \
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                             \
         if (lane == 0) __hip_atomic_store(&L.done[b * CC_CONSUMERS + cw], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                             \
+        if (have) { CC_READ_SLAB(bn_, 2) CC_READ_SLAB(bn_, 3) }                                              \
         if (node >= 0)                                                                                       \
           *o = f4{old[0] + ((accs0[0] + accs1[0]) + accb[0]), old[1] + ((accs0[1] + accs1[1]) + accb[1]),    \
                   old[2] + ((accs0[2] + accs1[2]) + accb[2]), old[3] + ((accs0[3] + accs1[3]) + accb[3])};   \
@@ -995,7 +1000,6 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
 #undef CC_READ_SLAB
 #undef CC_SLAB
 #undef CC_MFMA
-#undef CC_FIRST_READS
 #undef CC_A
     qbase += npass;
   }

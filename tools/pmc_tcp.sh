@@ -26,7 +26,7 @@ for f in glob.glob(f"{root}/{prefix}_*/**/*counter_collection.csv", recursive=Tr
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if kern in k:
-            tag = "KG8" if "ILi8E" in k else ("KG2" if "ILi2E" in k else "k")
+            tag = "NS4" if "ILi4E" in k else "k"
             out[tag][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {t: {c: sum(v) / len(v) for c, v in d.items()} for t, d in out.items()}
 res["_launches"] = {t: max(len(v) for v in d.values()) for t, d in out.items()}
