@@ -31,6 +31,7 @@ extern "C" {
 
 #define NBD_SRC_PAD 64      /* packed source arrays are padded to a multiple of this          */
 #define NBD_CC_TILE 128     /* nodes per tile of the fused ContinuousConv kernels             */
+#define NBD_CC_GROUPS 8     /* cell groups of the fused ContinuousConv kernel (one per XCD)     */
 #define NBD_CC_MAX_RES 4    /* filter resolutions per nbd_contconv_pairs_batch_f32 call       */
 
 typedef void* nbd_stream_t;

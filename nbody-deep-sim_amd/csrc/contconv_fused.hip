@@ -54,6 +54,7 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int status() { hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : (int)e; }
 
 constexpr int TN = NBD_CC_TILE;      // nodes per tile (128)
+constexpr int CC_GRID = 256;         // persistent workgroups of the fused kernel (one per CU of an MI355X)
 constexpr int MAXC = 160;            // filter cells kept (reachable) supported: D = 6 at R = 1 has exactly 160; the pair
                                      // kernel's LDS tables (7 bytes per (node, cell) + scan scratch) fill the 160 KiB at that
 constexpr int SUBR = 16;             // packed rows per step of the fused kernel (one 16 x 16 MFMA tile of rows)
@@ -151,6 +152,8 @@ struct PairJob {
   int4* steps;          // per tile (at step_base): {first row, cell | rows << 8 | steps left in the cell << 16, first pair, 0}
   int* tile_nsteps;     // [tiles]
   float* inv_deg;       // [n] 1 / max(in-degree, 1): the row scale of a mean aggregation, a by-product (saves a launch)
+  int2* cellstep;       // [tiles][n_cells + 1] {first step of the cell in the tile's list, running cost in front of it}: what the plan
+                        // kernel cuts the cells into groups with ([n_cells]: {steps, cost} of the whole tile)
   int* tile_cost;       // [tiles] sum of the tile's step costs (each step: max(CC_COST_MIN, its pairs)); the running
                         // (inclusive) sum inside the tile is the step records' .w
 };
@@ -313,6 +316,14 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
     }
     if (tid == 0) job.tile_cost[tile] = carry;
   }
+  // ---- B5: where every cell's steps begin in the tile's list and the running cost in front of them
+  {
+    int2* cs = job.cellstep + (size_t)tile * (n_cells + 1);
+    for (int k = tid; k <= n_cells; k += PAIR_THREADS) {
+      const int sb = k < n_cells ? cell_stepbase[k] : s_tile_steps;      // (an empty cell: where the next one begins)
+      cs[k] = s_over ? make_int2(0, 0) : make_int2(sb, sb > 0 ? t_steps[sb - 1].w : 0);
+    }
+  }
 
   PT(5)
   // ---- C: place the pairs (counters count down: slot = old - 1). A half-wave takes the next node from the
@@ -367,53 +378,98 @@ __global__ __launch_bounds__(PAIR_THREADS) void contconv_pairs_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------- plan
-// Once per pair list (one workgroup per job, right behind the pair kernel): tile_base[t] = first step of tile t in the
-// global step sequence, cuts[w] = first step of persistent workgroup w's range -- the sequence cut where the running cost
-// crosses w / G of its total: cut(w) = first step whose cost-before is >= B_w = C w / G. Every w is one thread: two
-// binary searches (tile by cost prefix, step by the running cost inside the tile).
-struct PlanJob { const int* tile_nsteps; const int* tile_cost; const int4* steps; const int* rowptr; int n_cells; int* cuts; int* tile_base; int* cost_base; };
+// Once per pair list (one workgroup per job, right behind the pair kernel). The filter cells are cut into `groups`
+// contiguous GROUPS of equal cost (over all tiles), one per XCD of an MI355X: persistent workgroup w of the fused kernel
+// works on group w mod groups -- workgroup w runs on XCD w mod 8 -- so the 32 workgroups that share an XCD's 4 MiB L2
+// re-read the fragments of the same ~20 cells (1.9 MB at D = 6) all launch long instead of sweeping all 160 (15.7 MB,
+// past the L2: in-kernel stamps of round 4 put a cell change at 1.2 us, an Infinity-Cache round trip that the one-step
+// reach of the in-place reload cannot cover). A group's step sequence = tile-major, the tile's steps of the group's
+// cells (contiguous in the tile's list); it is cut into CC_GRID / groups ranges of equal cost:
+//   gcell[g]                  first cell of group g ([groups] = n_cells)
+//   tile_base[g][t]           first step of tile t in group g's sequence ([tiles]: its length), cost_base likewise
+//   cuts[g][j]                first step (in group g's sequence) of the group's j-th workgroup
+// cut(j) = first step whose cost-before is >= C_g j / W. Every cut is one thread: two binary searches (tile by cost
+// prefix, step by the running cost inside the tile).
+struct PlanJob { const int* tile_nsteps; const int2* cellstep; const int4* steps; const int* rowptr; int n_cells, groups;
+                 int* cuts; int* tile_base; int* cost_base; int* gcell; };
 struct PlanJobs { PlanJob j[NBD_CC_MAX_RES]; };
-__global__ __launch_bounds__(1024) void contconv_plan_kernel(const PlanJobs jobs, int n_tiles, int G) {
+__global__ __launch_bounds__(1024) void contconv_plan_kernel(const PlanJobs jobs, int n_tiles) {
   const PlanJob& J = jobs.j[blockIdx.x];
+  const int K = J.n_cells, G = J.groups, W = CC_GRID / G;
+  __shared__ long long ccost[MAXC];
+  __shared__ int s_gc[NBD_CC_GROUPS + 1];
   __shared__ int red[2][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int scarry = 0, ccarry = 0;
-  for (int c0 = 0; c0 < n_tiles; c0 += 1024) {
-    const int t = c0 + tid;
-    const int vs = t < n_tiles ? max(J.tile_nsteps[t], 0) : 0;      // -1: a tile the pair kernel refused
-    const int vc = (t < n_tiles && J.tile_nsteps[t] > 0) ? J.tile_cost[t] : 0;
-    const int is = wave_incl_scan(vs, lane), ic = wave_incl_scan(vc, lane);
-    __syncthreads();
-    if (lane == 63) { red[0][wave] = is; red[1][wave] = ic; }
-    __syncthreads();
-    int os = 0, oc = 0, ts = 0, tc = 0;
-    for (int i = 0; i < 16; ++i) { const int x = red[0][i], y = red[1][i]; os += i < wave ? x : 0; oc += i < wave ? y : 0; ts += x; tc += y; }
-    if (t < n_tiles) { J.tile_base[t] = scarry + os + is - vs; J.cost_base[t] = ccarry + oc + ic - vc; }
-    scarry += ts; ccarry += tc;
+  const int2* cs = J.cellstep;
+  for (int k = tid; k < K; k += 1024) {
+    long long c = 0;
+    for (int t = 0; t < n_tiles; ++t)
+      if (J.tile_nsteps[t] > 0) c += cs[(size_t)t * (K + 1) + k + 1].y - cs[(size_t)t * (K + 1) + k].y;
+    ccost[k] = c;
   }
-  if (tid == 0) { J.tile_base[n_tiles] = scarry; J.cost_base[n_tiles] = ccarry; }
-  __threadfence_block();
   __syncthreads();
-  const int T = scarry;
-  const long long Ctot = ccarry;
-  for (int w = tid; w <= G; w += 1024) {
-    int cut;
-    if (w == 0 || Ctot == 0) cut = w == G ? T : 0;
-    else if (w >= G) cut = T;
-    else {
-      const int B = (int)(Ctot * w / G);
-      int lo = 0, hi = n_tiles - 1;                          // smallest t with cost_base[t + 1] > B
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (J.cost_base[mid + 1] > B) hi = mid; else lo = mid + 1; }
-      const int t = lo, rel = B - J.cost_base[t], sb = J.tile_base[t], ns = J.tile_base[t + 1] - sb;
-      if (rel == 0) cut = sb;
-      else {
-        const int4* ts_ = J.steps + step_base(t, J.rowptr[t * TN], J.n_cells);
-        int a = 0, b = ns;                                   // steps i with running cost ts_[i].w < rel (.w increases)
-        while (a < b) { const int mid = (a + b) >> 1; if (ts_[mid].w < rel) a = mid + 1; else b = mid; }
-        cut = sb + min(1 + a, ns);
-      }
+  if (tid == 0) {                                            // K <= 160: a serial prefix
+    long long tot = 0;
+    for (int k = 0; k < K; ++k) tot += ccost[k];
+    long long cum = 0;                                       // cost in front of cell k
+    int g = 1;
+    s_gc[0] = 0;
+    for (int k = 0; k <= K && g < G; ++k) {                  // gcell[g] = first cell whose cost-before reaches tot g / G
+      while (g < G && cum >= tot * g / G) s_gc[g++] = k;
+      if (k < K) cum += ccost[k];
     }
-    J.cuts[w] = cut;
+    while (g < G) s_gc[g++] = K;
+    s_gc[G] = K;
+    for (int i = 0; i <= G; ++i) J.gcell[i] = s_gc[i];
+  }
+  __syncthreads();
+  for (int g = 0; g < G; ++g) {
+    const int c0 = s_gc[g], c1 = s_gc[g + 1];
+    int* tb = J.tile_base + (size_t)g * (n_tiles + 1);
+    int* cb = J.cost_base + (size_t)g * (n_tiles + 1);
+    int scarry = 0, ccarry = 0;
+    for (int t0 = 0; t0 < n_tiles; t0 += 1024) {
+      const int t = t0 + tid;
+      int vs = 0, vc = 0;
+      if (t < n_tiles && J.tile_nsteps[t] > 0) {             // -1: a tile the pair kernel refused
+        const int2 a = cs[(size_t)t * (K + 1) + c0], b = cs[(size_t)t * (K + 1) + c1];
+        vs = b.x - a.x; vc = b.y - a.y;
+      }
+      const int is = wave_incl_scan(vs, lane), ic = wave_incl_scan(vc, lane);
+      __syncthreads();
+      if (lane == 63) { red[0][wave] = is; red[1][wave] = ic; }
+      __syncthreads();
+      int os = 0, oc = 0, ts = 0, tc = 0;
+      for (int i = 0; i < 16; ++i) { const int x = red[0][i], y = red[1][i]; os += i < wave ? x : 0; oc += i < wave ? y : 0; ts += x; tc += y; }
+      if (t < n_tiles) { tb[t] = scarry + os + is - vs; cb[t] = ccarry + oc + ic - vc; }
+      scarry += ts; ccarry += tc;
+    }
+    if (tid == 0) { tb[n_tiles] = scarry; cb[n_tiles] = ccarry; }
+    __threadfence_block();
+    __syncthreads();
+    const int T = scarry;
+    const long long Ctot = ccarry;
+    for (int w = tid; w <= W; w += 1024) {
+      int cut;
+      if (w == 0 || Ctot == 0) cut = w == W ? T : 0;
+      else if (w >= W) cut = T;
+      else {
+        const int B = (int)(Ctot * w / W);
+        int lo = 0, hi = n_tiles - 1;                        // smallest t with cost_base[t + 1] > B
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cb[mid + 1] > B) hi = mid; else lo = mid + 1; }
+        const int t = lo, rel = B - cb[t], sb = tb[t], ns = tb[t + 1] - sb;
+        if (rel == 0) cut = sb;
+        else {
+          const int2 first = cs[(size_t)t * (K + 1) + c0];   // the group's first step in tile t and the cost in front of it
+          const int4* ts_ = J.steps + step_base(t, J.rowptr[t * TN], K) + first.x;
+          int a = 0, b = ns;                                 // steps i with running cost (inside the group) < rel (.w increases)
+          while (a < b) { const int mid = (a + b) >> 1; if (ts_[mid].w - first.y < rel) a = mid + 1; else b = mid; }
+          cut = sb + min(1 + a, ns);
+        }
+      }
+      J.cuts[g * (W + 1) + w] = cut;
+    }
+    __syncthreads();
   }
 }
 
@@ -455,7 +511,6 @@ constexpr int CC_CONSUMERS = 8;                  // consumer waves (16 output co
 constexpr int CC_THREADS = (CC_CONSUMERS + NPROD) * 64;
 constexpr int LDO = 132;                         // accumulator row stride (floats): spreads the rows of a 128-bit scatter over the banks
 constexpr int CC_CAP = 256;                      // step records held in LDS at a time (a multiple of NPROD)
-constexpr int CC_GRID = 256;                     // persistent workgroups (one per CU of an MI355X)
 constexpr int PB = 8;                            // gathered rows per batch
 constexpr int NBF = 4;                           // batches of PB gathered rows in flight per producer wave
 // A step in LDS: three planes (hi, mid, lo) of 16 rows x 128 bf16 = 256 B per row, no padding: the 16-byte chunk c of row
@@ -506,9 +561,17 @@ __device__ __forceinline__ void split_bf16x3(f2 v, unsigned& hi, unsigned& mid, 
 __device__ long long* g_cc_trace = nullptr;
 #define DBG_T(x) const long long x = __builtin_amdgcn_s_memrealtime();
 #define DBG_ACC(cond, v, x) if (cond) v += __builtin_amdgcn_s_memrealtime() - x;
+// per-step timeline of ONE workgroup (g_cc_tl_wg): [wave][step of the range][4] stamps -- consumers: step entered, buffer full,
+// step done; producers: step begun, buffer asked for, buffer got, step published (tools/contconv_timeline.py)
+__device__ long long* g_cc_tl = nullptr;
+__device__ int g_cc_tl_wg = -1;
+constexpr int CC_TL_STEPS = 512;
+#define DBG_TL(WAVE, STEP, K) if (g_cc_tl && (int)blockIdx.x == g_cc_tl_wg && (tid & 63) == 0 && (STEP) < CC_TL_STEPS) \
+    g_cc_tl[(((size_t)(WAVE) * CC_TL_STEPS + (STEP)) << 2) + (K)] = __builtin_amdgcn_s_memrealtime();
 #else
 #define DBG_T(x)
 #define DBG_ACC(cond, v, x)
+#define DBG_TL(WAVE, STEP, K)
 #endif
 
 // LDS / memory loads are "divergent" to the compiler even at wave-uniform addresses: values that steer control flow
@@ -520,8 +583,9 @@ __device__ __forceinline__ int2 uni2(int2 v) { return make_int2(UNI(v.x), UNI(v.
 struct CCArgs {
   const float* feat; int ldf, I; const int* rowptr; int n, n_tiles;
   const int2* rows; const int2* pair; const int4* steps; const int* tile_nsteps; const int* tile_cost;
-  const int* cuts;     // [CC_GRID + 1] first step of every workgroup's range ...
-  const int* tile_base;   // ... and [tiles + 1] first step of every tile: the plan, computed once per pair list (contconv_plan_kernel)
+  // the plan, computed once per pair list (contconv_plan_kernel): cell groups, and per group the first step of every
+  // workgroup's range ([groups][CC_GRID / groups + 1]) and of every tile ([groups][tiles + 1]) in the group's sequence
+  const int* cuts; const int* tile_base; const int* gcell; const int2* cellstep; int groups;
   const uint4* filt; int n_cells, colblocks, OP; float* partial;
 };
 
@@ -557,12 +621,14 @@ static_assert(NBUF <= 8, "full[] has eight words");
 // The step records of [p0, p1) of the global sequence -> LDS (all 1024 threads; both roles call it at the same
 // points, so the barriers match). The ring is idle here (first pass: untouched; later passes: every wave has left
 // the previous pass), so the segment list may borrow its first buffer.
-__device__ __forceinline__ void cc_load_table(const CCArgs& A, const CCLds& L, int p0, int p1, int tid) {
+__device__ __forceinline__ void cc_load_table(const CCArgs& A, const CCLds& L, int grp, int p0, int p1, int tid) {
+  const int* tbase = A.tile_base + (size_t)grp * (A.n_tiles + 1);
+  const int gc0 = UNI(A.gcell[grp]);                              // the group's first cell
   __syncthreads();
   if (tid == 0) *L.s_nseg = 0;
   __syncthreads();
   for (int t = tid; t < A.n_tiles; t += CC_THREADS) {
-    const int base = A.tile_base[t], v = A.tile_base[t + 1] - base;
+    const int base = tbase[t], v = tbase[t + 1] - base;
     if (v > 0 && base < p1 && base + v > p0) {
       const int s = atomicAdd(L.s_nseg, 1);                        // order-free: every segment is copied whole
       L.seg[s] = t; L.seg[CC_CAP + s] = base; L.seg[2 * CC_CAP + s] = v;
@@ -573,7 +639,7 @@ __device__ __forceinline__ void cc_load_table(const CCArgs& A, const CCLds& L, i
   for (int s = 0; s < nseg; ++s) {
     const int t = UNI(L.seg[s]), base = UNI(L.seg[CC_CAP + s]), cnt = UNI(L.seg[2 * CC_CAP + s]);
     const int e_t = UNI(A.rowptr[t * TN]);
-    const int4* ts = A.steps + step_base(t, e_t, A.n_cells);
+    const int4* ts = A.steps + step_base(t, e_t, A.n_cells) + UNI(A.cellstep[(size_t)t * (A.n_cells + 1) + gc0].x);   // the group's steps of the tile
     const int j_lo = max(p0 - base, 0), j_hi = min(p1 - base, cnt);
     for (int j = j_lo + tid; j < j_hi; j += CC_THREADS) {
       const int4 r = ts[j];
@@ -591,7 +657,7 @@ __device__ __forceinline__ void cc_load_table(const CCArgs& A, const CCLds& L, i
 // step: the records of 64 pairs are fetched by ONE coalesced vector load (the first 64 of a step already while the
 // wave's previous step was summed) and parked in wave-private LDS. A finished row (fp32 sums of columns 2 lane, 2 lane + 1
 // in the lane) is split into its three bf16 terms and stored as three dwords.
-__device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int g0, int g1, int tid, long long* dbg) {
+__device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int grp, int g0, int g1, int tid, long long* dbg) {
   const int lane = tid & 63, p = UNI(tid >> 6) - CC_CONSUMERS;     // the wave index in an SGPR: `p`-dependent branches are scalar
   __builtin_amdgcn_s_setprio(CC_PRODUCER_PRIO);
   int2* my_scr = L.scratch + p * 128;
@@ -622,7 +688,7 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
   for (int p0 = g0; p0 < g1; p0 += CC_CAP) {
     const int p1 = min(g1, p0 + CC_CAP), npass = p1 - p0;
     DBG_T(t0_)
-    cc_load_table(A, L, p0, p1, tid);
+    cc_load_table(A, L, grp, p0, p1, tid);
     DBG_ACC(true, dbg[2], t0_)
     Pre nx = {make_int2(0, 0), 0, 0, 0.f, 0.f};
     if (p < npass) fetch(p, nx);
@@ -630,6 +696,7 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
       const int q = qbase + i, b = q % NBUF, use = q / NBUF;
       char* a_dst = L.a_buf + b * A_STEP_BYTES;
       DBG_T(s0_)
+      DBG_TL(CC_CONSUMERS + p, q, 0)
       const int4 r = uni4(L.st4[i]);
       const int2 pr = uni2(L.st2[i]);
       const int cnt = (r.x >> 8) & 31, pb = pr.x, np = pr.y - pr.x;
@@ -645,8 +712,10 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
       auto claim = [&]() {
         if (!claimed) {
           DBG_T(c0_)
+          DBG_TL(CC_CONSUMERS + p, q, 1)
           if (use > 0) CC_WAIT_ALL_DONE(L.done + b * CC_CONSUMERS, use);   // the consumers are done with this buffer
           DBG_ACC(true, dbg[0], c0_)
+          DBG_TL(CC_CONSUMERS + p, q, 2)
           if (lane < SUBR) L.rowmap[b * SUBR + lane] = lane < cnt ? rinfo.x : -1;   // padding rows: no node
           claimed = true;
         }
@@ -763,6 +832,7 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
       store_row();
       CC_RELEASE_FENCE();
       if (lane == 0) __hip_atomic_store(&L.full[b], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      DBG_TL(CC_CONSUMERS + p, q, 3)
       DBG_ACC(true, dbg[1], s0_)
     }
     qbase += npass;
@@ -803,7 +873,7 @@ __device__ __forceinline__ void cc_producer(const CCArgs& A, const CCLds& L, int
 // slab 0 already in the middle of the previous step, when that step's flag showed the buffer full), slab 3 when slab 0's
 // products are issued -- 36 VGPRs instead of 48.
 template <int NS>
-__device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int g0, int g1, int tid, long long* dbg) {
+__device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int grp, int slot0, int g0, int g1, int tid, long long* dbg) {
   const int lane = tid & 63, cw = UNI(tid >> 6);
   if (cw < CC_CONSUMERS / 2) __builtin_amdgcn_s_setprio(CC_PRIO_HI);
   else __builtin_amdgcn_s_setprio(CC_PRIO_LO);
@@ -815,7 +885,7 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
     int ln = lane;
     asm volatile("" : "+v"(ln));     // opaque: keeps hipcc from hoisting this rare path's per-lane addresses out of the step
                                      // loops, where they cost VGPRs the step body needs
-    float* dst = A.partial + ((size_t)(blockIdx.x + tile) * TN) * A.OP + (size_t)blockIdx.z * 128 + cw * 16 + (ln & 3) * 4;
+    float* dst = A.partial + ((size_t)(slot0 + tile) * TN) * A.OP + (size_t)blockIdx.z * 128 + cw * 16 + (ln & 3) * 4;
     float* src = L.out_acc + cw * 16 + (ln & 3) * 4;
 #pragma unroll 4
     for (int r0 = 0; r0 < TN; r0 += 16) {
@@ -866,7 +936,7 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
   int qbase = 0;
   for (int p0 = g0; p0 < g1; p0 += CC_CAP) {
     const int p1 = min(g1, p0 + CC_CAP), npass = p1 - p0;
-    cc_load_table(A, L, p0, p1, tid);
+    cc_load_table(A, L, grp, p0, p1, tid);
     // pipeline registers: the A quads and the row map entry of the step about to run (valid when `have`), that step's tile
     q4 a[NS][3];                                       // [slab][0 hi, 1 mid, 2 lo]
 #pragma unroll
@@ -914,6 +984,7 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
         if (cur_tile >= 0 && has_cols) flush_acc(cur_tile);                                                  \
         cur_tile = tile_n;                                                                                   \
       }                                                                                                      \
+      DBG_TL(cw, q_, 0)                                                                                      \
       if (!have) {                                     /* not prefetched: the step was not full yet */     \
         DBG_T(c0_) CC_WAIT(L.full[b], >= use + 1);                                                           \
         DBG_ACC(true, dbg[0], c0_)                                                                           \
@@ -922,7 +993,7 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
           CC_READ_SLAB(b, 0) CC_READ_SLAB(b, 1) CC_READ_SLAB(b, 2) CC_READ_SLAB(b, 3)                        \
         }                                                                                                    \
       }                                                                                                      \
-      DBG_T(w0_)                                                                                             \
+      DBG_T(w0_) DBG_TL(cw, q_, 1)                                                                           \
       /* control reads for step IDX + 1, issued now, used half a burst later */                             \
       const int nidx_ = min((IDX) + 1, npass - 1), qn_ = q_ + 1, bn_ = qn_ % NBUF;                           \
       const int tile_v_ = L.st4[nidx_].y;                                                                    \
@@ -967,7 +1038,7 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
         have = false;                                                                                        \
         if (lane == 0) __hip_atomic_store(&L.done[b * CC_CONSUMERS + cw], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
       }                                                                                                      \
-      DBG_ACC(true, dbg[1], w0_)                                                                             \
+      DBG_ACC(true, dbg[1], w0_) DBG_TL(cw, q_, 2)                                                           \
     }
     // meta = cell | rows << 8 | steps left in the cell << 16. A cell's steps but the last run in a loop that requests
     // nothing; the last one requests the next cell's fragment (a pass's last step: its own cell's again -- the next pass
@@ -1030,13 +1101,16 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
   // are dense. The cuts are part of the pair lists (contconv_plan_kernel, once per graph and resolution).
   if (tid < 8) L.full[tid] = 0;
   if (tid < NBUF * CC_CONSUMERS) L.done[tid] = 0;
-  const int g0 = UNI(A.cuts[blockIdx.x]), g1 = UNI(A.cuts[blockIdx.x + 1]);
+  // workgroup w = blockIdx.x runs on XCD w mod 8: it takes group w mod groups, and is the group's (w / groups)-th
+  const int grp = blockIdx.x % A.groups, wig = blockIdx.x / A.groups, wpg = CC_GRID / A.groups;
+  const int g0 = UNI(A.cuts[grp * (wpg + 1) + wig]), g1 = UNI(A.cuts[grp * (wpg + 1) + wig + 1]);
   if (g0 >= g1) return;                                            // uniform: the whole workgroup leaves
+  const int slot0 = grp * (wpg + A.n_tiles) + wig;                 // partial slot of (this workgroup, tile t) = slot0 + t
   for (int i = tid; i < TN * LDO / 4; i += CC_THREADS) reinterpret_cast<f4*>(L.out_acc)[i] = f4{0.f, 0.f, 0.f, 0.f};
   // (the first cc_load_table's barriers order the zeroing before any consumer's first scatter)
   DBG_T(r0_)
-  if (wave >= CC_CONSUMERS) cc_producer(A, L, g0, g1, tid, dbg_wait);
-  else cc_consumer<NS>(A, L, g0, g1, tid, dbg_wait);
+  if (wave >= CC_CONSUMERS) cc_producer(A, L, grp, g0, g1, tid, dbg_wait);
+  else cc_consumer<NS>(A, L, grp, slot0, g0, g1, tid, dbg_wait);
   DBG_ACC(true, dbg_wait[3], r0_)
 #ifdef NBD_CC_TRACE
   if (lane == 0) { for (int i = 0; i < 4; ++i) s_dbg[wave][i] = dbg_wait[i]; }
@@ -1052,34 +1126,44 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
 #endif
 }
 
-// out = act(scale * sum of the tile's partial slots), in workgroup order. grid (tiles, 4): 32 rows of a tile each
-// (graphs of < 64 tiles: (tiles, 16), 8 rows each -- a 2 000-node training batch spreads every tile over ~16 workgroups'
+// out = act(scale * sum of the tile's partial slots), in (group, workgroup) order. grid (tiles, 4): 32 rows of a tile each
+// (graphs of < 64 tiles: (tiles, 16), 8 rows each -- a 2 000-node training batch spreads every tile over many workgroups'
 // slots, and 64 blocks walking them serially took 40 us).
-// cuts[w] = first step of workgroup w's range (written by the fused kernel): the workgroups whose ranges meet the
-// tile's steps [base, base + cnt) are the ones that wrote a slot for it.
+// The workgroups whose ranges meet the tile's steps of a group, [tile_base[g][t], tile_base[g][t + 1]), are the ones that
+// wrote a slot for it: slot(group g, its j-th workgroup, tile t) = g (W + tiles) + j + t -- a merge-path numbering inside
+// every group, unique and independent of timing.
 __global__ __launch_bounds__(256) void contconv_stream_finish_kernel(
     const float* __restrict__ partial, const int* __restrict__ tile_nsteps, const int* __restrict__ cuts,
-    const int* __restrict__ tile_base, int n_tiles,
-    int G, const float* __restrict__ rowscale, int act, float* __restrict__ out, int ldo, int n, int O, int OP) {
-  __shared__ int s_cut[CC_GRID + 1];
+    const int* __restrict__ tile_base, int n_tiles, int groups,
+    const float* __restrict__ rowscale, int act, float* __restrict__ out, int ldo, int n, int O, int OP) {
+  __shared__ int s_cut[CC_GRID + NBD_CC_GROUPS];
+  __shared__ int s_slot[CC_GRID];
+  __shared__ int s_ns;
   const int tid = threadIdx.x, tile = blockIdx.x;
-  for (int w = tid; w <= G; w += 256) s_cut[w] = cuts[w];
+  const int W = CC_GRID / groups;
+  for (int i = tid; i < groups * (W + 1); i += 256) s_cut[i] = cuts[i];
   __syncthreads();
-  const int base = tile_base[tile];
-  const int cnt = tile_nsteps[tile];
-  int w_first = 0, w_last = -1;
-  if (cnt > 0) {
-    int a = 0, b = G - 1;                                          // largest w with cut[w] <= base
-    while (a < b) { const int m = (a + b + 1) >> 1; if (s_cut[m] <= base) a = m; else b = m - 1; }
-    w_first = a;
-    w_last = a;
-    while (w_last + 1 < G && s_cut[w_last + 1] < base + cnt) ++w_last;
+  const int cnt_all = tile_nsteps[tile];
+  if (tid == 0) {
+    int ns = 0;
+    for (int g = 0; g < groups && cnt_all > 0; ++g) {
+      const int* tb = tile_base + (size_t)g * (n_tiles + 1);
+      const int base = tb[tile], cnt = tb[tile + 1] - base;
+      if (cnt <= 0) continue;
+      const int* cut = s_cut + g * (W + 1);
+      int a = 0, b = W - 1;                                        // largest w with cut[w] <= base
+      while (a < b) { const int m = (a + b + 1) >> 1; if (cut[m] <= base) a = m; else b = m - 1; }
+      for (int w = a; w < W && cut[w] < base + cnt; ++w)
+        if (cut[w] < cut[w + 1] && cut[w + 1] > base) s_slot[ns++] = g * (W + n_tiles) + w + tile;   // an empty range wrote nothing
+    }
+    s_ns = ns;
   }
+  __syncthreads();
+  const int ns = s_ns;
   const int rb = TN / gridDim.y;                                   // rows of the tile this block finishes
   const int r0 = tile * TN + blockIdx.y * rb;
   // four output quads per thread and trip, three slots per round trip: the loads go out together (the slots were written by
-  // other XCDs a moment ago, every load is a cold round trip; one quad and one slot at a time made the kernel a chain of
-  // them: 13.9 -> 11.7 us), summed in slot order per element as before. (fast tanh instead of libm's here: no change.)
+  // other XCDs a moment ago, every load is a cold round trip), summed in slot order per element.
   constexpr int U = 4;
   const int total = rb * OP / 4;
   for (int e0 = tid; e0 < total; e0 += 256 * U) {
@@ -1093,20 +1177,20 @@ __global__ __launch_bounds__(256) void contconv_stream_finish_kernel(
       c[u] = (e - rl * (OP / 4)) * 4;
       row[u] = r0 + rl;
       ok[u] = e < total && row[u] < n && c[u] < O;
-      v[u] = cnt < 0 ? f4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")}      // refused tile
-                     : f4{0.f, 0.f, 0.f, 0.f};
+      v[u] = cnt_all < 0 ? f4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")}      // refused tile
+                         : f4{0.f, 0.f, 0.f, 0.f};
     }
-    constexpr int WB = 3;                                                      // slots per round trip (a tile rarely has more)
-    for (int w0 = w_first; w0 <= w_last; w0 += WB) {
+    constexpr int WB = 3;                                                      // slots per round trip
+    for (int i0 = 0; i0 < ns; i0 += WB) {
       f4 x[WB][U];
       bool live[WB];
 #pragma unroll
       for (int q = 0; q < WB; ++q) {
-        const int w = w0 + q;
-        live[q] = w <= w_last && s_cut[min(w, G - 1)] < s_cut[min(w, G - 1) + 1];     // an empty range wrote nothing
+        live[q] = i0 + q < ns;
+        const int slot = s_slot[min(i0 + q, ns - 1)];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          x[q][u] = ok[u] && live[q] ? *reinterpret_cast<const f4*>(partial + ((size_t)(w + tile) * TN + (row[u] - tile * TN)) * OP + c[u])
+          x[q][u] = ok[u] && live[q] ? *reinterpret_cast<const f4*>(partial + ((size_t)slot * TN + (row[u] - tile * TN)) * OP + c[u])
                                      : f4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
@@ -1490,6 +1574,11 @@ extern "C" {
 
 #ifdef NBD_CC_TRACE
 int nbd_debug_cc_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cc_trace), &buf, sizeof(buf)); }
+int nbd_debug_cc_timeline(void* buf, int workgroup) {       // buf: 16 waves x 512 steps x 4 int64
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_cc_tl), &buf, sizeof(buf));
+  if (e != hipSuccess) return (int)e;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cc_tl_wg), &workgroup, sizeof(workgroup));
+}
 #endif
 
 #ifdef NBD_PAIRS_TRACE
@@ -1502,7 +1591,12 @@ int nbd_contconv_fused_supported(int in_channels, int out_channels, int n_cells)
 }
 
 namespace {
-struct PairsLayout { size_t desc, rows, src, w, steps, nsteps, cost, scale, cuts, tbase, cbase, total; };
+struct PairsLayout { size_t desc, rows, src, w, steps, nsteps, cost, scale, cuts, tbase, cbase, gcell, cellstep, total; };
+// cell groups of a layer with n_cells kept cells (a divisor of CC_GRID): one per XCD when the fragments of all cells are
+// well past an XCD's 4 MiB L2 (12 KiB per cell and 16-column block: 15.7 MB at D = 6, 128 -> 128), else one for all -- at
+// D = 4 (64 cells, 6 MB) the groups' extra accumulator flushes (a workgroup then crosses ~5 tiles instead of 1.5) cost more
+// than the fragment's L2 misses: same box, 0.252 -> 0.276 ms, against 0.385 -> 0.367 ms at D = 6
+inline int cc_groups(int n_cells) { return n_cells >= 96 ? NBD_CC_GROUPS : 1; }
 PairsLayout pairs_layout(int n, int64_t edge_capacity, int n_cells) {
   const size_t tiles = (size_t)ceil_div(n, TN);
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -1516,9 +1610,11 @@ PairsLayout pairs_layout(int n, int64_t edge_capacity, int n_cells) {
   L.nsteps = at; at += up(tiles * sizeof(int));
   L.cost = at; at += up(tiles * sizeof(int));
   L.scale = at; at += up((size_t)n * sizeof(float));
-  L.cuts = at; at += up((CC_GRID + 1) * sizeof(int));          // the plan (contconv_plan_kernel)
-  L.tbase = at; at += up((tiles + 1) * sizeof(int));
-  L.cbase = at; at += up((tiles + 1) * sizeof(int));
+  L.cuts = at; at += up((CC_GRID + NBD_CC_GROUPS) * sizeof(int));          // the plan (contconv_plan_kernel)
+  L.tbase = at; at += up(NBD_CC_GROUPS * (tiles + 1) * sizeof(int));
+  L.cbase = at; at += up(NBD_CC_GROUPS * (tiles + 1) * sizeof(int));
+  L.gcell = at; at += up((NBD_CC_GROUPS + 1) * sizeof(int));
+  L.cellstep = at; at += up(tiles * (size_t)(n_cells + 1) * sizeof(int2));
   L.total = at + 256;
   return L;
 }
@@ -1563,9 +1659,11 @@ int nbd_contconv_pairs_jobs_f32(const float* pos, int n, float radius_sq, int n_
     j.pair = reinterpret_cast<int2*>(base + L.src);
     j.steps = reinterpret_cast<int4*>(base + L.steps); j.tile_nsteps = reinterpret_cast<int*>(base + L.nsteps);
     j.tile_cost = reinterpret_cast<int*>(base + L.cost);
+    j.cellstep = reinterpret_cast<int2*>(base + L.cellstep);
     j.inv_deg = reinterpret_cast<float*>(base + L.scale);
     PlanJob& pj = plans.j[r];
-    pj.tile_nsteps = j.tile_nsteps; pj.tile_cost = j.tile_cost; pj.steps = j.steps; pj.rowptr = q.rowptr; pj.n_cells = nc;
+    pj.tile_nsteps = j.tile_nsteps; pj.cellstep = j.cellstep; pj.steps = j.steps; pj.rowptr = q.rowptr; pj.n_cells = nc;
+    pj.groups = cc_groups(nc); pj.gcell = reinterpret_cast<int*>(base + L.gcell);
     pj.cuts = reinterpret_cast<int*>(base + L.cuts); pj.tile_base = reinterpret_cast<int*>(base + L.tbase);
     pj.cost_base = reinterpret_cast<int*>(base + L.cbase);
     const int kc = (nc + 3) & ~3;
@@ -1581,7 +1679,7 @@ int nbd_contconv_pairs_jobs_f32(const float* pos, int n, float radius_sq, int n_
   contconv_pairs_kernel<<<dim3(ceil_div(n, TN), n_jobs), PAIR_THREADS, lds, (hipStream_t)stream>>>(pos, n, radius_sq, jobs);
   int rc = status();
   if (rc) return rc;
-  contconv_plan_kernel<<<n_jobs, 1024, 0, (hipStream_t)stream>>>(plans, ceil_div(n, TN), CC_GRID);
+  contconv_plan_kernel<<<n_jobs, 1024, 0, (hipStream_t)stream>>>(plans, ceil_div(n, TN));
   return status();
 }
 
@@ -1611,12 +1709,13 @@ int nbd_contconv_pairs_f32(const float* pos, const int* rowptr, const int* centr
                                       &n_cells, lists, &pair_lists_bytes, stream);
 }
 
-// [cuts: CC_GRID + 1 ints][partial slots: (workgroup + tile) < CC_GRID + tiles, each TN rows x (column groups x 128) floats]
+// [4 KiB header, unused][partial slots: per cell group (its workgroups + tiles) = CC_GRID + groups x tiles in all, each TN
+// rows x (column groups x 128) floats]
 constexpr size_t CC_CUTS_BYTES = 4096;
 static_assert((CC_GRID + 1) * sizeof(int) <= CC_CUTS_BYTES, "cuts header");
 size_t nbd_contconv_fused_workspace_bytes(int n, int n_cells, int out_channels) {
   if (n <= 0 || n_cells <= 0 || out_channels <= 0) return 0;
-  return CC_CUTS_BYTES + (size_t)(CC_GRID + ceil_div(n, TN)) * TN * (size_t)(ceil_div(out_channels, 128) * 128) * sizeof(float);
+  return CC_CUTS_BYTES + (size_t)(CC_GRID + (size_t)cc_groups(n_cells) * ceil_div(n, TN)) * TN * (size_t)(ceil_div(out_channels, 128) * 128) * sizeof(float);
 }
 
 size_t nbd_contconv_filter_floats(int in_channels, int out_channels, int n_cells) {
@@ -1655,6 +1754,8 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
   CCArgs A;
   A.feat = feat; A.ldf = ldf; A.I = in_channels; A.rowptr = rowptr; A.n = n; A.n_tiles = tiles;
   A.rows = rows; A.pair = pair; A.steps = steps; A.tile_nsteps = tile_nsteps; A.tile_cost = tile_cost; A.cuts = cuts; A.tile_base = tile_base;
+  A.gcell = reinterpret_cast<const int*>(base + L.gcell); A.cellstep = reinterpret_cast<const int2*>(base + L.cellstep);
+  A.groups = cc_groups(n_cells);
   A.filt = reinterpret_cast<const uint4*>(filters_shuffled); A.n_cells = n_cells;
   A.colblocks = ceil_div(out_channels, 16); A.OP = OP; A.partial = partial;
 #define CC_LAUNCH(K)                                                                                                \
@@ -1668,7 +1769,7 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
 #undef CC_LAUNCH
   int rc = status();
   if (rc) return rc;
-  contconv_stream_finish_kernel<<<dim3(tiles, tiles >= 64 ? 4 : 16), 256, 0, st>>>(partial, tile_nsteps, cuts, tile_base, tiles, CC_GRID, rowscale, act, out,
+  contconv_stream_finish_kernel<<<dim3(tiles, tiles >= 64 ? 4 : 16), 256, 0, st>>>(partial, tile_nsteps, cuts, tile_base, tiles, cc_groups(n_cells), rowscale, act, out,
                                                                  ldo, n, out_channels, OP);
   return status();
 }

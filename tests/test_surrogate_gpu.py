@@ -989,6 +989,49 @@ def test_contconv_full_size_config_rows_match_oracle_and_layer_is_linear(gpu_dev
     assert 10 < ei.shape[1] / n <= 32                                  # capped at 32 per centre (uncapped mean ~32)
 
 
+@pytest.mark.parametrize("D", [6, 4])
+@pytest.mark.parametrize("spread", ["normal", "2^-20..2^20"])
+def test_contconv_bf16x3_contraction_error_is_no_larger_than_the_fp32_matrix_pipes(D, spread, gpu_device):
+    """The fused kernel multiplies on the bf16 matrix pipe with both operands split into three bf16 terms (csrc/contconv_fused.hip).
+    `dtype` stays "fp32" only if that is fp32-equivalent: on the published layer shape (N = 16 384, 128 -> 128 channels, D = 6
+    and D = 4) the row error against an exact (fp64) product must be no larger than that of the fp32 matrix instruction
+    on the same inputs -- the library's other ContinuousConv path (binned features + nbd_linear_f32, v_mfma_f32_16x16x4_f32).
+    The graph isolates the contraction: bodies farther apart than the radius, self loops only, so every node reaches the
+    eight cells around the grid centre with weight 1/8 (exact) and the exact result is feat . (sum of those filters) / 8.
+    Inputs: N(0, 1), and magnitudes 2^u, u uniform in [-20, 20], random signs."""
+    import contconv
+    n, C = 16384, 128
+    g = torch.Generator().manual_seed(1000 * D + len(spread))
+    side = 26
+    idx = torch.arange(n)
+    pos = torch.stack((idx % side, (idx // side) % side, idx // (side * side)), 1).to(torch.float32) * 3.0     # spacing 3 > radius 1
+    def draw(*shape):
+        if spread == "normal":
+            return torch.randn(*shape, generator=g)
+        mag = torch.exp2(torch.rand(*shape, generator=g) * 40.0 - 20.0)
+        return mag * (torch.randint(0, 2, shape, generator=g).to(torch.float32) * 2.0 - 1.0)
+    feat = draw(n, C)
+    layer = contconv.ContinuousConv(C, C, D, radius=1.0, agg="sum").cuda()
+    with torch.no_grad():
+        layer.filters.copy_(draw(D, D, D, C, C))
+    ei = torch.stack((idx, idx)).cuda()                                       # self loops
+    with torch.no_grad():
+        assert layer.fused_ok()
+        got = layer(pos.cuda(), feat.cuda(), edge_index=ei).cpu().double()
+        layer.use_fused = False
+        f32 = layer(pos.cuda(), feat.cuda(), edge_index=ei).cpu().double()
+    c0 = D // 2 - 1                                                            # D even: |r| = 0 sits between cells c0 and c0 + 1 on every axis
+    fsum = layer.filters.detach().cpu().double()[c0:c0 + 2, c0:c0 + 2, c0:c0 + 2].sum((0, 1, 2))
+    ref = feat.double() @ fsum / 8.0
+    scale = ref.abs().amax(1).clamp_min(1e-300)
+    err_bf = ((got - ref).abs().amax(1) / scale)
+    err_32 = ((f32 - ref).abs().amax(1) / scale)
+    assert float(err_32.max()) < 1e-5 and float(err_bf.max()) < 1e-5           # both are fp32 products at all
+    # no larger: in the worst row and on (quadratic) average over the 16 384 rows
+    assert float(err_bf.max()) <= float(err_32.max()), (float(err_bf.max()), float(err_32.max()))
+    assert float(err_bf.square().mean().sqrt()) <= float(err_32.square().mean().sqrt())
+
+
 BENCH_SCALE_16384 = 4.599349753792708      # tools/bench_surrogates.py: Plummer positions x this -> mean radius-1 degree 32
 
 
