@@ -683,6 +683,15 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
                            const float* rowscale, int act, float* out, int ldo, void* workspace,
                            size_t workspace_bytes, nbd_stream_t stream);
 
+/* ContinuousConv's public helpers (contconv.py:30-33 and 53-78), as methods of the drop-in layer:
+ * nbd_ball_to_cube_f32: out[i] = r[i] / (|r[i]| + 1e-8) * tanh |r[i]|, r and out (n, 3) row-major.
+ * nbd_trilinear_interpolate_f32: out (n, in, out) = the filters (D, D, D, in, out) blended at coords (n, 3) in grid units
+ * [0, D - 1] exactly as the reference's F.grid_sample call does it (align_corners = True, zero padding outside the grid,
+ * coordinate component 0 along the LAST filter axis). */
+int nbd_ball_to_cube_f32(const float* r, int n, float* out, nbd_stream_t stream);
+int nbd_trilinear_interpolate_f32(const float* filters, int filter_resolution, int in_channels, int out_channels,
+                                  const float* coords, int n, float* out, nbd_stream_t stream);
+
 /* scale[i] from the CSR degree d_i: mode 0 = 1/max(d,1), 1 = d, 2 = (d > 0). */
 int nbd_degree_scale_f32(const int* rowptr, int n, int mode, float* scale, nbd_stream_t stream);
 

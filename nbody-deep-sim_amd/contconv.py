@@ -44,6 +44,16 @@ class ContinuousConv(nn.Module):
         self.filters = nn.Parameter(torch.randn(filter_resolution, filter_resolution, filter_resolution,
                                                 in_channels, out_channels))            # contconv.py:20-28
 
+    def ball_to_cube(self, r):
+        """contconv.py:30-33: r / (|r| + 1e-8) * tanh |r| (inference helper: no autograd; the layer's forward does the same
+        mapping inside its kernels)."""
+        return nnops.ball_to_cube(r)
+
+    def trilinear_interpolate(self, coords):
+        """contconv.py:53-78: the (N, in, out) filters blended at coords (N, 3) in grid units [0, D - 1] (inference helper;
+        the layer's forward applies the same blend to the features instead and never forms this tensor)."""
+        return nnops.trilinear_interpolate(self.filters, coords)
+
     def cells(self):
         """(reachable cell indices int64 [K], cell -> compact index int32 [D^3], K) on the filters' device:
         only grid points within tanh(radius) (D-1)/2 (+ their adjacent unit cubes) of the grid centre can be
@@ -82,6 +92,8 @@ class ContinuousConv(nn.Module):
         return ok
 
     use_fused = True         # block-sparse fused kernels (csrc/contconv_fused.hip) where the shape allows
+    last_path = None         # which path the last forward took: "fused" (pair lists + stream kernel), "binned" (A in HBM + GEMM),
+                             # "fused_train" / "binned_train" under autograd, "extreme" (max / min / mul)
 
     def trains_fused(self) -> bool:
         """Whether the training step of this layer runs on the pair lists (forward, filter gradient, feature gradient --
@@ -111,6 +123,7 @@ class ContinuousConv(nn.Module):
                 centres = torch.zeros(1, dtype=torch.int32, device=positions.device)
         r2 = float(np.float32(self.radius ** 2))                       # contconv.py:86: python double -> fp32
         if self.agg in ("max", "min", "mul"):
+            self.last_path = "extreme"
             return self._forward_extreme(positions, features, rowptr, centres, act, out)
         if self.agg != "mean":
             scale = None
@@ -129,6 +142,7 @@ class ContinuousConv(nn.Module):
                     _, cmap, n_cells = self.cells()
                     pb, cap_e = graph.pairs(self.filter_resolution, cmap, n_cells)
                     scale = nnops.contconv_pairs_inv_degree(pb, n, cap_e, n_cells)
+                self.last_path = "fused_train"
                 return ag.ContConvFusedFn.apply(features, self.filters, graph, self.filter_resolution, scale, act,
                                                 self.cells())
             if self.agg == "mean" and scale is None:
@@ -138,6 +152,7 @@ class ContinuousConv(nn.Module):
             else:
                 rp, tg = graphops.csr_by_key(edge_index[1], edge_index[0], n)
                 bwd = dict(rowptr_s=rp, tgt_s=tg if tg.numel() else torch.zeros(1, dtype=torch.int32, device=tg.device))
+            self.last_path = "binned_train"
             return ag.ContConvFn.apply(features, self.filters, positions.contiguous(), (rowptr, centres), bwd,
                                        self.filter_resolution, r2, scale, act, self.cells())
         if self.fused_ok() and n > 0:
@@ -151,8 +166,10 @@ class ContinuousConv(nn.Module):
                 pairs = nnops.contconv_pairs(positions.contiguous(), rowptr, centres, centres.numel(),
                                              self.filter_resolution, r2, cmap, n_cells)
             wf = wt if (wt is not None and wt.dim() == 1) else self.weight_fused()
+            self.last_path = "fused"
             return nnops.contconv_fused(feats, rowptr, pairs[0], pairs[1], wf, n_cells, self.out_channels,
                                         rowscale=scale, act=act, out=out)
+        self.last_path = "binned"
         wt = self.weight_t() if (wt is None or wt.dim() == 1) else wt
         if out is None:
             out = torch.empty((n, self.out_channels), dtype=torch.float32, device=positions.device)
@@ -301,6 +318,7 @@ class ContinuousConvModel(nn.Module):
         x7 = data.x
         if not x7.is_cuda:
             raise NbdError("ContinuousConvModel.forward: data must live on the GPU (no CPU path)")
+        self._last_path = None
         w = self._cache.get(self._build_weights)
         n = x7.shape[0]
         pre = getattr(data, "_x_pos", None)        # predict() hands over [pos | mass] and pos as it built them
@@ -375,6 +393,12 @@ class ContinuousConvModel(nn.Module):
         ln = nnops.layernorm(cat_buf, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
                              self.layer_norm.eps)
         return run_chain(ln, w["head"], out_last=out)
+
+    @property
+    def last_path(self):
+        """The path every layer's last forward took (ContinuousConv.last_path), e.g. ("fused", "fused"); "one_call_train" when the
+        whole training pass ran behind nbd_cc_train_*_f32."""
+        return getattr(self, "_last_path", None) or tuple(l.last_path for l in self.contconv)
 
     @property
     def input_dim(self):
@@ -520,6 +544,7 @@ class ContinuousConvModel(nn.Module):
         lists = graphops.radius_lists(pos, self.radius, getattr(data, "batch", None), loop=self.self_loops,
                                       max_num_neighbors=self.max_num_neighbors)
         one = self._one_call_train(x, pos, lists)
+        self._last_path = "one_call_train" if one is not None else None
         if one is not None:
             return one
         enc = self._encoder_autograd(x) if isinstance(self.node_encoder, MLP) else x

@@ -561,6 +561,11 @@ int nbd_gnn_layer_f32(const nbd_gnn_layer_args* args, nbd_stream_t stream) {
   const bool adv = a.adv_vel_half || a.adv_pos || a.adv_posm || a.adv_pos_out;
   if (adv && (!a.adv_vel_half || !a.adv_pos || !a.adv_posm || !a.adv_pos_out || !a.kick_vel)) return NBD_E_BADARG;
   if (adv && (a.epilogue != NBD_GNN_FINAL_HEAD || a.ep_out != 3 || a.h != 64 || a.e > 64)) return NBD_E_UNSUPPORTED;
+  // The pre-advance epilogue overwrites adv_pos / adv_posm rows of the nodes a workgroup owns while other workgroups of the
+  // same launch still gather their neighbours' rows. That is safe only when the edge loop reads the PREVIOUS layer's
+  // tables (pq / epq): a first-layer launch (pq == NULL) gathers from x -- the very position rows a one-layer model's
+  // caller hands in as adv_posm -- and would mix step t and step t + 1 positions. Refused, whatever x aliases.
+  if (adv && !a.pq) return NBD_E_UNSUPPORTED;
   if (a.out_epq && ((a.epilogue != NBD_GNN_NEXT_PQ && a.epilogue != NBD_GNN_NEXT_PQ_FOLDED) || a.ldout_epq < a.ep_out)) return NBD_E_BADARG;
   int n_ep = 0;
   switch (a.epilogue) {

@@ -881,6 +881,53 @@ int launch_linear(const float* X, int ldx, const float* W, int ldw, const float*
 
 }  // namespace
 
+// ContinuousConv's two public helpers (contconv.py:30-33, 53-78), callable on the drop-in layer as in the reference.
+// ball_to_cube: r / (|r| + 1e-8) * tanh |r| with torch's own order of operations (norm -> divide -> multiply).
+__global__ __launch_bounds__(256) void ball_to_cube_kernel(const float* __restrict__ r, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = r[3 * i], y = r[3 * i + 1], z = r[3 * i + 2];
+  const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+  const float den = nrm + 1e-8f, th = tanhf(nrm);
+  out[3 * i] = __fmul_rn(x / den, th); out[3 * i + 1] = __fmul_rn(y / den, th); out[3 * i + 2] = __fmul_rn(z / den, th);
+}
+
+// trilinear_interpolate: F.grid_sample(filters as (1, I O, D, D, D), mode = "bilinear", align_corners = True, zero
+// padding) at coords in grid units -- coordinate component 0 indexes the LAST filter axis (filters[z][y][x]).
+// One thread per (sample, 4 consecutive (i, o) entries): the eight corners' weights from grid_sample's own arithmetic
+// (normalise to [-1, 1], un-normalise, floor, products of the three distances).
+__global__ __launch_bounds__(256) void trilinear_interpolate_kernel(const float* __restrict__ filt, int D, int io,
+                                                                    const float* __restrict__ coords, int n, float* __restrict__ out) {
+  const int q4 = (io + 3) >> 2;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)n * q4) return;
+  const int s = (int)(idx / q4), c0 = (int)(idx - (size_t)s * q4) * 4;
+  float g[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float nc = (coords[3 * s + a] / (float)(D - 1)) * 2.0f - 1.0f;     // contconv.py:62
+    g[a] = ((nc + 1.0f) / 2.0f) * (float)(D - 1);                            // grid_sampler_unnormalize, align_corners
+  }
+  const float fx = floorf(g[0]), fy = floorf(g[1]), fz = floorf(g[2]);
+  const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+  const float tx = g[0] - fx, ty = g[1] - fy, tz = g[2] - fz;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int corner = 0; corner < 8; ++corner) {
+    const int ax = corner & 1, ay = (corner >> 1) & 1, az = corner >> 2;
+    const int cx = ix + ax, cy = iy + ay, cz = iz + az;
+    if ((unsigned)cx >= (unsigned)D || (unsigned)cy >= (unsigned)D || (unsigned)cz >= (unsigned)D) continue;   // zero padding
+    const float w = (ax ? tx : 1.0f - tx) * (ay ? ty : 1.0f - ty) * (az ? tz : 1.0f - tz);
+    const float* f = filt + ((size_t)(cz * D + cy) * D + cx) * io + c0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c0 + j < io) acc[j] = __builtin_fmaf(f[j], w, acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (c0 + j < io) out[(size_t)s * io + c0 + j] = acc[j];
+}
+
 extern "C" {
 
 size_t nbd_linear_workspace_bytes(int n_rows, int n_cols, int k) {
@@ -1051,6 +1098,25 @@ int nbd_degree_scale_f32(const int* rowptr, int n, int mode, float* scale, nbd_s
   if (n == 0) return 0;
   if (!rowptr || !scale) return NBD_E_BADARG;
   degree_scale_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(rowptr, n, mode, scale);
+  return status();
+}
+
+int nbd_ball_to_cube_f32(const float* r, int n, float* out, nbd_stream_t stream) {
+  if (n < 0) return NBD_E_BADARG;
+  if (n == 0) return 0;
+  if (!r || !out) return NBD_E_BADARG;
+  ball_to_cube_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(r, n, out);
+  return status();
+}
+
+int nbd_trilinear_interpolate_f32(const float* filters, int filter_resolution, int in_channels, int out_channels,
+                                  const float* coords, int n, float* out, nbd_stream_t stream) {
+  if (n < 0 || filter_resolution < 2 || in_channels <= 0 || out_channels <= 0) return NBD_E_BADARG;
+  if (n == 0) return 0;
+  if (!filters || !coords || !out) return NBD_E_BADARG;
+  const int io = in_channels * out_channels;
+  const size_t threads = (size_t)n * ((io + 3) / 4);
+  trilinear_interpolate_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream>>>(filters, filter_resolution, io, coords, n, out);
   return status();
 }
 

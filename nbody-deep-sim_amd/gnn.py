@@ -27,7 +27,7 @@ from torch.nn import LayerNorm, Linear, ModuleList, Sequential, Tanh
 
 from nbd import autograd as ag
 from nbd import graphops, nnops
-from nbd._lib import NbdError
+from nbd._lib import NbdError, NbdUnsupported
 from nbd.data import Data
 
 
@@ -178,6 +178,8 @@ class GraphModel(torch.nn.Module):
         self._brs_const = None
         self._knn_buf = None
         self._one_call = None          # cached nbd_gnn_forward_args of predict() (see _one_call_plan)
+        self.last_path = None          # which path the last inference call took: "one_call+tables" / "one_call" (+ "+pre_advance"),
+                                       # "fused" (per-kernel fused layers), "general" (linear + aggregate kernels), "max"
         self.use_exp_tables = os.environ.get("NBD_GNN_EXP_TABLES", "1") != "0"   # 0: the one-call pass without tables
         self.use_one_call = True       # predict(): search + layers through ONE C-ABI call when the configuration allows
         self.to(device)
@@ -249,6 +251,7 @@ class GraphModel(torch.nn.Module):
             done = self._forward_fused(w, x_c, n, h, rowptr, src, fixed_k, aggr, None)
             self._out_hint = None
             if done:
+                self.last_path = "fused"
                 return self._fused_out
         cat_buf = torch.empty((n, enc_dim + h), dtype=torch.float32, device=dev)
         enc_view, gnn_view = cat_buf[:, :enc_dim], cat_buf[:, enc_dim:]
@@ -269,9 +272,12 @@ class GraphModel(torch.nn.Module):
         else:
             brs = nnops.degree_scale(rowptr, n, brs_mode, dev)
         if self.aggr == "max":
+            self.last_path = "max"
             return self._forward_max(w, enc_view, gnn_view, cat_buf, n, h, rowptr, src, fixed_k, ei)
         if self.use_fused and self._forward_fused(w, enc_view, n, h, rowptr, src, fixed_k, aggr, cat_buf):
+            self.last_path = "fused"
             return self._fused_out
+        self.last_path = "general"
         x = enc_view
         for li, (wpq, bpq, w2, b2) in enumerate(w["layers"]):
             pq = nnops.linear(x, wpq, bpq)                                        # (n, 2H) = [P | Q]
@@ -453,7 +459,9 @@ class GraphModel(torch.nn.Module):
             # (vel_half, pos_out, posm, dt): the leapfrog bookkeeping in the last layer's epilogue (include/nbd.h,
             # nbd_gnn_layer_args.adv_*); `pos` is then the pre-advanced position array the epilogue advances again
             vh, pos_out, posm, dt = advance
-            ok = (kick is not None and od == 3 and self.gnn_dim == 64 and self.input_dim <= 64
+            # (a one-layer model's only launch gathers neighbour rows from x = posm, which this epilogue overwrites: the
+            # C-ABI refuses that combination, NBD_E_UNSUPPORTED; the caller keeps its separate kick-drift launch)
+            ok = (kick is not None and od == 3 and self.gnn_dim == 64 and self.input_dim <= 64 and fa.n_layers >= 2
                   and all(t.shape == (n, 3) and t.dtype == torch.float32 and t.is_contiguous() and t.device == dev for t in (vh, pos_out))
                   and posm.dtype == torch.float32 and posm.is_contiguous() and posm.shape[1] == 4 and posm.shape[0] >= n)
             if not ok:
@@ -466,6 +474,7 @@ class GraphModel(torch.nn.Module):
             _lib.check(_lib.lib().nbd_gnn_forward_f32(ctypes.byref(fa), _lib.current_stream(dev)), "nbd_gnn_forward_f32")
         self._kick_done = kick is not None
         self._advance_done = advance is not None
+        self.last_path = ("one_call+tables" if fa.workspace_bytes else "one_call") + ("+pre_advance" if advance is not None else "")
         graphops.mark(buf, "_nbd_grouped")
         return out
 
@@ -524,7 +533,7 @@ class GraphModel(torch.nn.Module):
             if pred is not None:
                 return pred
             if advance is not None:
-                raise NbdError("GraphModel._predict_posm: the pre-advancing step needs the one-call fused path")
+                raise NbdUnsupported("GraphModel._predict_posm: the pre-advancing step needs the one-call fused path")
             buf = self._knn_buf
             if buf is not None and (buf.shape != (2, n * kk) or buf.device != pos.device):
                 buf = None

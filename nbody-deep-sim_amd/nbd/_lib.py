@@ -28,6 +28,11 @@ class NbdError(RuntimeError):
     pass
 
 
+class NbdUnsupported(NbdError):
+    """A configuration a fast path does not cover (NBD_E_UNSUPPORTED, or the Python-side check in front of it): callers that
+    probe a path catch THIS and fall back; any other NbdError is a real failure and propagates."""
+
+
 def build(verbose: bool = False) -> str:
     """Compile every .hip under csrc/ into libnbd_hip.so (make is incremental)."""
     res = subprocess.run(["make", "-C", CSRC_DIR, "-j4"], capture_output=True, text=True)
@@ -221,6 +226,8 @@ SIGNATURES = {
     "nbd_contconv_bin_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "nbd_contconv_fused_supported": (c_int, [c_int, c_int, c_int]),
+    "nbd_ball_to_cube_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "nbd_trilinear_interpolate_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "nbd_contconv_pairs_layout": (c_int, [c_int, c_int64, c_int, POINTER(c_size_t)]),
     "nbd_contconv_pairs_bytes": (c_size_t, [c_int, c_int64, c_int]),
     "nbd_contconv_pairs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_int,
@@ -325,7 +332,7 @@ def lib() -> ctypes.CDLL:
 def check(code: int, what: str) -> None:
     if code != 0:
         msg = lib().nbd_strerror(code)
-        raise NbdError(f"{what} failed with code {code}: {msg.decode() if msg else '?'}")
+        raise (NbdUnsupported if code == -3 else NbdError)(f"{what} failed with code {code}: {msg.decode() if msg else '?'}")
 
 
 def ptr(t) -> int | None:

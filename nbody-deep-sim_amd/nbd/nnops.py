@@ -213,6 +213,38 @@ def contconv_bin(pos, feat, rowptr, centres, d, radius_sq, out=None, node_begin=
     return out
 
 
+def ball_to_cube(r: torch.Tensor) -> torch.Tensor:
+    """contconv.py:30-33 on the GPU (nbd_ball_to_cube_f32): r (..., 3) -> r / (|r| + 1e-8) * tanh |r|."""
+    if not r.is_cuda:
+        raise _lib.NbdError("ball_to_cube: tensors must live on the GPU (no CPU path)")
+    shape = r.shape
+    if shape[-1] != 3:
+        raise _lib.NbdError("ball_to_cube: r must be (..., 3)")
+    rc = r.detach().to(torch.float32).reshape(-1, 3).contiguous()
+    out = torch.empty_like(rc)
+    with _lib.on_device(rc.device):
+        _lib.check(_lib.lib().nbd_ball_to_cube_f32(rc.data_ptr(), rc.shape[0], out.data_ptr(), _lib.current_stream(rc.device)),
+                   "nbd_ball_to_cube_f32")
+    return out.reshape(shape)
+
+
+def trilinear_interpolate(filters: torch.Tensor, coords: torch.Tensor) -> torch.Tensor:
+    """contconv.py:53-78 on the GPU (nbd_trilinear_interpolate_f32): filters (D, D, D, I, O), coords (N, 3) in [0, D - 1]
+    -> (N, I, O), the reference's grid_sample call (align_corners, zero padding, component 0 along the last grid axis)."""
+    if not (filters.is_cuda and coords.is_cuda):
+        raise _lib.NbdError("trilinear_interpolate: tensors must live on the GPU (no CPU path)")
+    d, i_ch, o_ch = filters.shape[0], filters.shape[3], filters.shape[4]
+    if coords.dim() != 2 or coords.shape[1] != 3:
+        raise _lib.NbdError("trilinear_interpolate: coords must be (N, 3)")
+    f = filters.detach().to(torch.float32).contiguous()
+    c = coords.detach().to(torch.float32).contiguous()
+    out = torch.empty((c.shape[0], i_ch, o_ch), dtype=torch.float32, device=f.device)
+    with _lib.on_device(f.device):
+        _lib.check(_lib.lib().nbd_trilinear_interpolate_f32(f.data_ptr(), d, i_ch, o_ch, c.data_ptr(), c.shape[0], out.data_ptr(),
+                                                            _lib.current_stream(f.device)), "nbd_trilinear_interpolate_f32")
+    return out
+
+
 def contconv_fused_supported(i_ch: int, o_ch: int, n_cells: int) -> bool:
     return bool(_lib.lib().nbd_contconv_fused_supported(int(i_ch), int(o_ch), int(n_cells)))
 

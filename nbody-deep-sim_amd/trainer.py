@@ -21,6 +21,7 @@ import torch
 
 from datautils import get_dataloader
 from nbd import direct
+from nbd._lib import NbdUnsupported
 
 ROLLOUT_COLUMNS = ["filename", "scene", "step", "x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az",
                    "pred_x", "pred_y", "pred_z", "pred_vx", "pred_vy", "pred_vz", "pred_ax", "pred_ay", "pred_az",
@@ -39,6 +40,7 @@ class Trainer:
         self.use_hip_graph = True
         self.hip_graph_min_steps = 5       # shorter rollouts do not amortise the capture
         self.pre_advance = True            # captured GNN step: leapfrog bookkeeping in the last layer's epilogue (_capture_step)
+        self.last_capture = None           # which form _capture_step captured: "pre_advance" / "packed" / "generic"; None: eager
 
     def train_from_dir(self, data_path, epochs, batch_size, save_every, save_path=None, create_save_path=False):
         """trainer.py:20-92. Returns (epoch_losses, epoch_mse_losses). Checkpoints are `model_{epoch}.pt`
@@ -130,13 +132,20 @@ class Trainer:
             if packed and self.pre_advance and getattr(self.model, "supports_pre_advance", False):
                 vel_half, pos_pre = s_vel.clone(), s_pos.clone()
                 direct.kick_drift(pos_pre, vel_half, s_acc, m_flat, half, full, posm=posm)
-                try:        # one un-captured step: does this model / shape take the one-call path with the epilogue?
+                # one un-captured step: does this model / shape take the one-call path with the epilogue? Only the dedicated
+                # refusal (NbdUnsupported) means "no": any other failure is a real one and goes to the handler below.
+                try:
                     t_pos, t_vel, t_acc, t_vh, t_pp, t_pm = (t.clone() for t in (s_pos, s_vel, s_acc, vel_half, pos_pre, posm))
                     self.model._predict_posm(t_pm, t_pp, out=t_acc, kick=(t_vel, half), advance=(t_vh, t_pos, full))
                     if self.model._advance_done:
+                        # ... and the probe's step must BE step(): same position, velocity and acceleration (bit for bit:
+                        # the epilogue rounds as the separate kernels do)
+                        e_pos, e_vel, e_acc = self.step(s_pos, s_vel, m, s_acc, dt)
+                        if not (torch.equal(e_pos, t_pos) and torch.equal(e_vel, t_vel) and torch.equal(e_acc, t_acc)):
+                            raise RuntimeError("the pre-advancing step does not reproduce Trainer.step()")
                         pre = (vel_half, pos_pre)
                         keep += [vel_half, pos_pre]
-                except Exception:
+                except NbdUnsupported:
                     pre = None
             with torch.cuda.graph(graph):
                 # step() on the static state IN PLACE (same kernels and arithmetic; the functional clones and
@@ -161,7 +170,10 @@ class Trainer:
             import warnings
             warnings.warn(f"hipGraph capture of the rollout step failed ({exc}); using eager launches")
             torch.cuda.synchronize()
+            self.last_capture = None
             return None
+
+        self.last_capture = "pre_advance" if pre is not None else ("packed" if packed else "generic")
 
         def advance(clone=True):
             """One captured step. clone=False hands back the graph's own state buffers: valid only until

@@ -136,6 +136,10 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert L.nbd_contconv_shuffle_filters_f32(None, None, 4, 8, 8, 0, None, None) == -1
     assert L.nbd_linear_wgrad_bias_f32(None, 4, None, 4, None, 10, 4, 4, None, 4, None, None, 0, None) == -1
     assert L.nbd_rowptr_sorted_i64(None, 5, 3, None, None) == -1
+    assert L.nbd_ball_to_cube_f32(None, 5, None, None) == -1 and L.nbd_ball_to_cube_f32(None, 0, None, None) == 0
+    assert L.nbd_trilinear_interpolate_f32(None, 4, 3, 5, None, 7, None, None) == -1          # NULL buffers
+    assert L.nbd_trilinear_interpolate_f32(None, 1, 3, 5, None, 0, None, None) == -1          # a grid needs two points per axis
+    assert L.nbd_trilinear_interpolate_f32(None, 4, 3, 5, None, 0, None, None) == 0
     assert L.nbd_gnn_train_forward_f32(None, None) == -1 and L.nbd_cc_train_forward_f32(None, None) == -1
     assert L.nbd_knn_graph_hint_pq_f32(None, 5, 3, 0, 15, None, None, None, None) == -1
     pq = _lib.KnnPqArgs()

@@ -636,20 +636,25 @@ def test_test_from_dir_on_a_generated_csv(tmp_path, gpu_device):
     assert np.isfinite(df_roll.values).all() and (df_roll.loc[("output_file_1.csv", 0, 0)][["pos_rmse", "vel_rmse"]] == 0).all()
 
 
-@pytest.mark.parametrize("kind", ["gnn", "gnn64", "gnn64_separate_kick_drift", "contconv"])
+@pytest.mark.parametrize("kind", ["gnn", "gnn64", "gnn64_separate_kick_drift", "gnn64_one_layer", "gnn64_one_layer_no_tables", "contconv"])
 def test_hipgraph_rollout_step_equals_eager(kind, gpu_device):
     """Trainer._capture_step replays the captured step several times (state advances inside the graph);
     every replay must equal the eager Trainer.step bit for bit -- in particular counters that are
     zeroed inside the captured region have to be re-zeroed on every replay. gnn64: the published width, whose
     captured step has no kick-drift launch (the last layer's epilogue does the leapfrog bookkeeping, rounding as the
-    separate kernels do); gnn64_separate_kick_drift: the same model with that form switched off."""
+    separate kernels do); gnn64_separate_kick_drift: the same model with that form switched off. gnn64_one_layer(_no_tables):
+    message_passing_steps = 1 -- the only layer launch gathers its neighbours' rows from the position array itself, which the
+    pre-advancing epilogue would overwrite under the other workgroups' feet: the library refuses that form (NBD_E_UNSUPPORTED)
+    and the captured step keeps its kick-drift launch; with the exponential tables off the edge loop really reads those rows."""
     import contconv
     import gnn
     import trainer
     torch.manual_seed(5)
     if kind.startswith("gnn"):
-        model = gnn.GraphModel(input_dim=4, gnn_dim=32 if kind == "gnn" else 64, message_passing_steps=2, aggr="mean",
-                               neighbors=10, device="cuda")
+        model = gnn.GraphModel(input_dim=4, gnn_dim=32 if kind == "gnn" else 64,
+                               message_passing_steps=1 if "one_layer" in kind else 2, aggr="mean", neighbors=10, device="cuda")
+        if kind.endswith("no_tables"):
+            model.use_exp_tables = False
     else:
         model = contconv.ContinuousConvModel(in_channels=4, out_channels=3, filter_resolution=[4, 3], radius=1.0, agg="mean",
                                              continuous_conv_layers=2, continuous_conv_dim=16, encoder_hiddens=[8],
@@ -663,6 +668,11 @@ def test_hipgraph_rollout_step_equals_eager(kind, gpu_device):
     assert adv is not None
     if kind.startswith("gnn"):
         assert model._advance_done == (kind == "gnn64")
+        assert tr.last_capture == ("pre_advance" if kind == "gnn64" else "packed")
+        assert model.last_path == {"gnn": "one_call", "gnn64": "one_call+tables+pre_advance", "gnn64_separate_kick_drift": "one_call+tables",
+                                   "gnn64_one_layer": "one_call+tables", "gnn64_one_layer_no_tables": "one_call"}[kind]
+    else:
+        assert model.last_path == ("fused", "fused") and tr.last_capture == "generic"
     p, v, a = pos, vel, acc
     for i in range(4):
         p, v, a = tr.step(p, v, m1, a, 0.01)
@@ -755,6 +765,32 @@ def test_trained_gnn_fixture_rollout(gpu_device):
 def _ref_vectors(name):
     import os
     return np.load(os.path.join(os.path.dirname(__file__), "golden", f"surrogate_ref_{name}.npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_contconv_public_helpers_reproduce_the_reference_class(case, gpu_device):
+    """ContinuousConv.ball_to_cube / .trilinear_interpolate (contconv.py:30-33, 53-78) on the drop-in layer against the
+    outputs of the reference's own methods (tests/golden/surrogate_ref_contconv.npz, make_golden_surrogate.py): the mapped
+    offsets, the (N, I, O) blends at stored grid coordinates, and the composition the layer's forward uses."""
+    import contconv
+    g = _ref_vectors("contconv")
+    filters = torch.tensor(g[f"c{case}_filters"])
+    d, i, o = filters.shape[0], filters.shape[3], filters.shape[4]
+    layer = contconv.ContinuousConv(i, o, d, radius=1.0).cuda()
+    with torch.no_grad():
+        layer.filters.copy_(filters.cuda())
+    r = torch.tensor(g[f"c{case}_r"]).cuda()
+    cube = layer.ball_to_cube(r)
+    assert cube.shape == r.shape and float((cube.cpu() - torch.tensor(g[f"c{case}_cube"])).abs().max()) <= 2e-7
+    coords = torch.tensor(g[f"c{case}_coords"]).cuda()
+    got = layer.trilinear_interpolate(coords)
+    ref = torch.tensor(g[f"c{case}_interp"])
+    assert got.shape == ref.shape and float((got.cpu() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    grid = (cube + 1) * ((d - 1) / 2)                                              # contconv.py:89-90
+    got_r = layer.trilinear_interpolate(grid)
+    ref_r = torch.tensor(g[f"c{case}_interp_of_r"])
+    assert float((got_r.cpu() - ref_r).abs().max()) <= 1e-5 * max(1.0, float(ref_r.abs().max()))
+    assert layer.trilinear_interpolate(coords[:0]).shape == (0, i, o) and layer.ball_to_cube(r[:0]).shape == (0, 3)
 
 
 @pytest.mark.parametrize("case", [0, 1, 2, 3])
