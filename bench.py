@@ -193,6 +193,31 @@ def main():
     for _ in range(args.warmup):
         sim.step()
 
+    def host_enqueue_ms(s_, k_=20):
+        """wall time the host spends enqueueing one step (no synchronisation inside the loop)"""
+        barrier()
+        t_ = time.perf_counter()
+        for _ in range(k_):
+            s_.step()
+        dt_ = (time.perf_counter() - t_) / k_ * 1e3
+        barrier()
+        return dt_
+    # The range-sharded step as ONE hipGraph, collective included (LeapFrogSimulator.capture_step); eager stays the
+    # fallback when the runtime refuses the capture (gloo rehearsals always do), and the JSON says which ran.
+    sharded_info = None
+    if sim._sharded:
+        sharded_info = {"host_enqueue_ms_eager": host_enqueue_ms(sim)}
+        want = os.environ.get("NBD_CAPTURE_SHARDED", "1") != "0" and (group is None or dist.get_backend() == "nccl")
+        ok_t = torch.tensor([1 if (want and sim.capture_step()) else 0], dtype=torch.int32, device="cuda")
+        if group is not None:                      # all ranks replay or none does
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        if not ok_t.item():
+            sim._step_graph = None
+        sharded_info["captured"] = bool(ok_t.item())
+        sharded_info["step_ran"] = "hipGraph replay (kick-drift, all-gather, both force blocks)" if ok_t.item() else "eager launches"
+        if ok_t.item():
+            sharded_info["host_enqueue_ms_captured"] = host_enqueue_ms(sim)
+
     def timed_windows(s_, min_repeats, min_total_s):
         """EXACTLY --steps steps per window, each window bracketed by barrier + synchronize on both sides and the MAX
         over ranks taken per window; repeated (median of >= 5 repeats) until >= min_total_s of timed
@@ -218,35 +243,75 @@ def main():
 
     # roofline leg (every rank runs it to stay in lock-step; rank 0 reports): HIP events on the
     # launch stream around the force kernel of K further steps
-    evs = []
-    for _ in range(args.steps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); e1.record()                       # creates the hipEvent_t handles
-        if not sim._sharded:
-            new_acc = torch.empty_like(sim.accelerations)
-            direct.leapfrog_step(sim.positions, sim.velocities, sim.accelerations, new_acc, sim.masses,
-                                 direct.f32(0.5 * sim.dt), direct.f32(sim.dt), sim._eps2, sim._g,
-                                 sim._posm, sim._ws, ev_begin=e0, ev_end=e1, uniform=getattr(sim, "_uniform", None))
-            sim.accelerations = new_acc
-        else:                                          # sharded step: events around BOTH force launches
-            half, dt = direct.f32(0.5 * sim.dt), direct.f32(sim.dt)
-            pt = sim.part
-            direct.kick_drift(sim.positions, sim.velocities, sim.accelerations, sim._mass_local, half, dt,
-                              posm=sim._posm_local)
-            handle = sim._gather.start(sim._posm_local, sim._posm)
-            sim._gather.finish(handle, sim._posm)      # measurement leg: no overlap, the kernels alone
-            loc = sim._posm_local[:direct.padded_len(pt.n_local)]
-            acc = torch.empty_like(sim.accelerations)
-            e0.record()
-            direct.shard_force_local(loc, pt.n_local, sim.n, pt.lo, sim._eps2, sim._ws, uniform=getattr(sim, "_uniform", None))
-            direct.shard_force_remote(sim._posm, sim.n, loc, pt.n_local, pt.lo, sim._eps2, sim._g, acc,
-                                      sim.velocities, half, sim._ws, uniform=getattr(sim, "_uniform", None))
-            e1.record()
-            sim.accelerations = acc
-        evs.append((e0, e1))
-    barrier()
-    k_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+    def kernel_event_ms(sim):
+        evs = []
+        for _ in range(args.steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record()                       # creates the hipEvent_t handles
+            if not sim._sharded:
+                new_acc = torch.empty_like(sim.accelerations)
+                direct.leapfrog_step(sim.positions, sim.velocities, sim.accelerations, new_acc, sim.masses,
+                                     direct.f32(0.5 * sim.dt), direct.f32(sim.dt), sim._eps2, sim._g,
+                                     sim._posm, sim._ws, ev_begin=e0, ev_end=e1, uniform=getattr(sim, "_uniform", None))
+                sim.accelerations = new_acc
+            else:                                          # sharded step: events around BOTH force launches
+                half, dt = direct.f32(0.5 * sim.dt), direct.f32(sim.dt)
+                pt = sim.part
+                direct.kick_drift(sim.positions, sim.velocities, sim.accelerations, sim._mass_local, half, dt,
+                                  posm=sim._posm_local)
+                handle = sim._gather.start(sim._posm_local, sim._posm)
+                sim._gather.finish(handle, sim._posm)      # measurement leg: no overlap, the kernels alone
+                loc = sim._posm_local[:direct.padded_len(pt.n_local)]
+                acc = torch.empty_like(sim.accelerations)
+                e0.record()
+                direct.shard_force_local(loc, pt.n_local, sim.n, pt.lo, sim._eps2, sim._ws, uniform=getattr(sim, "_uniform", None))
+                direct.shard_force_remote(sim._posm, sim.n, loc, pt.n_local, pt.lo, sim._eps2, sim._g, acc,
+                                          sim.velocities, half, sim._ws, uniform=getattr(sim, "_uniform", None))
+                e1.record()
+                if sim._step_graph is not None:
+                    sim.accelerations.copy_(acc)           # the captured step's static buffer
+                else:
+                    sim.accelerations = acc
+            evs.append((e0, e1))
+        barrier()
+        return sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+    k_ms = kernel_event_ms(sim)
     assert torch.isfinite(sim.positions).all()
+
+    # where a rank's step goes (HIP events between the phases of EAGER steps, MAX over ranks): own x own block, launch
+    # stream idle until the all-gather has landed, own x remote block; beside the host's enqueue time
+    if sharded_info is not None:
+        ph = [sim.step_phases() for _ in range(max(args.steps, 5))]
+        keys = ("kick_drift_ms", "local_force_ms", "gather_wait_ms", "remote_force_ms", "host_enqueue_ms")
+        t_ph = torch.tensor([sorted(x[k_] for x in ph)[len(ph) // 2] for k_ in keys], dtype=torch.float64, device="cuda")
+        if group is not None:
+            dist.all_reduce(t_ph, op=dist.ReduceOp.MAX)
+        sharded_info.update({k_: float(v_) for k_, v_ in zip(keys, t_ph.tolist())})
+        sharded_info["phases_note"] = ("median over eager steps of HIP-event intervals on the launch stream, MAX over ranks; "
+                                       "gather_wait_ms = stream idle between the end of the own x own block and the all-gather's "
+                                       "completion (what the overlap does not cover)")
+
+    # the general-mass kernel beside the equal-mass headline (the reference multiplies by m_j per pair,
+    # simulation.py:86-88; the Plummer set's equal masses let the headline kernel factor the mass out of the sum)
+    general = None
+    if world == 1 and not strong and getattr(sim, "_uniform", None) is not None:
+        os.environ["NBD_UNIFORM_MASS"] = "0"
+        try:
+            sim_g = simulation.LeapFrogSimulator(positions=p, velocities=v, masses=m, g_const=1.0, softening=0.1,
+                                                 dt=0.01, calc_energy=False, device="cuda")
+        finally:
+            del os.environ["NBD_UNIFORM_MASS"]
+        for _ in range(args.warmup):
+            sim_g.step()
+        w_g = timed_windows(sim_g, args.repeats, min(args.min_timed_seconds, 0.5))
+        el_g = w_g[len(w_g) // 2]
+        kg_ms = kernel_event_ms(sim_g)
+        ach_g = float(n_total) * float(n_total) * FLOP_PER_PAIR / (kg_ms * 1e-3) / 1e12
+        general = {"kernel": "accel_kernel<false,8>", "why": "NBD_UNIFORM_MASS=0: the per-pair multiply by m_j kept (any unequal-mass caller, "
+                   "e.g. generate_disk's star masses, runs this kernel)", "ms_per_step": el_g / args.steps * 1e3, "repeats": len(w_g),
+                   "value": float(n_total) * float(n_total) * args.steps / el_g, "kernel_ms": kg_ms, "achieved": ach_g,
+                   "frac": ach_g / PEAK_FP32_TFLOPS}
+        del sim_g
 
     # BASELINE.json's metric string reads "N = 65 536 ... 1/2/4/8 MI355X": next to the weak series above
     # (fixed bodies per GPU, configs[4] at 8 GPUs), time the SAME 65 536-body problem split over all ranks.
@@ -276,10 +341,13 @@ def main():
     n_loc = sim.part.n_local
     pairs_per_launch = float(n_loc) * float(n_total)
     achieved = pairs_per_launch * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1 and not strong:
-        traffic = json.load(open(tpath)).get("accel_kernel_hbm_bytes_per_launch")
+        tj = json.load(open(tpath))
+        traffic = tj.get("accel_kernel_hbm_bytes_per_launch")
+        traffic_source = ("profiles/traffic.json (" + str(tj.get("source", "rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE passes of an earlier run of this command")) +
+                          "): a constant read from the repository, NOT measured by this run")
     plan = direct.accel_plan(n_total, n_loc) if not sim._sharded else direct.shard_plan(n_total, sim.part.lo, n_loc)
     out = {
         "metric": "pair-interactions/sec, direct O(N^2) leapfrog N-body, fp32",
@@ -309,7 +377,7 @@ def main():
             # peak and the fp32 MFMA peak are the same 157.3 TFLOP/s, so the fraction is unambiguous
             "bound": "mfma", "compute_unit": "fp32 VALU (v_pk_fma_f32 / v_rsq_f32), no MFMA instructions",
             "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+            "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
             "kernel": ("accel_kernel<false,8,uniform mass>" if getattr(sim, "_uniform", None) is not None
                        else "accel_kernel<false,8>"),
             "kernel_ms": k_ms, "flop_per_pair": FLOP_PER_PAIR,
@@ -321,6 +389,10 @@ def main():
                     "at 2.4 GHz (general masses: 64 cycles, 62%)",
         },
     }
+    if general is not None:
+        out["roofline"]["general_mass"] = general
+    if sharded_info is not None:
+        out["sharded_step"] = sharded_info
     if strong_leg is not None:
         out["strong_scaling_n65536"] = strong_leg
     if args.cpu_seconds > 0 and world == 1:

@@ -358,10 +358,92 @@ class LeapFrogSimulator(BaseSimulator):
             return
         # sharded: kick+drift+pack of the own bodies -> all-gather in flight || own x own force block ->
         # own x remote block + slab sum + second kick. Four launches and one collective.
+        if self._step_graph is not None:                 # capture_step(): the same launches and the collective, replayed
+            self._step_graph.replay()
+            return
         if self.part.n_local:
             direct.kick_drift(self.positions, self.velocities, self.accelerations, self._mass_local, half, dt,
                               posm=self._posm_local)
         self.accelerations = self._force_sharded(self.velocities, half)
+
+    _step_graph = None
+
+    def capture_step(self, warmup: int = 3) -> bool:
+        """Capture the range-sharded leapfrog step -- kick-drift, the all-gather, both force blocks, the second kick -- into
+        ONE hipGraph (torch's NCCL backend = RCCL records its collective into a capturing stream): a rank's step at the
+        strong-scaled size is ~136 us of kernels behind ~28 us of host enqueue (profiles/r02_shard_rank_of_8.json), and the
+        enqueue is what a replay removes. `accelerations` becomes a static buffer (the graph copies the new values into
+        it: 12 B per body). Returns False -- and step() stays eager -- when the runtime refuses the capture; every rank
+        must call this together (the warm-up steps run the collective)."""
+        if not self._sharded or self.n == 0 or self._step_graph is not None:
+            return self._step_graph is not None
+        try:
+            for _ in range(warmup):                      # communicator, allocator pools, hipFuncSetAttribute calls
+                self.step()
+            torch.cuda.synchronize(self.device)
+            half, dt = direct.f32(0.5 * self.dt), direct.f32(self.dt)
+            acc_static = self.accelerations.clone()
+            self.accelerations = acc_static
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    if self.part.n_local:
+                        direct.kick_drift(self.positions, self.velocities, acc_static, self._mass_local, half, dt,
+                                          posm=self._posm_local)
+                    new_acc = self._force_sharded(self.velocities, half)
+                    acc_static.copy_(new_acc)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            self._step_graph, self._step_graph_keep = graph, (new_acc, acc_static, side)
+            return True
+        except Exception as exc:                          # pragma: no cover - depends on the runtime's capture support
+            import warnings
+            warnings.warn(f"hipGraph capture of the range-sharded step failed ({exc}); the step stays eager")
+            try:
+                torch.cuda.synchronize(self.device)
+            except Exception:
+                pass
+            self._step_graph = None
+            return False
+
+    def step_phases(self):
+        """One EAGER range-sharded step with HIP events between its phases: {"local_force_ms", "gather_wait_ms",
+        "remote_force_ms", "kick_drift_ms", "host_enqueue_ms"} -- gather_wait = the launch stream idle between the end of
+        the own x own block and the completion of the all-gather (what the overlap does not cover). Synchronises."""
+        if not self._sharded or self.n == 0:
+            raise _lib.NbdError("step_phases(): only the range-sharded step has phases")
+        half, dt = direct.f32(0.5 * self.dt), direct.f32(self.dt)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        p = self.part
+        t0 = time.perf_counter()
+        ev[0].record()
+        if p.n_local:
+            direct.kick_drift(self.positions, self.velocities, self.accelerations, self._mass_local, half, dt,
+                              posm=self._posm_local)
+        handle = self._gather.start(self._posm_local, self._posm)
+        acc = torch.empty((p.n_local, 3), dtype=torch.float32, device=self.device)
+        ev[1].record()
+        local = self._posm_local[:direct.padded_len(p.n_local)]
+        if p.n_local:
+            direct.shard_force_local(local, p.n_local, self.n, p.lo, self._eps2, self._ws, uniform=self._uniform)
+        ev[2].record()
+        self._gather.finish(handle, self._posm)
+        ev[3].record()
+        if p.n_local:
+            direct.shard_force_remote(self._posm, self.n, local, p.n_local, p.lo, self._eps2, self._g, acc,
+                                      self.velocities, half, self._ws, uniform=self._uniform)
+        ev[4].record()
+        host = (time.perf_counter() - t0) * 1e3
+        if self._step_graph is not None:
+            self.accelerations.copy_(acc)                # the captured step's static buffer
+        else:
+            self.accelerations = acc
+        torch.cuda.synchronize(self.device)
+        return {"kick_drift_ms": ev[0].elapsed_time(ev[1]), "local_force_ms": ev[1].elapsed_time(ev[2]),
+                "gather_wait_ms": ev[2].elapsed_time(ev[3]), "remote_force_ms": ev[3].elapsed_time(ev[4]),
+                "host_enqueue_ms": host}
 
 
 class EulerSimulator(BaseSimulator):

@@ -358,6 +358,35 @@ def test_bench_py_multi_rank_json_end_to_end(gpu_device, tmp_path):
     assert strong["n_particles"] == per and strong["scaling"] == "strong" and strong["value"] > 0
     assert out["roofline"]["pairs_per_launch"] == per * world * per and 0 < out["roofline"]["frac"] < 1
     assert out["cpu_baseline"] is None
+    sh = out["sharded_step"]                                       # where a rank's step goes, and which form of the step ran
+    for k in ("local_force_ms", "gather_wait_ms", "remote_force_ms", "host_enqueue_ms", "kick_drift_ms", "host_enqueue_ms_eager"):
+        assert sh[k] >= 0.0, k
+    assert sh["captured"] is False and sh["step_ran"] == "eager launches"      # gloo rehearsal: nothing to capture
+
+
+def test_captured_sharded_step_is_bit_identical_to_eager_one_rank_rccl(gpu_device):
+    """LeapFrogSimulator.capture_step(): the range-sharded step -- kick-drift, the all-gather, both force blocks, the second
+    kick -- as ONE hipGraph replay, on a one-rank RCCL group (tools/shard_capture_check.py, started from
+    torch.distributed.run before the GPU is touched): 20 steps bit-identical to the eager sharded step from the same state.
+    Capture refused by the runtime is reported, not hidden: the simulator then stays eager and must still be identical."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, NBD_FORCE_SHARDED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "shard_capture_check.py"), "8192", "20"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["bit_identical"] and out["backend"] == "nccl"
+    assert out["captured"], "the runtime refused to capture the collective: " + res.stderr[-1500:]
+    assert out["host_enqueue_ms_captured"] < out["host_enqueue_ms_eager"]
+    assert set(out["phases_ms"]) >= {"local_force_ms", "gather_wait_ms", "remote_force_ms", "host_enqueue_ms"}
 
 
 def test_full_size_all_rows_against_c_oracle_f64(gpu_device):

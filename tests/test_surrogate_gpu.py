@@ -986,12 +986,18 @@ def test_gnn_full_size_config_matches_oracle(gpu_device):
     assert global_rel(got, ref) < TOL and row_rel(got, ref) < 10 * TOL
     # second call on: hinted search in place, one C-ABI call, tanh through the exponential tables -- the same bar against
     # the oracle, and bit-identical from call to call
+    assert model.last_path == "fused"                                             # first call: the per-kernel fused layers
     again = model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu()
     assert model._one_call is not None and model._one_call["fa"].workspace_bytes > 0
+    assert model.last_path == "one_call+tables"                                   # the fast path was taken, and says so
     assert global_rel(again, ref) < TOL and row_rel(again, ref) < 10 * TOL
     assert torch.equal(model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu(), again)
     model.use_exp_tables, model._one_call = False, None                           # without the tables: the first call's bits
     assert torch.equal(model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu(), got)
+    assert model.last_path == "one_call"
+    model.use_fused, model._one_call = False, None                                # a forced fallback shows up, it is not silent
+    model.predict(pos.cuda(), feat.cuda(), neighbors=32)
+    assert model.last_path == "general"
 
 
 def test_contconv_full_size_config_rows_match_oracle_and_layer_is_linear(gpu_device):
@@ -1111,6 +1117,14 @@ def test_contconv_published_model_at_config_size_matches_oracle_rows(gpu_device)
     pos = pos * BENCH_SCALE_16384
     feat = torch.cat([vel, m[:, None] * n], 1)
     got = model.predict(pos.cuda(), feat.cuda()).cpu()
+    assert model.last_path == ("fused", "fused")                              # the block-sparse kernels ran, not the binned fallback
+    for layer in model.contconv:
+        layer.use_fused = False
+    slow = model.predict(pos.cuda(), feat.cuda()).cpu()
+    assert model.last_path == ("binned", "binned")                            # a forced fallback shows up in last_path
+    for layer in model.contconv:
+        layer.use_fused = True
+    assert global_rel(slow, got) < TOL
 
     ei = so.radius_graph(pos, 1.0, loop=True, max_num_neighbors=32)           # the oracle's own edge list
     rows = torch.randperm(n, generator=torch.Generator().manual_seed(5))[:40]
