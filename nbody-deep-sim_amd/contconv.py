@@ -449,6 +449,20 @@ class ContinuousConvModel(nn.Module):
             data._radius_cache = self._radius_cache if self.use_radius_cache else None
             return self.forward(data)
 
+    def predict_batched(self, pos, feat, batch):
+        """predict() for several independent systems at once (Trainer.test_from_dir): `batch` (sorted int64) names every
+        body's system; the radius graph stays inside a system (radius_graph(batch=...)). One set of launches for all."""
+        from nbd.data import Data
+        ensure_eval(self)
+        with torch.no_grad():
+            if (self.in_channels == 4 and pos.dtype == torch.float32 and feat.dtype == torch.float32 and pos.is_cuda
+                    and pos.dim() == 2 and pos.shape[1] == 3 and feat.dim() == 2 and feat.shape[1] >= 4):
+                data = Data(x=pos, batch=batch)
+                data._x_pos = (torch.cat((pos, feat[:, 3:]), dim=-1), pos.contiguous())
+            else:
+                data = Data(x=torch.cat((pos, feat), dim=-1), batch=batch)
+            return self.forward(data)
+
     def eval_graph_batch(self, data):
         self.eval()
         with torch.no_grad():

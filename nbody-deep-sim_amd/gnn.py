@@ -504,6 +504,26 @@ class GraphModel(torch.nn.Module):
             pred = self._forward_inference(x_in, ei, max(min(k, pos.shape[0] - 1), 0))
         return pred
 
+    def predict_batched(self, pos, feat, batch, neighbors=None):
+        """predict() for SEVERAL independent systems at once (Trainer.test_from_dir advances all scenes of a file
+        together): `batch` (sorted int64, one entry per body) names every body's system; neighbours are searched inside
+        a system only (knn_graph(batch=...), k = 50 as predict(), fewer in systems of <= k bodies), one set of launches for
+        all of them. Same layer kernels as the first predict() call of a sequence (CSR form, exact tanh)."""
+        ensure_eval(self)
+        with torch.no_grad():
+            k = 50 if neighbors is None else neighbors
+            if not pos.is_cuda:
+                raise NbdError("GraphModel.predict_batched: tensors must live on the GPU (no CPU path)")
+            x_in = torch.cat((pos, feat[:, 3:]), dim=-1) if self.input_dim == 4 else torch.cat((pos, feat), dim=-1)
+            x_in = x_in.to(torch.float32)
+            buf = getattr(self, "_knn_buf_batched", None)
+            lay = getattr(batch, "_nbd_knn_layout", None)
+            if buf is not None and (lay is None or buf.shape != (2, lay[2]) or buf.device != pos.device):
+                buf = None
+            ei = graphops.knn_graph(pos.contiguous(), k=k, batch=batch, loop=False, out=buf)
+            self._knn_buf_batched = ei
+            return self._forward_inference(x_in, ei, None)
+
     supports_pre_advance = True          # _predict_posm(advance=...): see Trainer._capture_step
 
     def _predict_posm(self, posm, pos, k=50, out=None, kick=None, advance=None):

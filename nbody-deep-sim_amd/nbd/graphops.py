@@ -78,9 +78,21 @@ def knn_graph(x: torch.Tensor, k: int, batch: torch.Tensor | None = None, loop: 
         kk = max(min(k, n - (0 if loop else 1)), 0)
         e, off = n * kk, None
     else:
-        per = torch.clamp((hi - lo).to(torch.int64) - (0 if loop else 1), min=0, max=k)
-        off = (torch.cumsum(per, 0) - per).contiguous()
-        e = int(per.sum().item())
+        # edges per centre and their offsets depend only on (segment sizes, k, loop): remembered on the batch vector, so a
+        # rollout that advances several scenes together pays the one host read-back of the edge count once, not per step
+        # (and none at all inside a hipGraph capture)
+        key = (batch._version, int(k), bool(loop), str(dev))
+        memo = getattr(batch, "_nbd_knn_layout", None)
+        if memo is not None and memo[0] == key:
+            off, e = memo[1], memo[2]
+        else:
+            per = torch.clamp((hi - lo).to(torch.int64) - (0 if loop else 1), min=0, max=k)
+            off = (torch.cumsum(per, 0) - per).contiguous()
+            e = int(per.sum().item())
+            try:
+                batch._nbd_knn_layout = (key, off, e)
+            except (AttributeError, RuntimeError):
+                pass
     if out is not None:
         if out.shape != (2, e) or out.dtype != torch.int64 or not out.is_contiguous() or out.device != dev:
             raise _lib.NbdError(f"knn_graph: out must be a contiguous int64 (2, {e}) tensor on {dev}")

@@ -93,16 +93,17 @@ class Trainer:
         return epoch_losses, epoch_mse_losses
 
     # ------------------------------------------------------------------ trainer.py:217-226
-    def step(self, pos, vel, m, acc, dt):
-        """Leapfrog with model-predicted accelerations; functional (returns new tensors)."""
+    def step(self, pos, vel, m, acc, dt, predict=None):
+        """Leapfrog with model-predicted accelerations; functional (returns new tensors). predict: the function standing
+        in for self.model.predict (the scenes-together rollout passes the model's predict_batched bound to its batch)."""
         half, full = direct.f32(0.5 * dt), direct.f32(dt)
         pos_, vel_ = pos.contiguous().clone(), vel.contiguous().clone()
         direct.kick_drift(pos_, vel_, acc.contiguous(), None, half, full)          # vel_ = vel + .5dt acc ; pos_ = pos + dt vel_
-        acc_ = self.model.predict(pos_, torch.cat([vel_, m], dim=-1))
+        acc_ = (predict or self.model.predict)(pos_, torch.cat([vel_, m], dim=-1))
         direct.kick(vel_, acc_, half)                                              # vel_ += .5dt acc_
         return pos_, vel_, acc_
 
-    def _capture_step(self, pos, vel, m, acc, dt):
+    def _capture_step(self, pos, vel, m, acc, dt, predict=None):
         """Capture self.step() on static buffers into a hipGraph; returns a callable that advances the
         static state by one step per call and hands back (pos, vel, acc) copies, or None if capture is
         not possible (then the eager path is used). Same kernels, same arithmetic, fewer launch gaps."""
@@ -112,13 +113,13 @@ class Trainer:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):                       # warm-up: allocator pools, weight caches, attributes
-                    self.step(s_pos, s_vel, m, s_acc, dt)
+                    self.step(s_pos, s_vel, m, s_acc, dt, predict)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             half, full = direct.f32(0.5 * dt), direct.f32(dt)
             # a model whose input is [pos | mass] (GraphModel, input_dim 4) can read the packed {x,y,z,m} rows the
             # kick-drift kernel writes anyway: no concatenations in the captured step
-            packed = (hasattr(self.model, "_predict_posm") and getattr(self.model, "input_dim", 0) == 4
+            packed = (predict is None and hasattr(self.model, "_predict_posm") and getattr(self.model, "input_dim", 0) == 4
                       and m.dim() == 2 and m.shape[1] == 1 and m.dtype == torch.float32)
             keep = [m]                 # every buffer the captured kernels touch must outlive the graph
             if packed:
@@ -162,7 +163,7 @@ class Trainer:
                         direct.kick(s_vel, o_acc, half)
                 else:
                     direct.kick_drift(s_pos, s_vel, s_acc, None, half, full)
-                    o_acc = self.model.predict(s_pos, torch.cat([s_vel, m], dim=-1))
+                    o_acc = (predict or self.model.predict)(s_pos, torch.cat([s_vel, m], dim=-1))
                     direct.kick(s_vel, o_acc, half)
                 if o_acc.data_ptr() != s_acc.data_ptr():
                     s_acc.copy_(o_acc)
@@ -188,7 +189,8 @@ class Trainer:
         return advance
 
     # ------------------------------------------------------------------ trainer.py:228-344
-    def evaluate_rollout(self, filename, data, scene, sim_steps, dt, df):
+    def _rollout_inputs(self, data, sim_steps):
+        """(gt (sim_steps, n, 9), pos, vel, m, feats) of one scene's batch of `sim_steps` graphs."""
         data = data.to(self.device)
         # Ground truth of every step in ONE pass: the reference selects `data.x[data.step == step]` inside the loop
         # (trainer.py:281-284) -- a boolean mask per step, i.e. a device->host count per step here. A stable sort
@@ -205,7 +207,72 @@ class Trainer:
         gt = torch.cat([data.x[:, :6], data.y], dim=1)[order[:sim_steps * n]].reshape(sim_steps, n, 9)
         first = order[:n]
         feats = data.x[first]
-        pos, vel, m = feats[:, :3].contiguous(), feats[:, 3:6].contiguous(), feats[:, 6:].contiguous()
+        return gt, feats[:, :3].contiguous(), feats[:, 3:6].contiguous(), feats[:, 6:].contiguous(), feats
+
+    @staticmethod
+    def _rollout_frame(filename, scene, table, times, sim_steps, n):
+        steps = np.repeat(np.arange(sim_steps), n)
+        df_new = pd.DataFrame(table.reshape(sim_steps * n, 18), columns=ROLLOUT_COLUMNS[3:21])
+        df_new.insert(0, "step", steps)
+        df_new.insert(0, "scene", scene)
+        df_new.insert(0, "filename", filename)
+        df_new["step_time"] = np.repeat(times, n)
+        return df_new[ROLLOUT_COLUMNS]
+
+    def evaluate_rollout_scenes(self, filename, datas, sim_steps, dt, df):
+        """evaluate_rollout for ALL scenes of a file advanced TOGETHER as one batched system (trainer.py:171-175 runs them
+        one after another: at the reference's sizes -- 3 .. 500 bodies -- a step is pure launch latency, the same few
+        launches whether they carry one scene or six). Needs model.predict_batched(pos, feat, batch) (GraphModel,
+        ContinuousConvModel): neighbours are searched inside a scene only. Rows come out exactly as the per-scene calls
+        would append them (scene-major); `step_time` = the batched step's time / number of scenes."""
+        ins = [self._rollout_inputs(d, sim_steps) for d in datas]
+        sizes = [g.shape[1] for g, *_ in ins]
+        pos, vel, m = (torch.cat([x[k] for x in ins]).contiguous() for k in (1, 2, 3))
+        feats = torch.cat([x[4] for x in ins])
+        batch = torch.repeat_interleave(torch.arange(len(ins), device=pos.device), torch.tensor(sizes, device=pos.device))
+        from nbd import graphops
+        graphops.mark(batch, "_nbd_sorted")
+        predict = lambda p_, f_: self.model.predict_batched(p_, f_, batch)     # noqa: E731
+        n_all = pos.shape[0]
+
+        def timed(fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn()
+            e1.record()
+            return out, (e0, e1)
+        acc, ev = timed(lambda: predict(pos, feats[:, 3:].contiguous()))
+        events = [ev]
+        pred = torch.empty((sim_steps, n_all, 9), dtype=torch.float32, device=pos.device)
+        torch.cat([pos, vel, acc], dim=1, out=pred[0])
+        graphed = (self._capture_step(pos, vel, m, acc, dt, predict=predict)
+                   if (self.use_hip_graph and sim_steps >= self.hip_graph_min_steps) else None)
+        torch.cuda.synchronize()
+        t_loop = time.perf_counter()
+        for step in range(1, sim_steps):
+            if graphed is not None:
+                (pos, vel, acc), ev = timed(lambda: graphed(clone=False))
+            else:
+                (pos, vel, acc), ev = timed(lambda: self.step(pos, vel, m, acc, dt, predict))
+            events.append(ev)
+            torch.cat([pos, vel, acc], dim=1, out=pred[step])
+        torch.cuda.synchronize()
+        self.last_rollout_timing = {"steps": sim_steps - 1, "loop_wall_s": time.perf_counter() - t_loop,
+                                    "captured": graphed is not None, "scenes_together": len(ins), "bodies": n_all}
+        times = np.array([a.elapsed_time(b) * 1e-3 for a, b in events]) / len(ins)
+        pred_h = pred.cpu().numpy().astype(np.float64)
+        frames, lo = [], 0
+        for scene, ((gt, *_), n) in enumerate(zip(ins, sizes)):
+            table = np.concatenate([gt.cpu().numpy().astype(np.float64), pred_h[:, lo:lo + n]], axis=2)
+            frames.append(self._rollout_frame(filename, scene, table, times, sim_steps, n))
+            lo += n
+        if df is not None and len(df):
+            frames.insert(0, df)
+        return pd.concat(frames, ignore_index=True)
+
+    def evaluate_rollout(self, filename, data, scene, sim_steps, dt, df):
+        gt, pos, vel, m, feats = self._rollout_inputs(data, sim_steps)
+        n = gt.shape[1]
 
         def timed(fn):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -236,13 +303,7 @@ class Trainer:
                                     "captured": graphed is not None}
         table = torch.cat([gt, pred], dim=2).cpu().numpy().astype(np.float64)      # ONE device->host copy
         times = np.array([a.elapsed_time(b) * 1e-3 for a, b in events])
-        steps = np.repeat(np.arange(sim_steps), n)
-        df_new = pd.DataFrame(table.reshape(sim_steps * n, 18), columns=ROLLOUT_COLUMNS[3:21])
-        df_new.insert(0, "step", steps)
-        df_new.insert(0, "scene", scene)
-        df_new.insert(0, "filename", filename)
-        df_new["step_time"] = np.repeat(times, n)
-        df_new = df_new[ROLLOUT_COLUMNS]
+        df_new = self._rollout_frame(filename, scene, table, times, sim_steps, n)
         return df_new if df is None or len(df) == 0 else pd.concat([df, df_new], ignore_index=True)
 
     # ------------------------------------------------------------------ trainer.py:202-215
@@ -259,6 +320,8 @@ class Trainer:
         return df
 
     # ------------------------------------------------------------------ trainer.py:94-200
+    batch_scenes = True      # test_from_dir: all scenes of a file advance together when the model has predict_batched
+
     def test_from_dir(self, data_path, model_path=None, sim_steps=1000, stepwise=True, rollout=True):
         if model_path:
             models = sorted(os.listdir(model_path), key=lambda x: int(x.split("_")[1].split(".")[0]))
@@ -277,7 +340,11 @@ class Trainer:
             for f in csv_files:
                 loader = get_dataloader(csv_path=f, batch_size=sim_steps, k=self.model.neighbors, shuffle=False,
                                         device=self.device)
-                for scene, data in enumerate(loader):
+                scenes = list(loader)
+                if self.batch_scenes and len(scenes) > 1 and hasattr(self.model, "predict_batched"):
+                    df_rollout = self.evaluate_rollout_scenes(f.split("/")[-1], scenes, sim_steps, self.dt, df_rollout)
+                    continue
+                for scene, data in enumerate(scenes):
                     df_rollout = self.evaluate_rollout(f.split("/")[-1], data, scene, sim_steps, self.dt, df_rollout)
         cols = ["x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az"]
         for col in cols:                                                           # trainer.py:177-178
