@@ -501,7 +501,12 @@ class GraphModel(torch.nn.Module):
                 buf = None
             ei = graphops.knn_graph(pos, k=k, batch=None, loop=False, hint=buf, out=buf)
             self._knn_buf = ei
-            pred = self._forward_inference(x_in, ei, max(min(k, pos.shape[0] - 1), 0))
+            # First call of a sequence: the graph just built is the buffer and hint the one-call pass was missing -- take
+            # that pass now (one more, hinted, search), so that this call and every later one run the SAME arithmetic
+            # (exponential tables or not): predict() on the same input returns the same bits, call after call.
+            pred = self._predict_one_call(x_in, pos.contiguous(), k)
+            if pred is None:
+                pred = self._forward_inference(x_in, ei, max(min(k, pos.shape[0] - 1), 0))
         return pred
 
     def predict_batched(self, pos, feat, batch, neighbors=None):

@@ -1035,20 +1035,20 @@ def test_gnn_full_size_config_matches_oracle(gpu_device):
     ref = ora.predict(pos, feat, k=32)
     got = model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu()
     assert global_rel(got, ref) < TOL and row_rel(got, ref) < 10 * TOL
-    # second call on: hinted search in place, one C-ABI call, tanh through the exponential tables -- the same bar against
-    # the oracle, and bit-identical from call to call
-    assert model.last_path == "fused"                                             # first call: the per-kernel fused layers
-    again = model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu()
+    # the first call already takes the one-call pass (hinted search in place, tanh through the exponential tables), so
+    # predict() is idempotent: the same input gives the same bits call after call
     assert model._one_call is not None and model._one_call["fa"].workspace_bytes > 0
     assert model.last_path == "one_call+tables"                                   # the fast path was taken, and says so
-    assert global_rel(again, ref) < TOL and row_rel(again, ref) < 10 * TOL
-    assert torch.equal(model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu(), again)
-    model.use_exp_tables, model._one_call = False, None                           # without the tables: the first call's bits
-    assert torch.equal(model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu(), got)
-    assert model.last_path == "one_call"
-    model.use_fused, model._one_call = False, None                                # a forced fallback shows up, it is not silent
-    model.predict(pos.cuda(), feat.cuda(), neighbors=32)
-    assert model.last_path == "general"
+    for _ in range(2):
+        assert torch.equal(model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu(), got)
+    model.use_exp_tables, model._one_call = False, None                           # without the tables: exact tanh
+    plain = model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu()
+    assert model.last_path == "one_call" and global_rel(plain, ref) < TOL and row_rel(plain, ref) < 10 * TOL
+    model.use_one_call = False                                                    # one launch per layer: the same bits
+    assert torch.equal(model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu(), plain) and model.last_path == "fused"
+    model.use_fused = False                                                       # a forced fallback shows up, it is not silent
+    slow = model.predict(pos.cuda(), feat.cuda(), neighbors=32).cpu()
+    assert model.last_path == "general" and global_rel(slow, ref) < TOL
 
 
 def test_contconv_full_size_config_rows_match_oracle_and_layer_is_linear(gpu_device):
