@@ -521,10 +521,12 @@ class GraphModel(torch.nn.Module):
                 raise NbdError("GraphModel.predict_batched: tensors must live on the GPU (no CPU path)")
             x_in = torch.cat((pos, feat[:, 3:]), dim=-1) if self.input_dim == 4 else torch.cat((pos, feat), dim=-1)
             x_in = x_in.to(torch.float32)
+            # the search always writes into a buffer of the layout's size (remembered on `batch`): no per-call read-back of
+            # the edge count, safe inside a hipGraph capture; self is masked in the kernel (the rollout's form of the rule)
+            _, e = graphops.knn_layout(batch, pos.shape[0], k, False, pos.device)
             buf = getattr(self, "_knn_buf_batched", None)
-            lay = getattr(batch, "_nbd_knn_layout", None)
-            if buf is not None and (lay is None or buf.shape != (2, lay[2]) or buf.device != pos.device):
-                buf = None
+            if buf is None or buf.shape != (2, e) or buf.device != pos.device:
+                buf = torch.empty((2, e), dtype=torch.int64, device=pos.device)
             ei = graphops.knn_graph(pos.contiguous(), k=k, batch=batch, loop=False, out=buf)
             self._knn_buf_batched = ei
             return self._forward_inference(x_in, ei, None)

@@ -51,6 +51,27 @@ def _segments(batch: torch.Tensor | None, n: int, device):
     return lo, hi
 
 
+def knn_layout(batch: torch.Tensor, n: int, k: int, loop: bool, device):
+    """(first edge of every centre int64 [n], edge count) of knn_graph(batch=...): they depend only on (segment sizes, k,
+    loop), so they are remembered on the batch vector -- a rollout that advances several scenes together pays the one host
+    read-back of the edge count once, not per step (and none at all inside a hipGraph capture)."""
+    lo, hi = _segments(batch, n, device)
+    key = (batch._version, int(k), bool(loop), str(device))
+    memo = getattr(batch, "_nbd_knn_layout", None)
+    if memo is not None and key in memo:
+        return memo[key]
+    per = torch.clamp((hi - lo).to(torch.int64) - (0 if loop else 1), min=0, max=k)
+    off = (torch.cumsum(per, 0) - per).contiguous()
+    val = (off, int(per.sum().item()))
+    try:
+        if memo is None:
+            batch._nbd_knn_layout = memo = {}
+        memo[key] = val
+    except (AttributeError, RuntimeError):
+        pass
+    return val
+
+
 def knn_graph(x: torch.Tensor, k: int, batch: torch.Tensor | None = None, loop: bool = False,
               hint: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
     """int64 edge_index [2, E]: per centre i its k nearest j (ascending (d2, j)); row 0 = j, row 1 = i.
@@ -78,21 +99,7 @@ def knn_graph(x: torch.Tensor, k: int, batch: torch.Tensor | None = None, loop: 
         kk = max(min(k, n - (0 if loop else 1)), 0)
         e, off = n * kk, None
     else:
-        # edges per centre and their offsets depend only on (segment sizes, k, loop): remembered on the batch vector, so a
-        # rollout that advances several scenes together pays the one host read-back of the edge count once, not per step
-        # (and none at all inside a hipGraph capture)
-        key = (batch._version, int(k), bool(loop), str(dev))
-        memo = getattr(batch, "_nbd_knn_layout", None)
-        if memo is not None and memo[0] == key:
-            off, e = memo[1], memo[2]
-        else:
-            per = torch.clamp((hi - lo).to(torch.int64) - (0 if loop else 1), min=0, max=k)
-            off = (torch.cumsum(per, 0) - per).contiguous()
-            e = int(per.sum().item())
-            try:
-                batch._nbd_knn_layout = (key, off, e)
-            except (AttributeError, RuntimeError):
-                pass
+        off, e = knn_layout(batch, n, k, loop, dev)
     if out is not None:
         if out.shape != (2, e) or out.dtype != torch.int64 or not out.is_contiguous() or out.device != dev:
             raise _lib.NbdError(f"knn_graph: out must be a contiguous int64 (2, {e}) tensor on {dev}")

@@ -331,6 +331,7 @@ class Trainer:
         csv_files = [f.replace("\\", "/") for f in glob(data_path + "/*.csv")]
         df_stepwise = pd.DataFrame(columns=["filename", "scene", "step", "loss", "mse_loss", "step_time"])
         df_rollout = pd.DataFrame(columns=ROLLOUT_COLUMNS)
+        self.last_rollout_modes = []       # per file: how its scenes were advanced
         if stepwise:
             for f in csv_files:
                 loader = get_dataloader(csv_path=f, batch_size=1, k=self.model.neighbors, shuffle=False,
@@ -343,7 +344,9 @@ class Trainer:
                 scenes = list(loader)
                 if self.batch_scenes and len(scenes) > 1 and hasattr(self.model, "predict_batched"):
                     df_rollout = self.evaluate_rollout_scenes(f.split("/")[-1], scenes, sim_steps, self.dt, df_rollout)
+                    self.last_rollout_modes.append((f.split("/")[-1], f"{len(scenes)} scenes together"))
                     continue
+                self.last_rollout_modes.append((f.split("/")[-1], "scene by scene"))
                 for scene, data in enumerate(scenes):
                     df_rollout = self.evaluate_rollout(f.split("/")[-1], data, scene, sim_steps, self.dt, df_rollout)
         cols = ["x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az"]

@@ -672,7 +672,7 @@ def test_hipgraph_rollout_step_equals_eager(kind, gpu_device):
         assert model.last_path.startswith("one_call") and model.last_path.endswith("+pre_advance") == (kind == "gnn64")
         assert ("+tables" in model.last_path) == (not kind.endswith("no_tables"))
     else:
-        assert model.last_path == ("fused", "fused") and tr.last_capture == "generic"
+        assert model.last_path == ("fused", "fused") and tr.last_capture == "packed"
     p, v, a = pos, vel, acc
     for i in range(4):
         p, v, a = tr.step(p, v, m1, a, 0.01)
@@ -897,7 +897,8 @@ def test_test_from_dir_reproduces_reference_frames(use_graph, together, tmp_path
     steps = int(g["sim_steps"])
     tr.hip_graph_min_steps = 2         # the fixture has 4 steps: capture anyway
     df_step, df_roll = tr.test_from_dir(str(tmp_path), sim_steps=steps)
-    assert ("scenes_together" in tr.last_rollout_timing) == (together and len(set(g["rollout_index_scene"].tolist())) > 1)
+    modes = {m for _, m in tr.last_rollout_modes}
+    assert modes == ({"2 scenes together", "scene by scene"} if together else {"scene by scene"})      # a 2-scene and a 1-scene file
     df_step, df_roll = df_step.sort_index(), df_roll.sort_index()
     assert list(df_step.columns) == list(g["stepwise_columns"]) and list(df_roll.columns) == list(g["rollout_columns"])
     assert [i[0] for i in df_step.index] == list(g["stepwise_index_filename"])
