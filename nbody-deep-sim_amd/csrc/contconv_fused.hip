@@ -396,80 +396,88 @@ struct PlanJobs { PlanJob j[NBD_CC_MAX_RES]; };
 __global__ __launch_bounds__(1024) void contconv_plan_kernel(const PlanJobs jobs, int n_tiles) {
   const PlanJob& J = jobs.j[blockIdx.x];
   const int K = J.n_cells, G = J.groups, W = CC_GRID / G;
-  __shared__ long long ccost[MAXC];
+  __shared__ int ccost[MAXC];                               // cost of cell k over all tiles (the whole list's cost fits an int)
   __shared__ int s_gc[NBD_CC_GROUPS + 1];
   __shared__ int red[2][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int2* cs = J.cellstep;
-  for (int k = tid; k < K; k += 1024) {
-    long long c = 0;
-    for (int t = 0; t < n_tiles; ++t)
-      if (J.tile_nsteps[t] > 0) c += cs[(size_t)t * (K + 1) + k + 1].y - cs[(size_t)t * (K + 1) + k].y;
-    ccost[k] = c;
-  }
-  __syncthreads();
-  if (tid == 0) {                                            // K <= 160: a serial prefix
-    long long tot = 0;
-    for (int k = 0; k < K; ++k) tot += ccost[k];
-    long long cum = 0;                                       // cost in front of cell k
-    int g = 1;
-    s_gc[0] = 0;
-    for (int k = 0; k <= K && g < G; ++k) {                  // gcell[g] = first cell whose cost-before reaches tot g / G
-      while (g < G && cum >= tot * g / G) s_gc[g++] = k;
-      if (k < K) cum += ccost[k];
+  if (G == 1) {                                              // one group: all cells
+    if (tid == 0) { s_gc[0] = 0; s_gc[1] = K; J.gcell[0] = 0; J.gcell[1] = K; }
+  } else {
+    for (int k = tid; k < K; k += 1024) ccost[k] = 0;
+    __syncthreads();
+    // every (tile, cell) entry once, neighbouring threads on neighbouring cells of a tile (coalesced), summed per cell in LDS
+    for (int i = tid; i < n_tiles * K; i += 1024) {
+      const int t = i / K, k = i - t * K;
+      if (J.tile_nsteps[t] > 0) {
+        const int c = cs[(size_t)t * (K + 1) + k + 1].y - cs[(size_t)t * (K + 1) + k].y;
+        if (c) atomicAdd(&ccost[k], c);
+      }
     }
-    while (g < G) s_gc[g++] = K;
-    s_gc[G] = K;
-    for (int i = 0; i <= G; ++i) J.gcell[i] = s_gc[i];
+    __syncthreads();
+    if (tid == 0) {                                          // K <= 160: a serial prefix
+      long long tot = 0;
+      for (int k = 0; k < K; ++k) tot += ccost[k];
+      long long cum = 0;                                     // cost in front of cell k
+      int g = 1;
+      s_gc[0] = 0;
+      for (int k = 0; k <= K && g < G; ++k) {                // gcell[g] = first cell whose cost-before reaches tot g / G
+        while (g < G && cum >= tot * g / G) s_gc[g++] = k;
+        if (k < K) cum += ccost[k];
+      }
+      while (g < G) s_gc[g++] = K;
+      s_gc[G] = K;
+      for (int i = 0; i <= G; ++i) J.gcell[i] = s_gc[i];
+    }
   }
   __syncthreads();
-  for (int g = 0; g < G; ++g) {
-    const int c0 = s_gc[g], c1 = s_gc[g + 1];
+  // per group: prefix over the tiles of (steps, cost) of the group's cells -- wave g scans group g, 64 tiles per trip
+  if (wave < G) {
+    const int g = wave, c0 = s_gc[g], c1 = s_gc[g + 1];
     int* tb = J.tile_base + (size_t)g * (n_tiles + 1);
     int* cb = J.cost_base + (size_t)g * (n_tiles + 1);
     int scarry = 0, ccarry = 0;
-    for (int t0 = 0; t0 < n_tiles; t0 += 1024) {
-      const int t = t0 + tid;
+    for (int t0 = 0; t0 < n_tiles; t0 += 64) {
+      const int t = t0 + lane;
       int vs = 0, vc = 0;
       if (t < n_tiles && J.tile_nsteps[t] > 0) {             // -1: a tile the pair kernel refused
         const int2 a = cs[(size_t)t * (K + 1) + c0], b = cs[(size_t)t * (K + 1) + c1];
         vs = b.x - a.x; vc = b.y - a.y;
       }
       const int is = wave_incl_scan(vs, lane), ic = wave_incl_scan(vc, lane);
-      __syncthreads();
-      if (lane == 63) { red[0][wave] = is; red[1][wave] = ic; }
-      __syncthreads();
-      int os = 0, oc = 0, ts = 0, tc = 0;
-      for (int i = 0; i < 16; ++i) { const int x = red[0][i], y = red[1][i]; os += i < wave ? x : 0; oc += i < wave ? y : 0; ts += x; tc += y; }
-      if (t < n_tiles) { tb[t] = scarry + os + is - vs; cb[t] = ccarry + oc + ic - vc; }
-      scarry += ts; ccarry += tc;
+      if (t < n_tiles) { tb[t] = scarry + is - vs; cb[t] = ccarry + ic - vc; }
+      scarry += __shfl(is, 63); ccarry += __shfl(ic, 63);
     }
-    if (tid == 0) { tb[n_tiles] = scarry; cb[n_tiles] = ccarry; }
-    __threadfence_block();
-    __syncthreads();
-    const int T = scarry;
-    const long long Ctot = ccarry;
-    for (int w = tid; w <= W; w += 1024) {
-      int cut;
-      if (w == 0 || Ctot == 0) cut = w == W ? T : 0;
-      else if (w >= W) cut = T;
+    if (lane == 0) { tb[n_tiles] = scarry; cb[n_tiles] = ccarry; }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // every cut of every group by its own thread
+  for (int i = tid; i < G * (W + 1); i += 1024) {
+    const int g = i / (W + 1), w = i - g * (W + 1);
+    const int c0 = s_gc[g];
+    const int* tb = J.tile_base + (size_t)g * (n_tiles + 1);
+    const int* cb = J.cost_base + (size_t)g * (n_tiles + 1);
+    const int T = tb[n_tiles];
+    const long long Ctot = cb[n_tiles];
+    int cut;
+    if (w == 0 || Ctot == 0) cut = w == W ? T : 0;
+    else if (w >= W) cut = T;
+    else {
+      const int B = (int)(Ctot * w / W);
+      int lo = 0, hi = n_tiles - 1;                          // smallest t with cost_base[t + 1] > B
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (cb[mid + 1] > B) hi = mid; else lo = mid + 1; }
+      const int t = lo, rel = B - cb[t], sb = tb[t], ns = tb[t + 1] - sb;
+      if (rel == 0) cut = sb;
       else {
-        const int B = (int)(Ctot * w / W);
-        int lo = 0, hi = n_tiles - 1;                        // smallest t with cost_base[t + 1] > B
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cb[mid + 1] > B) hi = mid; else lo = mid + 1; }
-        const int t = lo, rel = B - cb[t], sb = tb[t], ns = tb[t + 1] - sb;
-        if (rel == 0) cut = sb;
-        else {
-          const int2 first = cs[(size_t)t * (K + 1) + c0];   // the group's first step in tile t and the cost in front of it
-          const int4* ts_ = J.steps + step_base(t, J.rowptr[t * TN], K) + first.x;
-          int a = 0, b = ns;                                 // steps i with running cost (inside the group) < rel (.w increases)
-          while (a < b) { const int mid = (a + b) >> 1; if (ts_[mid].w - first.y < rel) a = mid + 1; else b = mid; }
-          cut = sb + min(1 + a, ns);
-        }
+        const int2 first = cs[(size_t)t * (K + 1) + c0];     // the group's first step in tile t and the cost in front of it
+        const int4* ts_ = J.steps + step_base(t, J.rowptr[t * TN], K) + first.x;
+        int a = 0, b = ns;                                   // steps i with running cost (inside the group) < rel (.w increases)
+        while (a < b) { const int mid = (a + b) >> 1; if (ts_[mid].w - first.y < rel) a = mid + 1; else b = mid; }
+        cut = sb + min(1 + a, ns);
       }
-      J.cuts[g * (W + 1) + w] = cut;
     }
-    __syncthreads();
+    J.cuts[i] = cut;
   }
 }
 
@@ -1029,10 +1037,13 @@ __device__ __forceinline__ void cc_consumer(const CCArgs& A, const CCLds& L, int
         __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                             \
         if (lane == 0) __hip_atomic_store(&L.done[b * CC_CONSUMERS + cw], use + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
         __atomic_signal_fence(__ATOMIC_SEQ_CST);                                                             \
-        if (have) { CC_READ_SLAB(bn_, 2) CC_READ_SLAB(bn_, 3) }                                              \
+        /* the scatter BEFORE the next step's slabs 2-3 are requested: hipcc waits for `old` with lgkmcnt(0) (the reads \
+           behind it are conditional), which would also wait out reads issued a moment ago */              \
         if (node >= 0)                                                                                       \
           *o = f4{old[0] + ((accs0[0] + accs1[0]) + accb[0]), old[1] + ((accs0[1] + accs1[1]) + accb[1]),    \
                   old[2] + ((accs0[2] + accs1[2]) + accb[2]), old[3] + ((accs0[3] + accs1[3]) + accb[3])};   \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (have) { CC_READ_SLAB(bn_, 2) CC_READ_SLAB(bn_, 3) }                                              \
       } else {                                                                                               \
         tile_n = UNI(tile_v_);                                                                               \
         have = false;                                                                                        \
