@@ -62,8 +62,8 @@ constexpr int SUBR = 16;             // packed rows per step of the fused kernel
 // consumers ~1.1-1.45 us whatever it holds and the producers ~14.5 ns per pair (in-kernel stamps at the published shape,
 // round 3: the gathers are served from the Infinity Cache at ~3.5 TB/s), so below ~80-100 pairs the matrix side sets
 // the pace and above it the gather. (The additive model cost = a + pairs, a = 32 .. 96, measured 2-12 % slower.)
-constexpr int CC_COST_MIN = 80;    // swept once the cuts moved into the plan kernel (profiles/r03_contconv_ablations.json):
-                                   // 56 / 64 / 72 / 80 / 88 / 96 -> D = 6 + D = 4 layers 0.657 / 0.636 / 0.633 / 0.626 / 0.634 / 0.633 ms
+constexpr int CC_COST_MIN = 64;    // round 4 (bf16 consumers), same box, D = 6 + D = 4 layers: 24 / 40 / 56 / 64 / 72 / 80 / 112 ->
+                                   // 0.741 / 0.662 / 0.611 / 0.609 / 0.613 / 0.620 / 0.658 ms (round 3's fp32 consumers: 80)
 __host__ __device__ inline int step_cost(int pairs) { return pairs > CC_COST_MIN ? pairs : CC_COST_MIN; }
 
 // first step record of a tile: a (tile, cell) with r rows has ceil(r / 16) <= r / 16 + 1 steps and a tile's rows
@@ -398,7 +398,6 @@ __global__ __launch_bounds__(1024) void contconv_plan_kernel(const PlanJobs jobs
   const int K = J.n_cells, G = J.groups, W = CC_GRID / G;
   __shared__ int ccost[MAXC];                               // cost of cell k over all tiles (the whole list's cost fits an int)
   __shared__ int s_gc[NBD_CC_GROUPS + 1];
-  __shared__ int red[2][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int2* cs = J.cellstep;
   if (G == 1) {                                              // one group: all cells
@@ -406,29 +405,50 @@ __global__ __launch_bounds__(1024) void contconv_plan_kernel(const PlanJobs jobs
   } else {
     for (int k = tid; k < K; k += 1024) ccost[k] = 0;
     __syncthreads();
-    // every (tile, cell) entry once, neighbouring threads on neighbouring cells of a tile (coalesced), summed per cell in LDS
-    for (int i = tid; i < n_tiles * K; i += 1024) {
-      const int t = i / K, k = i - t * K;
-      if (J.tile_nsteps[t] > 0) {
-        const int c = cs[(size_t)t * (K + 1) + k + 1].y - cs[(size_t)t * (K + 1) + k].y;
+    // thread = (cell, slice of the tiles): neighbouring threads read neighbouring cells of a tile (coalesced), every thread's
+    // loads are independent of each other (eight in flight) -- one (tile, cell) entry per trip behind an LDS atomic took 30 us
+    {
+      const int slices = 1024 / K > 0 ? 1024 / K : 1;          // K <= 160: >= 6 slices
+      const int k = tid % K, sl = tid / K;
+      if (sl < slices) {
+        const int per = (n_tiles + slices - 1) / slices, t_lo = sl * per, t_hi = min(n_tiles, t_lo + per);
+        int c = 0;
+#pragma unroll 8
+        for (int t = t_lo; t < t_hi; ++t) {
+          const int a = cs[(size_t)t * (K + 1) + k].y, b = cs[(size_t)t * (K + 1) + k + 1].y;
+          c += b - a;                                          // (a refused tile's entries are zero)
+        }
         if (c) atomicAdd(&ccost[k], c);
       }
     }
     __syncthreads();
-    if (tid == 0) {                                          // K <= 160: a serial prefix
-      long long tot = 0;
-      for (int k = 0; k < K; ++k) tot += ccost[k];
-      long long cum = 0;                                     // cost in front of cell k
-      int g = 1;
-      s_gc[0] = 0;
-      for (int k = 0; k <= K && g < G; ++k) {                // gcell[g] = first cell whose cost-before reaches tot g / G
-        while (g < G && cum >= tot * g / G) s_gc[g++] = k;
-        if (k < K) cum += ccost[k];
+    if (wave == 0) {                                         // prefix over the cells (K <= 160 = three lane chunks), then the
+      static_assert(MAXC <= 192, "three chunks of 64 cells");       // group boundaries by ballot: a serial loop of dependent LDS
+      int before[3];                                         // reads and 64-bit products was 15 us of this kernel
+      int carry = 0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int k = 64 * c + lane;
+        const int v = k < K ? ccost[k] : 0;
+        const int incl = wave_incl_scan(v, lane);
+        before[c] = carry + incl - v;
+        carry += __shfl(incl, 63);
       }
-      while (g < G) s_gc[g++] = K;
-      s_gc[G] = K;
-      for (int i = 0; i <= G; ++i) J.gcell[i] = s_gc[i];
+      const long long tot = carry;
+      if (lane == 0) { s_gc[0] = 0; s_gc[G] = K; }
+      for (int g = 1; g < G; ++g) {                          // gcell[g] = first cell whose cost-before reaches tot g / G
+        int first = K;
+#pragma unroll
+        for (int c = 2; c >= 0; --c) {
+          const int k = 64 * c + lane;
+          const unsigned long long m = __ballot(k <= K && (long long)before[c] * G >= tot * g);
+          if (m) first = 64 * c + __builtin_ctzll(m);
+        }
+        if (lane == 0) s_gc[g] = min(first, K);
+      }
     }
+    __syncthreads();
+    if (tid <= G) J.gcell[tid] = s_gc[tid];
   }
   __syncthreads();
   // per group: prefix over the tiles of (steps, cost) of the group's cells -- wave g scans group g, 64 tiles per trip
@@ -453,6 +473,7 @@ __global__ __launch_bounds__(1024) void contconv_plan_kernel(const PlanJobs jobs
   __threadfence_block();
   __syncthreads();
   // every cut of every group by its own thread
+  const int wshift = 31 - __clz(W);
   for (int i = tid; i < G * (W + 1); i += 1024) {
     const int g = i / (W + 1), w = i - g * (W + 1);
     const int c0 = s_gc[g];
@@ -464,7 +485,7 @@ __global__ __launch_bounds__(1024) void contconv_plan_kernel(const PlanJobs jobs
     if (w == 0 || Ctot == 0) cut = w == W ? T : 0;
     else if (w >= W) cut = T;
     else {
-      const int B = (int)(Ctot * w / W);
+      const int B = (int)((Ctot * w) >> wshift);             // W is a power of two
       int lo = 0, hi = n_tiles - 1;                          // smallest t with cost_base[t + 1] > B
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (cb[mid + 1] > B) hi = mid; else lo = mid + 1; }
       const int t = lo, rel = B - cb[t], sb = tb[t], ns = tb[t + 1] - sb;
