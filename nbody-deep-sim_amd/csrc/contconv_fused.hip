@@ -1121,11 +1121,7 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
   __shared__ int statics[32 + NBUF * CC_CONSUMERS];                // s_red[16], s_nseg, full[8], done[NBUF][8]
   const CCLds L = cc_lds(reinterpret_cast<float*>(lds_aligned), statics);
   const int tid = threadIdx.x, wave = UNI(tid >> 6);
-#ifdef NBD_CC_TRACE
-  const int lane = tid & 63;
-  const long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
-  __shared__ long long s_dbg[16][4];
-#endif
+  DBG_T(dbg_t0)                                     // (probe build: the workgroup's start stamp)
   long long dbg_wait[4] = {0, 0, 0, 0};        // [0] time on the flags, [1] in the steps, [2] in the table loads, [3] whole role
 
   // ---- this workgroup's range of the global step sequence: cut where the running COST (per step: max(CC_COST_MIN,
@@ -1145,6 +1141,8 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
   else cc_consumer<NS>(A, L, grp, slot0, g0, g1, tid, dbg_wait);
   DBG_ACC(true, dbg_wait[3], r0_)
 #ifdef NBD_CC_TRACE
+  const int lane = tid & 63;
+  __shared__ long long s_dbg[16][4];
   if (lane == 0) { for (int i = 0; i < 4; ++i) s_dbg[wave][i] = dbg_wait[i]; }
   __syncthreads();
   if (tid < 64 && g_cc_trace && blockIdx.z == 0) {
