@@ -1626,7 +1626,9 @@ struct PairsLayout { size_t desc, rows, src, w, steps, nsteps, cost, scale, cuts
 // well past an XCD's 4 MiB L2 (12 KiB per cell and 16-column block: 15.7 MB at D = 6, 128 -> 128), else one for all -- at
 // D = 4 (64 cells, 6 MB) the groups' extra accumulator flushes (a workgroup then crosses ~5 tiles instead of 1.5) cost more
 // than the fragment's L2 misses: same box, 0.252 -> 0.276 ms, against 0.385 -> 0.367 ms at D = 6
-inline int cc_groups(int n_cells) { return n_cells >= 96 ? NBD_CC_GROUPS : 1; }
+// (D = 4 with two groups -- the halves the workgroups' parity used to split a tile into anyway, now aligned with the XCDs:
+// 0.248 -> 0.244 ms; four groups 0.266)
+inline int cc_groups(int n_cells) { return n_cells >= 96 ? NBD_CC_GROUPS : n_cells >= 32 ? 2 : 1; }
 PairsLayout pairs_layout(int n, int64_t edge_capacity, int n_cells) {
   const size_t tiles = (size_t)ceil_div(n, TN);
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };

@@ -326,10 +326,10 @@ __device__ long long* g_knn_trace = nullptr;      // probe build (tools/build_pr
 #define KT(s)
 #endif
 constexpr int kLW = 16;              // waves (= centres) per workgroup
-// the exponential tables of nbd_gnn_layer_args.epq: 2^(c v), c = 2 log2 e; NaN beyond |c v| = 16 (csrc/gnn_fused.hip)
+// the exponential tables of nbd_gnn_layer_args.epq: 2^(c v), c = 2 log2 e; NaN beyond |c v| = 100 (csrc/gnn_fused.hip)
 __device__ __forceinline__ float exp_entry(float v) {
   const float t = v * 2.8853900817779268f;
-  return fabsf(t) <= 16.f ? __builtin_amdgcn_exp2f(t) : __builtin_nanf("");
+  return fabsf(t) <= 100.f ? __builtin_amdgcn_exp2f(t) : __builtin_nanf("");
 }
 constexpr int kLCap = 256;           // list entries per wave; beyond: the insertion form on global memory
 constexpr int kStagedMaxN = 8192;    // 12 B * n + 12 B * kLW * kLCap <= 144 KiB of the CU's 160

@@ -503,6 +503,35 @@ def test_gnn_exponential_tables_survive_preactivations_out_of_their_range(gpu_de
     assert t._one_call is not None and t._one_call["fa"].workspace_bytes > 0
 
 
+@pytest.mark.parametrize("scale", [4.0, 12.0, 25.0])
+def test_gnn_exponential_tables_hold_the_bar_for_large_preactivations_inside_their_range(scale, gpu_device):
+    """tanh(P_i + Q_j) through the tables loses accuracy as |P| and |Q| grow inside the accepted range (the rounding of
+    2 log2(e) v is magnified where P + Q is near 0; csrc/gnn_fused.hip states the bound: 4e-6 absolute at the limit). Models
+    whose first-layer weights are scaled up -- pre-activations from a few units to the limit of the range and past it -- must
+    still meet the oracle at 1e-5, through the one-call pass with tables (advisor, round 3)."""
+    import gnn
+    from oracle import surrogate_oracle as so
+    torch.manual_seed(int(scale))
+    cfg = dict(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", neighbors=10)
+    ora = so.GraphModelOracle(**cfg).eval()
+    with torch.no_grad():
+        lin = ora.gnns[0].nn[0]                       # P = W[:, :F] x_i - W[:, F:] x_i, Q = W[:, F:] x_j: both grow with the scale
+        lin.weight.mul_(scale)
+    model = gnn.GraphModel(device="cuda", **cfg)
+    _copy_state(model, ora)
+    n = 1500
+    pos, vel, m = _plummer_pos(n, 77)
+    feat = torch.cat([vel, m[:, None] * n], 1)
+    ref = ora.predict(pos, feat, k=50)
+    got = model.predict(pos.cuda(), feat.cuda()).cpu()
+    assert model.last_path == "one_call+tables"
+    assert global_rel(got, ref) < TOL and row_rel(got, ref) < 10 * TOL, scale
+    # the pre-activations really are large: 2 log2(e) |Q| of the first layer reaches tens at these scales
+    x = torch.cat([pos, m[:, None] * n], 1)
+    q = (x @ lin.weight[:, 4:].t()).abs().max().item() * 2.8853900817779268
+    assert q > 10.0 * scale / 4.0
+
+
 def test_contconv_fused_refuses_a_row_beyond_its_16_bit_counters_loudly(gpu_device):
     """The pair kernel counts pairs per (node, cell) in 16 bits: a node with more than 65 535 edges cannot be binned.
     Its tile is refused -- NaN for the tile's 128 nodes -- and every other tile is computed as usual."""
