@@ -153,7 +153,22 @@ def test_knn_graph_with_coincident_bodies(gpu_device):
             # ... and then the rollout's fast path (diagonal masked in the kernel, hint / out buffers) is the same graph
             buf = graphops.knn_graph(pos.cuda(), k, loop=False, hint=got.cuda(), out=got.cuda().clone())
             assert torch.equal(buf.cpu(), ref)
-    assert so.knn_graph(pos, 1).shape[1] > 300          # the corner really occurs at k = 1 (bodies 42-45, 250)
+    ref1 = so.knn_graph(pos, 1)
+    assert ref1.shape[1] > 300                          # the corner really occurs at k = 1 (bodies 42-45, 250)
+    # The ONE documented divergence: the rollout's fast path (out= / hint= / inside a capture) masks the diagonal
+    # in the kernel and always returns k neighbours per centre, where the k + 1-then-drop-self rule keeps k + 1 for a centre
+    # with >= k + 1 lower-indexed bodies at distance exactly 0. Every edge of the fast path is one of the rule's, centres
+    # outside that corner get exactly the same neighbours, and the corner's centres lose their LAST (highest-index) one.
+    fast = graphops.knn_graph(pos.cuda(), 1, loop=False, out=torch.empty((2, 300), dtype=torch.int64, device="cuda")).cpu()
+    assert fast.shape == (2, 300) and torch.equal(fast[1], torch.arange(300))
+    ref_edges = {(int(a), int(b)) for a, b in ref1.t().tolist()}
+    assert all((int(a), int(b)) in ref_edges for a, b in fast.t().tolist())
+    deg = torch.bincount(ref1[1], minlength=300)
+    corner = set(torch.nonzero(deg == 2).flatten().tolist())
+    assert corner == {42, 43, 44, 45, 250}
+    for c in range(300):
+        mine = sorted(int(a) for a, b in ref1.t().tolist() if int(b) == c)
+        assert int(fast[0, c]) == mine[0], c           # the first (lowest-index among ties) neighbour either way
     b = _batch(300, [60, 140, 100])
     for k in (2, 7):
         assert torch.equal(graphops.knn_graph(pos.cuda(), k, batch=b.cuda()).cpu(), so.knn_graph(pos, k, batch=b))
