@@ -1,7 +1,11 @@
 """Fits the fused ContinuousConv kernel's per-workgroup duration (probe build, tools/build_contconv_trace.sh) to what the
 workgroup's range holds -- steps, pairs, pairs above a threshold, cell changes -- at BASELINE configs[3] (N = 16 384,
 128 -> 128 channels, D = 6 and D = 4), and evaluates per-step cost functions for the plan kernel's cuts by the makespan
-the fitted model predicts for them.    NBD_LIB_OVERRIDE=tools/_trace/libnbd_trace.so python tools/contconv_cost_fit.py"""
+the fitted model predicts for them.    NBD_LIB_OVERRIDE=tools/_trace/libnbd_trace.so python tools/contconv_cost_fit.py
+
+Written for round 3's single step sequence (workgroup w = the w-th contiguous range). Since round 4 a layer with >= 32 filter
+cells is cut into cell groups (workgroup w works in group w mod groups): the per-workgroup features below are then attributed
+to the wrong steps -- use it on layers with one group only, or read tools/contconv_timeline.py instead."""
 import ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for _p in (os.path.join(ROOT, "nbody-deep-sim_amd"), ROOT):
