@@ -1170,6 +1170,38 @@ def test_contconv_bf16x3_contraction_error_is_no_larger_than_the_fp32_matrix_pip
     assert float(err_bf.square().mean().sqrt()) <= float(err_32.square().mean().sqrt())
 
 
+def test_contconv_stream_kernel_ranges_longer_than_one_table_pass(gpu_device):
+    """A workgroup of the stream kernel copies <= 256 step records into LDS at a time; at the published size every range is
+    shorter than that. N = 40 000 at D = 6 gives every workgroup ~500 steps of its cell group (three passes: the ring's
+    counters run on across passes, the filter fragment is requested afresh at every pass start and drained at its end) and
+    N = 40 000 at D = 3 (27 cells: ONE cell group, 256 workgroups) ranges that cross many tiles. Checked against the
+    library's other path (binned features + fp32 GEMM) on every row, twice (deterministic)."""
+    import contconv
+    from nbd import graphops, nnops
+    n = 40000
+    pos, _, _ = _plummer_pos(n, 99)
+    pos = (pos * 6.2).cuda()                                            # mean radius-1 degree ~ 32 at this size
+    torch.manual_seed(4)
+    feat = torch.randn(n, 32).cuda()
+    lists = graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32)
+    for D in (6, 3):
+        layer = contconv.ContinuousConv(32, 32, D, radius=1.0, agg="mean").cuda()
+        _, cmap, n_cells = layer.cells()
+        pairs = nnops.contconv_pairs(pos, lists.rowptr, lists.centres, lists.centres.numel(), D, 1.0, cmap, n_cells)
+        steps = nnops.contconv_pairs_stats(pairs[0], n, pairs[1], n_cells)["steps"]
+        groups = 8 if n_cells >= 96 else 2 if n_cells >= 32 else 1
+        if D == 6:
+            assert steps / 256 > 2 * 256                                # every workgroup: more than two table passes
+        with torch.no_grad():
+            got = layer(pos, feat, lists=lists, act="tanh", pairs=pairs)
+            assert layer.last_path == "fused"
+            again = layer(pos, feat, lists=lists, act="tanh", pairs=pairs)
+            layer.use_fused = False
+            ref = layer(pos, feat, lists=lists, act="tanh")
+        assert torch.equal(got, again)
+        assert global_rel(got.cpu(), ref.cpu()) < TOL and row_rel(got.cpu(), ref.cpu()) < 10 * TOL, (D, groups)
+
+
 BENCH_SCALE_16384 = 4.599349753792708      # tools/bench_surrogates.py: Plummer positions x this -> mean radius-1 degree 32
 
 
