@@ -1156,90 +1156,73 @@ __global__ __launch_bounds__(CC_THREADS) void contconv_stream_kernel(const CCArg
 #endif
 }
 
-// out = act(scale * sum of the tile's partial slots), in (group, workgroup) order. grid (tiles, 4): 32 rows of a tile each
-// (graphs of < 64 tiles: (tiles, 16), 8 rows each -- a 2 000-node training batch spreads every tile over many workgroups'
-// slots, and 64 blocks walking them serially took 40 us).
+// out = act(scale * sum of the tile's partial slots), in (group, workgroup) order. grid (tiles, 16): 8 rows of a tile each,
+// one output quad per thread, so that a block's loads of up to FIN_WB slots go out as ONE round trip (the slots were written
+// by other XCDs a moment ago: every load is a cold trip through the fabric -- with 32 rows per block and three slots per
+// trip the D = 6 layer's ~10 slots per tile took 26.9 us, this form 21.3: 82 MB of partials at 3.9 TB/s, the bytes now).
 // The workgroups whose ranges meet the tile's steps of a group, [tile_base[g][t], tile_base[g][t + 1]), are the ones that
 // wrote a slot for it: slot(group g, its j-th workgroup, tile t) = g (W + tiles) + j + t -- a merge-path numbering inside
-// every group, unique and independent of timing.
+// every group, unique and independent of timing. The list is built by wave 0, 64 workgroups of a group per trip.
+constexpr int FIN_ROWS = 8, FIN_WB = 6;
 __global__ __launch_bounds__(256) void contconv_stream_finish_kernel(
     const float* __restrict__ partial, const int* __restrict__ tile_nsteps, const int* __restrict__ cuts,
     const int* __restrict__ tile_base, int n_tiles, int groups,
     const float* __restrict__ rowscale, int act, float* __restrict__ out, int ldo, int n, int O, int OP) {
-  __shared__ int s_cut[CC_GRID + NBD_CC_GROUPS];
   __shared__ int s_slot[CC_GRID];
   __shared__ int s_ns;
-  const int tid = threadIdx.x, tile = blockIdx.x;
+  const int tid = threadIdx.x, tile = blockIdx.x, lane = tid & 63;
   const int W = CC_GRID / groups;
-  for (int i = tid; i < groups * (W + 1); i += 256) s_cut[i] = cuts[i];
-  __syncthreads();
   const int cnt_all = tile_nsteps[tile];
-  if (tid == 0) {
-    int ns = 0;
-    for (int g = 0; g < groups && cnt_all > 0; ++g) {
-      const int* tb = tile_base + (size_t)g * (n_tiles + 1);
-      const int base = tb[tile], cnt = tb[tile + 1] - base;
-      if (cnt <= 0) continue;
-      const int* cut = s_cut + g * (W + 1);
-      int a = 0, b = W - 1;                                        // largest w with cut[w] <= base
-      while (a < b) { const int m = (a + b + 1) >> 1; if (cut[m] <= base) a = m; else b = m - 1; }
-      for (int w = a; w < W && cut[w] < base + cnt; ++w)
-        if (cut[w] < cut[w + 1] && cut[w + 1] > base) s_slot[ns++] = g * (W + n_tiles) + w + tile;   // an empty range wrote nothing
+  if (tid < 64) {
+    // lane g < groups: the tile's steps in group g
+    int base = 0, cnt = 0;
+    if (lane < groups && cnt_all > 0) {
+      const int* tb = tile_base + (size_t)lane * (n_tiles + 1);
+      base = tb[tile]; cnt = tb[tile + 1] - base;
     }
-    s_ns = ns;
+    int ns = 0;
+    for (int g = 0; g < groups; ++g) {
+      const int gb = __shfl(base, g), gc = __shfl(cnt, g);
+      if (gc <= 0) continue;                                         // wave-uniform
+      const int* cut = cuts + g * (W + 1);
+      for (int w0 = 0; w0 < W; w0 += 64) {
+        const int w = w0 + lane;
+        const int c0 = w < W ? cut[w] : 0, c1 = w < W ? cut[w + 1] : 0;
+        const bool hit = w < W && c0 < c1 && c0 < gb + gc && c1 > gb;     // a non-empty range that meets the tile's steps
+        const unsigned long long m = __ballot(hit);
+        if (hit) s_slot[ns + __popcll(m & ((1ull << lane) - 1))] = g * (W + n_tiles) + w + tile;
+        ns += __popcll(m);
+      }
+    }
+    if (lane == 0) s_ns = ns;
   }
   __syncthreads();
   const int ns = s_ns;
-  const int rb = TN / gridDim.y;                                   // rows of the tile this block finishes
-  const int r0 = tile * TN + blockIdx.y * rb;
-  // four output quads per thread and trip, three slots per round trip: the loads go out together (the slots were written by
-  // other XCDs a moment ago, every load is a cold round trip), summed in slot order per element.
-  constexpr int U = 4;
-  const int total = rb * OP / 4;
-  for (int e0 = tid; e0 < total; e0 += 256 * U) {
-    f4 v[U];
-    int row[U], c[U];
-    bool ok[U];
+  const int r0 = tile * TN + blockIdx.y * FIN_ROWS;
+  const int qpr = OP / 4;                                            // quads per row
+  for (int e = tid; e < FIN_ROWS * qpr; e += 256) {
+    const int rl = e / qpr, c = (e - rl * qpr) * 4, row = r0 + rl;
+    if (row >= n || c >= O) continue;
+    f4 v = cnt_all < 0 ? f4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")}      // refused tile
+                       : f4{0.f, 0.f, 0.f, 0.f};
+    const float* src = partial + (size_t)(row - tile * TN) * OP + c;
+    for (int i0 = 0; i0 < ns; i0 += FIN_WB) {
+      f4 x[FIN_WB];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = e0 + 256 * u;
-      const int rl = e / (OP / 4);
-      c[u] = (e - rl * (OP / 4)) * 4;
-      row[u] = r0 + rl;
-      ok[u] = e < total && row[u] < n && c[u] < O;
-      v[u] = cnt_all < 0 ? f4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")}      // refused tile
-                         : f4{0.f, 0.f, 0.f, 0.f};
-    }
-    constexpr int WB = 3;                                                      // slots per round trip
-    for (int i0 = 0; i0 < ns; i0 += WB) {
-      f4 x[WB][U];
-      bool live[WB];
+      for (int q = 0; q < FIN_WB; ++q)
+        x[q] = i0 + q < ns ? *reinterpret_cast<const f4*>(src + (size_t)s_slot[i0 + q] * TN * OP) : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < WB; ++q) {
-        live[q] = i0 + q < ns;
-        const int slot = s_slot[min(i0 + q, ns - 1)];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          x[q][u] = ok[u] && live[q] ? *reinterpret_cast<const f4*>(partial + ((size_t)slot * TN + (row[u] - tile * TN)) * OP + c[u])
-                                     : f4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int q = 0; q < WB; ++q) {
-        if (!live[q]) continue;                                                // wave-uniform; a skipped slot adds nothing, not + 0
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = f4{v[u][0] + x[q][u][0], v[u][1] + x[q][u][1], v[u][2] + x[q][u][2], v[u][3] + x[q][u][3]};
+      for (int q = 0; q < FIN_WB; ++q) {
+        if (i0 + q >= ns) break;                                     // uniform; a skipped slot adds nothing, not + 0
+        v = f4{v[0] + x[q][0], v[1] + x[q][1], v[2] + x[q][2], v[3] + x[q][3]};
       }
     }
+    const float sc = rowscale ? rowscale[row] : 1.0f;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!ok[u]) continue;
-      const float sc = rowscale ? rowscale[row[u]] : 1.0f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (c[u] + j < O) {
-          float y = rowscale ? __fmul_rn(v[u][j], sc) : v[u][j];
-          out[(size_t)row[u] * ldo + c[u] + j] = act == 1 ? tanhf(y) : y;
-        }
+    for (int j = 0; j < 4; ++j) {
+      if (c + j < O) {
+        const float y = rowscale ? __fmul_rn(v[j], sc) : v[j];
+        out[(size_t)row * ldo + c + j] = act == 1 ? tanhf(y) : y;
       }
     }
   }
@@ -1801,7 +1784,7 @@ int nbd_contconv_fused_f32(const float* feat, int ldf, int in_channels, const in
 #undef CC_LAUNCH
   int rc = status();
   if (rc) return rc;
-  contconv_stream_finish_kernel<<<dim3(tiles, tiles >= 64 ? 4 : 16), 256, 0, st>>>(partial, tile_nsteps, cuts, tile_base, tiles, cc_groups(n_cells), rowscale, act, out,
+  contconv_stream_finish_kernel<<<dim3(tiles, TN / FIN_ROWS), 256, 0, st>>>(partial, tile_nsteps, cuts, tile_base, tiles, cc_groups(n_cells), rowscale, act, out,
                                                                  ldo, n, out_channels, OP);
   return status();
 }
