@@ -1,6 +1,8 @@
 """ContinuousConv layer timings at BASELINE configs[3] (N = 16 384, mean radius-1 degree 32, 128 -> 128 channels,
 D = 6 and D = 4): pair lists, fused block-sparse layer, and the round-1 formulation (dense binned matrix + GEMM)
-on the same graph. HIP events, one JSON line.   python tools/bench_contconv.py [iters]"""
+on the same graph. HIP events, one JSON line.   python tools/bench_contconv.py [iters] [given|morton|random]
+(the body order: as generated, sorted along a Morton curve, or shuffled -- the radius graph's "first 32 by index" rule
+makes the edge set depend on it slightly; the question the orders answer is what spatial locality of the tiles buys)"""
 import json
 import os
 import sys
@@ -34,12 +36,22 @@ def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     n, c = 16384, 128
     p, v, m = generate_plummer(n, seed=1234)
+    order = sys.argv[2] if len(sys.argv) > 2 else "given"
+    if order == "morton":
+        q = ((p - p.min(0)) / (p.max(0) - p.min(0)) * 1023.0).astype(np.uint64)
+        key = np.zeros(n, dtype=np.uint64)
+        for b in range(10):
+            for a in range(3):
+                key |= ((q[:, a] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + a)
+        p = p[np.argsort(key, kind="stable")]
+    elif order == "random":
+        p = p[np.random.default_rng(5).permutation(n)]
     pos = torch.tensor(p * SCALE, dtype=torch.float32, device="cuda")
     torch.manual_seed(0)
     feat = torch.randn(n, c, device="cuda")
     lists = graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32)
     edges = int(lists.rowptr[-1])
-    out = {"n": n, "edges": edges, "channels": c}
+    out = {"n": n, "edges": edges, "channels": c, "order": order}
     for d in (6, 4):
         layer = contconv.ContinuousConv(c, c, d, radius=1.0, agg="mean").cuda()
         _, cmap, n_cells = layer.cells()

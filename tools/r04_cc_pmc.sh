@@ -1,10 +1,10 @@
 #!/bin/bash
-# L2 / fabric counters of the fused ContinuousConv layer (D = 6 and D = 4 launches apart).  bash tools/r04_cc_pmc.sh TAG
-R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r04pmc}
+# L2 / fabric counters of the fused ContinuousConv layer (D = 6 and D = 4 launches apart).  bash tools/r04_cc_pmc.sh TAG [given|morton|random]
+R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r04pmc}; ORDER=${2:-given}
 cd /tmp && export TMPDIR=/tmp
 i=0
 for s in "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
-  rocprofv3 --pmc $s --output-format csv -d $R/gpurun_out/${T}_$i -o run -- python3 $R/tools/bench_contconv.py 4 > $R/gpurun_out/${T}_$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $s --output-format csv -d $R/gpurun_out/${T}_$i -o run -- python3 $R/tools/bench_contconv.py 4 $ORDER > $R/gpurun_out/${T}_$i.log 2>&1 || echo "pass $i failed"
   i=$((i+1))
 done
 python3 - <<P
