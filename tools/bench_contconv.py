@@ -1,6 +1,6 @@
 """ContinuousConv layer timings at BASELINE configs[3] (N = 16 384, mean radius-1 degree 32, 128 -> 128 channels,
 D = 6 and D = 4): pair lists, fused block-sparse layer, and the round-1 formulation (dense binned matrix + GEMM)
-on the same graph. HIP events, one JSON line.   python tools/bench_contconv.py [iters] [given|morton|random]
+on the same graph. HIP events, one JSON line.   python tools/bench_contconv.py [iters] [given|morton|random|dealt]
 (the body order: as generated, sorted along a Morton curve, or shuffled -- the radius graph's "first 32 by index" rule
 makes the edge set depend on it slightly; the question the orders answer is what spatial locality of the tiles buys)"""
 import json
@@ -46,6 +46,14 @@ def main():
         p = p[np.argsort(key, kind="stable")]
     elif order == "random":
         p = p[np.random.default_rng(5).permutation(n)]
+    elif order == "dealt":       # bodies sorted by degree and dealt round-robin over the tiles of 128: every tile the same mix
+        deg = graphops.radius_lists(torch.tensor(p * SCALE, dtype=torch.float32, device="cuda"), 1.0, loop=True,
+                                    max_num_neighbors=32).deg.cpu().numpy()
+        rank = np.argsort(-deg, kind="stable")
+        tiles = n // 128
+        new_index = (np.arange(n) % tiles) * 128 + np.arange(n) // tiles      # rank r -> tile r mod tiles, slot r div tiles
+        perm = np.empty(n, dtype=np.int64); perm[new_index] = rank
+        p = p[perm]
     pos = torch.tensor(p * SCALE, dtype=torch.float32, device="cuda")
     torch.manual_seed(0)
     feat = torch.randn(n, c, device="cuda")
