@@ -1,22 +1,42 @@
-"""Host-side profile of GraphModel.predict in a rollout (one C-ABI call per prediction): cProfile over 2000 calls.
-python tools/profile_predict_host.py"""
-import cProfile, io, os, pstats, sys
+"""Host-side profile (cProfile) of the eager rollout step: Trainer.step with the published GNN / ContinuousConv models.
+   python tools/profile_predict_host.py gnn|contconv [steps]"""
+import cProfile, os, pstats, sys, io
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [os.path.join(ROOT, "nbody-deep-sim_amd"), ROOT]
+for _p in (os.path.join(ROOT, "nbody-deep-sim_amd"), ROOT):
+    sys.path.insert(0, _p)
 import torch
-import gnn
+import gnn, contconv, trainer
 from nbd.plummer import generate_plummer
-n = 4096
-torch.manual_seed(0)
-model = gnn.GraphModel(input_dim=4, node_encoder_dims=None, gnn_dim=64, message_passing_steps=2, aggr="mean",
-                       output_hiddens=None, device="cuda", neighbors=10, scale_factor=1e6)
+which = sys.argv[1] if len(sys.argv) > 1 else "gnn"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+if which == "gnn":
+    n = 4096
+    model = gnn.GraphModel(input_dim=4, gnn_dim=64, message_passing_steps=2, aggr="mean", device="cuda", neighbors=10,
+                           scale_factor=1e6).cuda().eval()
+    scale = 1.0
+else:
+    n = 16384
+    model = contconv.ContinuousConvModel(in_channels=4, out_channels=3, filter_resolution=[6, 4], radius=1.0, agg="mean",
+                                         continuous_conv_dim=128, continuous_conv_layers=2, device="cuda").cuda().eval()
+    scale = 4.599349753792708
 p, v, m = generate_plummer(n, seed=1234)
-pos = torch.tensor(p, dtype=torch.float32, device="cuda"); vel = torch.tensor(v, dtype=torch.float32, device="cuda")
-m1 = torch.tensor(m * n, dtype=torch.float32, device="cuda")[:, None]
-feat = torch.cat([vel, m1], 1)
-for _ in range(10): model.predict(pos, feat)
+pos = torch.tensor(p * scale, dtype=torch.float32, device="cuda")
+vel = torch.tensor(v, dtype=torch.float32, device="cuda")
+mass = torch.tensor(m, dtype=torch.float32, device="cuda")[:, None]
+tr = trainer.Trainer(model, None, device="cuda", dt=0.01)
+acc = torch.zeros_like(pos)
+for _ in range(20):
+    pos, vel, acc = tr.step(pos, vel, mass, acc, 0.01)
 torch.cuda.synchronize()
+import time
+t = time.perf_counter()
+for _ in range(steps):
+    pos, vel, acc = tr.step(pos, vel, mass, acc, 0.01)
+torch.cuda.synchronize()
+print("ms per eager step:", (time.perf_counter() - t) / steps * 1e3)
 pr = cProfile.Profile(); pr.enable()
-for _ in range(2000): model.predict(pos, feat)
-torch.cuda.synchronize(); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(18); print(s.getvalue())
+for _ in range(steps):
+    pos, vel, acc = tr.step(pos, vel, mass, acc, 0.01)
+torch.cuda.synchronize()
+pr.disable()
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28); print(s.getvalue()[:6000])
