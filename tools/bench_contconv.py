@@ -1,6 +1,6 @@
 """ContinuousConv layer timings at BASELINE configs[3] (N = 16 384, mean radius-1 degree 32, 128 -> 128 channels,
 D = 6 and D = 4): pair lists, fused block-sparse layer, and the round-1 formulation (dense binned matrix + GEMM)
-on the same graph. HIP events, one JSON line.   python tools/bench_contconv.py [iters] [given|morton|random|dealt]
+on the same graph. HIP events, one JSON line.   python tools/bench_contconv.py [iters] [given|morton|random|dealt|dealt_shuffled|strided]
 (the body order: as generated, sorted along a Morton curve, or shuffled -- the radius graph's "first 32 by index" rule
 makes the edge set depend on it slightly; the question the orders answer is what spatial locality of the tiles buys)"""
 import json
@@ -17,6 +17,33 @@ from nbd import graphops, nnops
 from nbd.plummer import generate_plummer
 
 SCALE = 4.599349753792708
+
+
+def ordered_bodies(p, order):
+    """The generated bodies `p` (n, 3) in another order (see the module docstring)."""
+    n = p.shape[0]
+    if order == "morton":
+        q = ((p - p.min(0)) / (p.max(0) - p.min(0)) * 1023.0).astype(np.uint64)
+        key = np.zeros(n, dtype=np.uint64)
+        for b in range(10):
+            for a in range(3):
+                key |= ((q[:, a] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + a)
+        p = p[np.argsort(key, kind="stable")]
+    elif order == "random":
+        p = p[np.random.default_rng(5).permutation(n)]
+    elif order in ("dealt", "dealt_shuffled"):       # bodies sorted by in-degree and dealt round-robin over the tiles of 128: every tile the same mix
+        rp = graphops.radius_lists(torch.tensor(p * SCALE, dtype=torch.float32, device="cuda"), 1.0, loop=True,
+                                   max_num_neighbors=32).rowptr.cpu().numpy()
+        deg = rp[1:] - rp[:-1]                       # the in-degree: the rows the layers aggregate over (uncapped: up to ~200)
+        rank = np.argsort(-deg, kind="stable")
+        tiles = n // 128
+        new_index = (np.arange(n) % tiles) * 128 + np.arange(n) // tiles      # rank r -> tile r mod tiles, slot r div tiles
+        perm = np.empty(n, dtype=np.int64); perm[new_index] = rank
+        if order == "dealt_shuffled":                # ... and in random order inside every tile (steps of mixed rows again)
+            rs = np.random.default_rng(7)
+            perm = np.concatenate([rs.permutation(perm[t * 128:(t + 1) * 128]) for t in range(tiles)])
+        p = p[perm]
+    return p
 
 
 def timeit(fn, iters):
@@ -37,28 +64,30 @@ def main():
     n, c = 16384, 128
     p, v, m = generate_plummer(n, seed=1234)
     order = sys.argv[2] if len(sys.argv) > 2 else "given"
-    if order == "morton":
-        q = ((p - p.min(0)) / (p.max(0) - p.min(0)) * 1023.0).astype(np.uint64)
-        key = np.zeros(n, dtype=np.uint64)
-        for b in range(10):
-            for a in range(3):
-                key |= ((q[:, a] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + a)
-        p = p[np.argsort(key, kind="stable")]
-    elif order == "random":
-        p = p[np.random.default_rng(5).permutation(n)]
-    elif order == "dealt":       # bodies sorted by degree and dealt round-robin over the tiles of 128: every tile the same mix
-        deg = graphops.radius_lists(torch.tensor(p * SCALE, dtype=torch.float32, device="cuda"), 1.0, loop=True,
-                                    max_num_neighbors=32).deg.cpu().numpy()
-        rank = np.argsort(-deg, kind="stable")
-        tiles = n // 128
-        new_index = (np.arange(n) % tiles) * 128 + np.arange(n) // tiles      # rank r -> tile r mod tiles, slot r div tiles
-        perm = np.empty(n, dtype=np.int64); perm[new_index] = rank
-        p = p[perm]
+    p = ordered_bodies(p, order if order != "strided" else "given")
     pos = torch.tensor(p * SCALE, dtype=torch.float32, device="cuda")
     torch.manual_seed(0)
     feat = torch.randn(n, c, device="cuda")
     lists = graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32)
     edges = int(lists.rowptr[-1])
+    if order == "strided":
+        # the SAME graph (searched in the given labels: the "first 32 by index" rule sees the caller's order) with the
+        # bodies relabelled i -> (i mod M) 128 + i div M, M = n / 128: tile t of the layers = bodies t, t + M, t + 2 M, ...
+        # (the rule lists low indices most -- in-edges per tile 690 ... 4878 in the given labels -- and a strided tile
+        # takes one body from every 128th of the index range)
+        M = n // 128
+        i = torch.arange(n, device="cuda")
+        pi = torch.where(i < 128 * M, (i % M) * 128 + i // M, i)
+        inv = torch.empty_like(pi); inv[pi] = i
+        rp = lists.rowptr.long()
+        tgt = torch.repeat_interleave(i, rp[1:] - rp[:-1])
+        src = lists.centres[:edges].long()
+        key = pi[tgt]
+        o = torch.argsort(key, stable=True)
+        lists.centres = torch.cat([pi[src][o].int(), lists.centres[edges:]]).contiguous()
+        cnt = torch.bincount(key, minlength=n)
+        lists.rowptr = torch.cat([torch.zeros(1, dtype=torch.long, device="cuda"), torch.cumsum(cnt, 0)]).int().contiguous()
+        pos, feat = pos[inv].contiguous(), feat[inv].contiguous()
     out = {"n": n, "edges": edges, "channels": c, "order": order}
     for d in (6, 4):
         layer = contconv.ContinuousConv(c, c, d, radius=1.0, agg="mean").cuda()

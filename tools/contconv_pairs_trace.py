@@ -6,12 +6,16 @@ import ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for _p in (os.path.join(ROOT, "nbody-deep-sim_amd"), ROOT):
     sys.path.insert(0, _p)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np, torch
 import contconv
 from nbd import graphops, nnops, _lib
 from nbd.plummer import generate_plummer
 n, c = 16384, 128
 p, v, m = generate_plummer(n, seed=1234)
+if len(sys.argv) > 1:                                   # body order, as tools/bench_contconv.py's
+    from bench_contconv import ordered_bodies
+    p = ordered_bodies(p, sys.argv[1])
 pos = torch.tensor(p * 4.599349753792708, dtype=torch.float32, device="cuda")
 lists = graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32)
 jobs = []
@@ -32,4 +36,9 @@ for half, sl in (("D6", slice(0, 128)), ("D4", slice(128, 256))):
     tt = t[sl]
     out[half] = {nm: [round(float((tt[:, i + 1] - tt[:, i]).mean()), 2), round(float((tt[:, i + 1] - tt[:, i]).max()), 2)] for i, nm in enumerate(names)}
     out[half]["total_mean_max"] = [round(float((tt[:, 6] - tt[:, 0]).mean()), 2), round(float((tt[:, 6] - tt[:, 0]).max()), 2)]
+if os.environ.get("NBD_PAIRS_TRACE_DUMP"):             # per tile: total us, in-edges of the tile
+    rp = lists.rowptr.cpu().numpy()
+    out["per_tile_D6_total_us"] = [round(float(x), 1) for x in (t[:128, 6] - t[:128, 0])]
+    out["per_tile_edges"] = [int(rp[min(n, 128 * (i + 1))] - rp[128 * i]) for i in range(128)]
+    out["per_tile_D6_start_us"] = [round(float(x), 1) for x in (t[:128, 0] - t[:, 0].min())]
 print(json.dumps(out))
