@@ -401,7 +401,7 @@ def contconv_pairs_inv_degree(pair_buf, n: int, edge_capacity: int, n_cells: int
 
 def contconv_pairs_stats(pair_buf, n: int, edge_capacity: int, n_cells: int) -> dict:
     """{"steps": 16-row MFMA steps the fused kernel will run over this graph, "cost": the weight its workgroup split
-    balances (sum over steps of max(96, pairs))} -- one host read-back: for reports (bench.py's executed-flop figure),
+    balances (sum over steps of max(64, pairs): CC_COST_MIN)} -- one host read-back: for reports (bench.py's executed-flop figure),
     not for the rollout loop."""
     L = _lib.lib()
     off = (ctypes.c_size_t * 9)()

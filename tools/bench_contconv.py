@@ -1,6 +1,6 @@
 """ContinuousConv layer timings at BASELINE configs[3] (N = 16 384, mean radius-1 degree 32, 128 -> 128 channels,
 D = 6 and D = 4): pair lists, fused block-sparse layer, and the round-1 formulation (dense binned matrix + GEMM)
-on the same graph. HIP events, one JSON line.   python tools/bench_contconv.py [iters] [given|morton|random|dealt|dealt_shuffled|strided]
+on the same graph. HIP events, one JSON line.   python tools/bench_contconv.py [iters] [given|morton|random|dealt|dealt_shuffled|strided|indeg_sorted]
 (the body order: as generated, sorted along a Morton curve, or shuffled -- the radius graph's "first 32 by index" rule
 makes the edge set depend on it slightly; the question the orders answer is what spatial locality of the tiles buys)"""
 import json
@@ -64,13 +64,13 @@ def main():
     n, c = 16384, 128
     p, v, m = generate_plummer(n, seed=1234)
     order = sys.argv[2] if len(sys.argv) > 2 else "given"
-    p = ordered_bodies(p, order if order != "strided" else "given")
+    p = ordered_bodies(p, order if order not in ("strided", "indeg_sorted") else "given")
     pos = torch.tensor(p * SCALE, dtype=torch.float32, device="cuda")
     torch.manual_seed(0)
     feat = torch.randn(n, c, device="cuda")
     lists = graphops.radius_lists(pos, 1.0, loop=True, max_num_neighbors=32)
     edges = int(lists.rowptr[-1])
-    if order == "strided":
+    if order in ("strided", "indeg_sorted"):
         # the SAME graph (searched in the given labels: the "first 32 by index" rule sees the caller's order) with the
         # bodies relabelled i -> (i mod M) 128 + i div M, M = n / 128: tile t of the layers = bodies t, t + M, t + 2 M, ...
         # (the rule lists low indices most -- in-edges per tile 690 ... 4878 in the given labels -- and a strided tile
@@ -78,6 +78,10 @@ def main():
         M = n // 128
         i = torch.arange(n, device="cuda")
         pi = torch.where(i < 128 * M, (i % M) * 128 + i // M, i)
+        if order == "indeg_sorted":                  # ... or by descending in-degree: dense tiles denser, sparse sparser
+            rp0 = lists.rowptr.long()
+            rank = torch.argsort(rp0[:-1] - rp0[1:], stable=True)       # ascending -(in-degree)
+            pi = torch.empty_like(i); pi[rank] = i
         inv = torch.empty_like(pi); inv[pi] = i
         rp = lists.rowptr.long()
         tgt = torch.repeat_interleave(i, rp[1:] - rp[:-1])
@@ -103,7 +107,8 @@ def main():
             layer.use_fused = False
             t_old = timeit(lambda: layer(pos, feat, lists=lists, act="tanh", wt=wt), max(iters // 4, 3))
             y_o = layer(pos, feat, lists=lists, act="tanh", wt=wt)
-        out[f"D{d}"] = {"cells": n_cells, "pairs_ms": t_pairs, "fused_layer_ms": t_fused, "binned_gemm_layer_ms": t_old,
+        st = nnops.contconv_pairs_stats(pairs[0], n, pairs[1], n_cells)
+        out[f"D{d}"] = {"cells": n_cells, "steps": st["steps"], "cost": st["cost"], "pairs_ms": t_pairs, "fused_layer_ms": t_fused, "binned_gemm_layer_ms": t_old,
                         "fused_vs_binned_max_abs_diff": float((y_f - y_o).abs().max())}
     jobs = []
     for d in (6, 4):
